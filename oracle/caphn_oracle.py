@@ -1,0 +1,376 @@
+"""CPU oracle for the hypernetwork-conditioned captioning training step.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product path (the package under
+``hypernet-image-captioning_amd/``) may import this file.  It is imported by
+``tests/``, by ``__graft_entry__.smoke()`` and by the ``cpu_baseline`` leg of
+``bench.py`` -- there only as the checker / the timed CPU baseline.
+
+It is a restatement, in plain PyTorch CPU ops on a flat dict of named tensors,
+of the algorithm the reference implements with nn.Modules.  Every function cites
+the reference file:line it follows (paths relative to the reference root).
+
+Pinning: ``tools/make_golden.py`` runs the *reference's own* modules
+(models.decoderlstm.AttentionGru / AttentionLstm, models.attention.BahdanauAttention,
+utils.flip_parameters_to_tensors / set_all_parameters) on seeded inputs and commits
+the results under ``tests/golden``; ``tests/test_oracle_golden.py`` checks this file
+against them.  The reference has no tests or golden vectors of its own.
+
+Parameter naming follows the reference's state_dict keys:
+  captioner.feature_fc.0.weight [F,D]  captioner.feature_fc.0.bias [F]
+  captioner.feature_fc.2.weight [F,F]  captioner.feature_fc.2.bias [F]
+  captioner.embed.weight [V,E]
+  captioner.fc.weight [V,H]            captioner.fc.bias [V]
+  captioner.attention.W_a.weight [H,F] captioner.attention.W_a.bias [H]
+  captioner.attention.U_a.weight [H,H] captioner.attention.U_a.bias [H]
+  captioner.attention.v_a.weight [1,H] captioner.attention.v_a.bias [1]
+  captioner.init_h.weight [H,F]        captioner.init_h.bias [H]
+  (lstm cell only) captioner.init_c.weight [H,F] captioner.init_c.bias [H]
+  hn_base.0.weight [he,he] hn_base.0.bias  hn_base.2.weight [he,he] hn_base.2.bias
+  hn_heads.{i}.0.weight [k_i,he] .0.bias   hn_heads.{i}.2.weight [w_i,k_i] .2.bias
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F_
+
+Tensor = torch.Tensor
+LRELU_SLOPE = 0.01  # nn.LeakyReLU() default, hypernet_attention.py:64,66
+
+
+# --------------------------------------------------------------------------
+# dimensions
+# --------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Dims:
+    """Shapes of one configuration.  D = encoder channels (2048), F = feature_out,
+    E = embedding_dim, H = hidden_dim, V = vocab, he = hypernet input width
+    (embed_size on the Flickr path, hyper_emb on the CC path;
+    hypernet_attention.py:57-60)."""
+    D: int = 2048
+    F: int = 200
+    E: int = 200
+    H: int = 200
+    V: int = 9684
+    he: int = 200
+    cell: str = "gru"  # "gru" (models/decoderlstm.py:32) or "lstm" (:209)
+
+    @property
+    def gates(self) -> int:
+        return 3 if self.cell == "gru" else 4
+
+    def cell_param_shapes(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        """named_parameters() order of nn.GRUCell / nn.LSTMCell, which is the order
+        the reference builds heads in (hypernet_attention.py:69) and slices theta in
+        (utils.py:47-60; order measured in SURVEY.md §8a H3)."""
+        g = self.gates * self.H
+        return [("weight_ih", (g, self.E + self.F)), ("weight_hh", (g, self.H)),
+                ("bias_ih", (g,)), ("bias_hh", (g,))]
+
+    @property
+    def theta_size(self) -> int:
+        return sum(int(np.prod(s)) for _, s in self.cell_param_shapes())
+
+
+def head_layout(dims: Dims) -> List[Tuple[int, int, int]]:
+    """(k_in, k_mid, w) of every head, following hypernet_attention.py:68-97 with
+    N = 1, M = 500.  The first branch (w < he) builds Linear(he,1)->Linear(w,w),
+    which cannot run (shape mismatch); it is unreachable for GRU/LSTM cells of
+    the supported sizes and rejected here."""
+    N, M = 1, 500
+    he = dims.he
+    out = []
+    for _, shape in dims.cell_param_shapes():
+        w = int(np.prod(shape))
+        if w < N * he:
+            raise ValueError("head rule branch 1 (w < he) is unrunnable in the reference "
+                             "(hypernet_attention.py:78-83)")
+        if w // M < N * he:
+            out.append((he, N * he, w))          # :85-90
+        else:
+            out.append((he, w // M, w))          # :91-96
+    return out
+
+
+def hypernet_param_shapes(dims: Dims) -> List[Tuple[str, Tuple[int, ...]]]:
+    he = dims.he
+    shapes = [("hn_base.0.weight", (he, he)), ("hn_base.0.bias", (he,)),
+              ("hn_base.2.weight", (he, he)), ("hn_base.2.bias", (he,))]
+    for i, (kin, kmid, w) in enumerate(head_layout(dims)):
+        shapes += [(f"hn_heads.{i}.0.weight", (kmid, kin)), (f"hn_heads.{i}.0.bias", (kmid,)),
+                   (f"hn_heads.{i}.2.weight", (w, kmid)), (f"hn_heads.{i}.2.bias", (w,))]
+    return shapes
+
+
+def decoder_param_shapes(dims: Dims) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Non-generated captioner parameters (models/decoderlstm.py:22-47)."""
+    D, F, E, H, V = dims.D, dims.F, dims.E, dims.H, dims.V
+    s = [("captioner.feature_fc.0.weight", (F, D)), ("captioner.feature_fc.0.bias", (F,)),
+         ("captioner.feature_fc.2.weight", (F, F)), ("captioner.feature_fc.2.bias", (F,)),
+         ("captioner.embed.weight", (V, E)),
+         ("captioner.fc.weight", (V, H)), ("captioner.fc.bias", (V,)),
+         ("captioner.attention.W_a.weight", (H, F)), ("captioner.attention.W_a.bias", (H,)),
+         ("captioner.attention.U_a.weight", (H, H)), ("captioner.attention.U_a.bias", (H,)),
+         ("captioner.attention.v_a.weight", (1, H)), ("captioner.attention.v_a.bias", (1,)),
+         ("captioner.init_h.weight", (H, F)), ("captioner.init_h.bias", (H,))]
+    if dims.cell == "lstm":
+        s += [("captioner.init_c.weight", (H, F)), ("captioner.init_c.bias", (H,))]
+    return s
+
+
+def init_params(dims: Dims, seed: int = 0, dtype=torch.float32) -> Dict[str, Tensor]:
+    """Deterministic, platform-stable initialisation (numpy PCG64, not torch's RNG,
+    so the GPU box regenerates bit-identical full-size parameters from a seed).
+    Distributions mirror torch defaults: Linear / cell U(-1/sqrt(fan_in), +),
+    Embedding N(0,1)."""
+    rng = np.random.default_rng(seed)
+    p: Dict[str, Tensor] = {}
+    for name, shape in decoder_param_shapes(dims) + hypernet_param_shapes(dims):
+        if name == "captioner.embed.weight":
+            a = rng.standard_normal(shape, dtype=np.float32)
+        else:
+            if name.endswith(".bias"):
+                wshape = dict(decoder_param_shapes(dims) + hypernet_param_shapes(dims))[
+                    name[:-5] + ".weight"]
+                fan_in = wshape[1]
+            else:
+                fan_in = shape[1]
+            b = 1.0 / math.sqrt(fan_in)
+            a = rng.uniform(-b, b, size=shape).astype(np.float32)
+        p[name] = torch.from_numpy(a).to(dtype)
+    return p
+
+
+def synth_batch(dims: Dims, B: int, T: int, P: int = 49, seed: int = 1234,
+                n_domains: int = 3) -> Dict[str, Tensor]:
+    """Synthetic Flickr30k-shaped batch: features relu(N(0,1))*0.45,
+    captions <s>=1 first, length ~ clip(round(N(12.9,4)),5,T), tokens uniform in
+    [7,V), </s>=2 last, <pad>=0 after; one domain per batch."""
+    rng = np.random.default_rng(seed)
+    feats = np.maximum(rng.standard_normal((B, P, dims.D), dtype=np.float32), 0) * 0.45
+    caps = np.zeros((B, T), dtype=np.int64)
+    lo = min(5, T)
+    for b in range(B):
+        L = int(np.clip(round(rng.normal(12.9, 4.0)), lo, T))
+        caps[b, 0] = 1
+        if L > 2:
+            caps[b, 1:L - 1] = rng.integers(7, dims.V, size=L - 2)
+        caps[b, L - 1] = 2
+    dom = int(rng.integers(0, n_domains))
+    return {"features": torch.from_numpy(feats), "captions": torch.from_numpy(caps),
+            "domain": dom}
+
+
+# --------------------------------------------------------------------------
+# hypernetwork (H1, H2)
+# --------------------------------------------------------------------------
+def hyper_forward(p: Dict[str, Tensor], x: Tensor, n_heads: int = 4) -> Tensor:
+    """theta = cat_i flatten(head_i(hn_base(x)))   hypernet_attention.py:111-118.
+    x: [1,he] (Flickr: embed(style_id), :139-142) or [he] (CC one-hot row,
+    cc_train_hypernet.py:142-144)."""
+    base = F_.leaky_relu(F_.linear(x, p["hn_base.0.weight"], p["hn_base.0.bias"]), LRELU_SLOPE)
+    base = F_.leaky_relu(F_.linear(base, p["hn_base.2.weight"], p["hn_base.2.bias"]), LRELU_SLOPE)
+    outs = []
+    for i in range(n_heads):
+        a = F_.leaky_relu(F_.linear(base, p[f"hn_heads.{i}.0.weight"], p[f"hn_heads.{i}.0.bias"]),
+                          LRELU_SLOPE)
+        outs.append(F_.linear(a, p[f"hn_heads.{i}.2.weight"], p[f"hn_heads.{i}.2.bias"]).flatten())
+    return torch.cat(outs, dim=0)
+
+
+def split_theta(dims: Dims, theta: Tensor) -> Dict[str, Tensor]:
+    """set_all_parameters slicing, utils.py:47-60: consecutive slices of theta[0]
+    reshaped to each parameter's shape, in registered_parameters_name order."""
+    out, off = {}, 0
+    theta = theta.reshape(-1)
+    for name, shape in dims.cell_param_shapes():
+        n = int(np.prod(shape))
+        out[name] = theta[off:off + n].reshape(shape)
+        off += n
+    assert off == theta.numel()
+    return out
+
+
+# --------------------------------------------------------------------------
+# decoder (H4-H9)
+# --------------------------------------------------------------------------
+def attention(p: Dict[str, Tensor], feats: Tensor, h: Tensor,
+              Waf: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """BahdanauAttention.forward, models/attention.py:21-46.  Waf = W_a(features)
+    is t-invariant; callers may hoist it (the reference recomputes it, :34)."""
+    if Waf is None:
+        Waf = F_.linear(feats, p["captioner.attention.W_a.weight"], p["captioner.attention.W_a.bias"])
+    uah = F_.linear(h, p["captioner.attention.U_a.weight"], p["captioner.attention.U_a.bias"])
+    e = F_.linear(torch.tanh(Waf + uah.unsqueeze(1)),
+                  p["captioner.attention.v_a.weight"], p["captioner.attention.v_a.bias"])  # [B,P,1]
+    alpha = torch.softmax(e, dim=1)
+    ctx = torch.sum(alpha * feats, dim=1)
+    return ctx, alpha.squeeze(2)
+
+
+def gru_cell(x: Tensor, h: Tensor, w: Dict[str, Tensor]) -> Tensor:
+    """nn.GRUCell arithmetic (used at models/decoderlstm.py:100), rows r,z,n."""
+    gi = F_.linear(x, w["weight_ih"], w["bias_ih"])
+    gh = F_.linear(h, w["weight_hh"], w["bias_hh"])
+    i_r, i_z, i_n = gi.chunk(3, 1)
+    h_r, h_z, h_n = gh.chunk(3, 1)
+    r = torch.sigmoid(i_r + h_r)
+    z = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    return (1 - z) * n + z * h
+
+
+def lstm_cell(x: Tensor, h: Tensor, c: Tensor, w: Dict[str, Tensor]) -> Tuple[Tensor, Tensor]:
+    """nn.LSTMCell arithmetic (models/decoderlstm.py:243), rows i,f,g,o."""
+    g = F_.linear(x, w["weight_ih"], w["bias_ih"]) + F_.linear(h, w["weight_hh"], w["bias_hh"])
+    i, f, gg, o = g.chunk(4, 1)
+    c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+    return torch.sigmoid(o) * torch.tanh(c2), c2
+
+
+def decoder_forward(dims: Dims, p: Dict[str, Tensor], cellw: Dict[str, Tensor],
+                    features: Tensor, captions: Tensor,
+                    use_sampling: Optional[Sequence[bool]] = None,
+                    sample_temp: float = 0.5, use_feature_fc: bool = True) -> Tuple[Tensor, Tensor]:
+    """AttentionGru.forward, models/decoderlstm.py:49-120 (cell == 'gru'), or the
+    same loop around an LSTMCell behind the same feature_fc (cell == 'lstm'; the
+    build's hypernet-LSTM configuration).
+
+    use_sampling[t]: the per-timestep draw ``np.random.random() < sample_prob``
+    (:80); None == all False (sample_prob = 0.0, teacher forcing).  t = 0 never
+    samples (:79).
+
+    Quirk (:82-84): at t = 0 the reference zeroes a *view* of embed[:,0,:] in place,
+    so x_0 = 0 and, because step 1 reads embed[:,0,:] again, x_1 = 0 as well.
+    """
+    B, T = captions.shape
+    if use_feature_fc:
+        f = F_.linear(features, p["captioner.feature_fc.0.weight"], p["captioner.feature_fc.0.bias"])
+        f = F_.linear(torch.relu(f), p["captioner.feature_fc.2.weight"], p["captioner.feature_fc.2.bias"])
+    else:   # reference AttentionLstm attends over the raw features (models/decoderlstm.py:242)
+        f = features
+    emb = F_.embedding(captions, p["captioner.embed.weight"])            # :62
+    mean_f = f.mean(dim=1)                                               # :133
+    h = F_.linear(mean_f, p["captioner.init_h.weight"], p["captioner.init_h.bias"])
+    c = None
+    if dims.cell == "lstm":
+        c = F_.linear(mean_f, p["captioner.init_c.weight"], p["captioner.init_c.bias"])
+    Waf = F_.linear(f, p["captioner.attention.W_a.weight"], p["captioner.attention.W_a.bias"])
+    outs, alphas = [], []
+    output = None
+    zero_x = torch.zeros(B, dims.E, dtype=f.dtype)
+    for t in range(T):
+        samp = bool(use_sampling[t]) if (use_sampling is not None and t > 0) else False
+        if not samp:
+            x = zero_x if t < 2 else emb[:, t - 1, :]                    # :82-88 + view quirk
+        else:
+            top = torch.argmax(F_.log_softmax(output / sample_temp, dim=1), dim=1)  # :91-95
+            x = F_.embedding(top, p["captioner.embed.weight"])
+        ctx, alpha = attention(p, f, h, Waf)                             # :97
+        xin = torch.cat([x, ctx], 1)                                     # :99
+        if dims.cell == "gru":
+            h = gru_cell(xin, h, cellw)                                  # :100
+        else:
+            h, c = lstm_cell(xin, h, c, cellw)
+        output = F_.linear(h, p["captioner.fc.weight"], p["captioner.fc.bias"])  # :105
+        outs.append(output)
+        alphas.append(alpha)
+    return torch.stack(outs, 1), torch.stack(alphas, 1)
+
+
+def caption_loss(logits: Tensor, captions: Tensor, pad: int = 0) -> Tensor:
+    """hypernet_attention.py:183 / cc_train_hypernet.py:153: target at step t is
+    caps[:,t]; mean over non-<pad> targets."""
+    V = logits.shape[-1]
+    return F_.cross_entropy(logits.reshape(-1, V), captions.reshape(-1).long(), ignore_index=pad)
+
+
+# --------------------------------------------------------------------------
+# full step: forward, gradients (literal + intended), clip, Adam
+# --------------------------------------------------------------------------
+TRAINABLE_DECODER = ("captioner.feature_fc.", "captioner.embed.", "captioner.fc.",
+                     "captioner.attention.", "captioner.init_h.", "captioner.init_c.")
+
+
+def trainable_names(p: Dict[str, Tensor]) -> List[str]:
+    """Optimiser parameter list, hypernet_attention.py:124-130 /
+    cc_train_hypernet.py:110-118: hn_heads, hn_base, then the captioner's
+    feature_fc, embed, fc, attention, init_h (never captioner.gru)."""
+    heads = [k for k in p if k.startswith("hn_heads.")]
+    base = [k for k in p if k.startswith("hn_base.")]
+    dec = [k for k in p if k.startswith(TRAINABLE_DECODER)]
+    return heads + base + dec
+
+
+def forward_backward(dims: Dims, p: Dict[str, Tensor], x_style: Tensor, features: Tensor,
+                     captions: Tensor, style_token: Optional[int] = None,
+                     detach_theta: bool = False):
+    """One forward + backward.  Returns (loss, logits, alphas, theta, grads) where
+    grads holds (i) the literal quantities the reference's autograd yields -- grads
+    of the non-generated captioner parameters and 'dtheta' = cat of the leaf grads of
+    the injected cell parameters (utils.py:57 makes each slice a fresh leaf) -- and,
+    unless detach_theta, (ii) the intended hypernet grads: the VJP of heads/base with
+    dtheta.  style_token: on the Flickr path x_style =
+    embed.weight[style_token][None] and the VJP also reaches that embedding row
+    (hypernet_attention.py:139-142)."""
+    q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    if style_token is not None:
+        x = q["captioner.embed.weight"][style_token].unsqueeze(0)
+    else:
+        x = x_style
+    theta = hyper_forward(q, x)
+    theta_leaf = theta.detach().clone().requires_grad_(True)             # utils.py:57
+    cellw = split_theta(dims, theta_leaf)
+    logits, alphas = decoder_forward(dims, q, cellw, features, captions)
+    loss = caption_loss(logits, captions)
+    loss.backward()
+    dtheta = theta_leaf.grad.detach().clone()
+    if not detach_theta:
+        theta.backward(dtheta)
+    grads = {k: (v.grad.detach().clone() if v.grad is not None else None) for k, v in q.items()}
+    grads["dtheta"] = dtheta
+    return loss.detach(), logits.detach(), alphas.detach(), theta.detach(), grads
+
+
+def clip_coef(grads: Sequence[Tensor], max_norm: float) -> Tuple[float, float]:
+    """torch.nn.utils.clip_grad_norm_ (gradient_clip_val=5., cc_train_hypernet.py:405):
+    total L2 norm over all grads; coef = min(1, max_norm / (norm + 1e-6))."""
+    tot = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads))
+    return tot, min(1.0, max_norm / (tot + 1e-6))
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
+              b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
+    """torch.optim.Adam single-tensor update (cc_train_hypernet.py:120 defaults),
+    in place: m,v EMA; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)."""
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def train_step(dims: Dims, p: Dict[str, Tensor], state: Dict[str, Tensor], step: int,
+               x_style: Optional[Tensor], features: Tensor, captions: Tensor,
+               lr: float = 1e-3, max_norm: float = 5.0, style_token: Optional[int] = None,
+               grads_override: Optional[Dict[str, Tensor]] = None):
+    """forward_backward -> clip -> Adam over trainable_names(p).  state holds
+    'm.<name>' / 'v.<name>'.  p and state are updated in place.  grads_override lets
+    the data-parallel tests inject already-averaged gradients."""
+    loss, logits, alphas, theta, grads = forward_backward(dims, p, x_style, features, captions,
+                                                          style_token=style_token)
+    if grads_override is not None:
+        grads = grads_override
+    names = [n for n in trainable_names(p) if grads.get(n) is not None]
+    tot, coef = clip_coef([grads[n] for n in names], max_norm)
+    for n in names:
+        if ("m." + n) not in state:
+            state["m." + n] = torch.zeros_like(p[n])
+            state["v." + n] = torch.zeros_like(p[n])
+        adam_step(p[n], grads[n] * coef, state["m." + n], state["v." + n], step, lr)
+    return loss, tot, logits, grads

@@ -1,0 +1,166 @@
+"""Pins oracle/caphn_oracle.py against golden vectors produced by the reference's own
+modules (tools/make_golden.py).  CPU only.  Tolerances: fp32, same torch build, only the
+summation order of hoisted/merged ops differs -> 2e-6 absolute on O(1) values."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import caphn_oracle as O
+from helpers import GOLDEN, TINY_DIMS, load_case, maxdiff, style_args
+
+GRU_CASES = ["gru_tiny_flickr", "gru_tiny_cc", "gru_odd_cc"]
+ATOL = 2e-6
+
+
+@pytest.mark.parametrize("name", GRU_CASES)
+def test_forward_and_grads(name):
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    loss, logits, alphas, theta, grads = O.forward_backward(dims, p, x, g["features"], g["captions"],
+                                                            style_token=tok)
+    assert maxdiff(theta, g["theta"]) < ATOL
+    assert maxdiff(logits, g["logits"]) < ATOL
+    assert maxdiff(alphas, g["alphas"]) < ATOL
+    assert abs(float(loss) - float(g["loss"])) < ATOL
+    assert maxdiff(grads["dtheta"], g["dtheta"]) < ATOL
+    n_lit = n_int = 0
+    for k, v in g.items():
+        if k.startswith("glit/"):
+            nm = k[5:]
+            if tok is not None and nm == "captioner.embed.weight":
+                continue   # the oracle returns the intended (decoder + style-row) grad for embed
+            assert maxdiff(grads[nm], v) < ATOL, nm
+            n_lit += 1
+        if k.startswith("gint/"):
+            assert maxdiff(grads[k[5:]], v) < ATOL, k
+            n_int += 1
+    assert n_lit >= 14 and n_int >= 20
+
+
+@pytest.mark.parametrize("name", GRU_CASES)
+def test_literal_detached_mode(name):
+    """detach_theta=True reproduces the reference's literal behaviour: no hypernet grads
+    (utils.py:57; meta.json hyper_grad_none_literal)."""
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    _, _, _, _, grads = O.forward_backward(dims, p, x, g["features"], g["captions"], style_token=tok,
+                                           detach_theta=True)
+    assert all(grads[k] is None for k in grads if k.startswith("hn_"))
+    assert maxdiff(grads["captioner.embed.weight"], g["glit/captioner.embed.weight"]) < ATOL
+    meta = json.load(open(os.path.join(GOLDEN, "meta.json")))
+    assert meta[name]["hyper_grad_none_literal"] is True
+    assert meta[name]["registered"] == [n for n, _ in dims.cell_param_shapes()]
+    assert meta[name]["n_set"] == dims.theta_size
+    assert [tuple(h) for h in meta[name]["heads"]] == O.head_layout(dims)
+
+
+@pytest.mark.parametrize("name", GRU_CASES)
+def test_caption_quirks(name):
+    """caps[:,0] and caps[:,T-1] never influence logits; caps[:,1] first matters at t=2
+    (models/decoderlstm.py:82-88 in-place zero of a view)."""
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    xs = p["captioner.embed.weight"][tok][None] if tok is not None else x
+    cellw = O.split_theta(dims, O.hyper_forward(p, xs))
+    base, _ = O.decoder_forward(dims, p, cellw, g["features"], g["captions"])
+    q0, _ = O.decoder_forward(dims, p, cellw, g["features"], g["captions_q0"])
+    q1, _ = O.decoder_forward(dims, p, cellw, g["features"], g["captions_q1"])
+    assert maxdiff(q0, base) == 0.0
+    assert maxdiff(g["logits_q0"], g["logits"]) == 0.0          # the reference agrees
+    assert maxdiff(q1, g["logits_q1"]) < ATOL
+    assert maxdiff(q1[:, :2], base[:, :2]) == 0.0
+    assert maxdiff(q1[:, 2], base[:, 2]) > 1e-4
+
+
+@pytest.mark.parametrize("name", GRU_CASES)
+def test_free_running(name):
+    """sample_prob=1.0: greedy argmax feedback for t>=1 (models/decoderlstm.py:89-96)."""
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    xs = p["captioner.embed.weight"][tok][None] if tok is not None else x
+    cellw = O.split_theta(dims, O.hyper_forward(p, xs))
+    T = g["captions"].shape[1]
+    logits, alphas = O.decoder_forward(dims, p, cellw, g["features"], g["captions"],
+                                       use_sampling=[True] * T)
+    assert maxdiff(logits, g["logits_free"]) < ATOL
+    assert maxdiff(alphas, g["alphas_free"]) < ATOL
+    assert torch.equal(logits.argmax(-1), g["tokens_free"])
+
+
+@pytest.mark.parametrize("name", GRU_CASES)
+def test_clip_and_adam(name):
+    """clip_coef + adam_step against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam."""
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    p2 = {k: v.clone() for k, v in p.items()}
+    state = {}
+    loss, tot, _, _ = O.train_step(dims, p2, state, 1, x, g["features"], g["captions"], lr=1e-3,
+                                   max_norm=float(g["clip_max_norm"]), style_token=tok)
+    assert abs(tot - float(g["clip_total_norm"])) < 1e-5 * max(1.0, tot)
+    for k, v in g.items():
+        if k.startswith("padam/"):
+            # d loss / d v_a.bias == 0 exactly (softmax is shift invariant): its gradient is rounding
+            # noise and Adam normalises noise to a +-lr step, so only |delta| <= 2 lr is meaningful
+            tol = 2.1e-3 if k.endswith("attention.v_a.bias") else ATOL
+            assert maxdiff(p2[k[6:]], v) < tol, k
+    if name == "gru_tiny_cc":
+        assert tot > float(g["clip_max_norm"])          # clipping really active in this case
+
+
+def test_lstm_cell_variant():
+    """Reference AttentionLstm (models/decoderlstm.py:188-261, num_features=F, p=0,
+    sample_prob=0) with hypernet-injected lstm weights."""
+    dims = TINY_DIMS["lstm_tiny"]
+    g, p = load_case("lstm_tiny")
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    theta = O.hyper_forward(q, g["x_style"])
+    assert maxdiff(theta, g["theta"]) < ATOL
+    tl = theta.detach().clone().requires_grad_(True)
+    logits, alphas = O.decoder_forward(dims, q, O.split_theta(dims, tl), g["features"], g["captions"],
+                                       use_feature_fc=False)
+    loss = O.caption_loss(logits, g["captions"])
+    loss.backward()
+    assert maxdiff(logits, g["logits"]) < ATOL
+    assert maxdiff(alphas, g["alphas"]) < ATOL
+    assert abs(float(loss) - float(g["loss"])) < ATOL
+    assert maxdiff(tl.grad, g["dtheta"]) < ATOL
+    for k, v in g.items():
+        if k.startswith("glit/"):
+            assert maxdiff(q[k[5:]].grad, v) < ATOL, k
+
+
+def test_full_size_samples():
+    """B=128,T=20 full-size reference run: sampled logits rows, argmax tokens, theta / dtheta
+    samples, gradient norms.  Parameters regenerated from the seed."""
+    path = os.path.join(GOLDEN, "gru_full.npz")
+    z = np.load(path)
+    dims = O.Dims()
+    seed, B, T, P = int(z["seed"]), int(z["B"]), int(z["T"]), int(z["P"])
+    p = O.init_params(dims, seed)
+    batch = O.synth_batch(dims, B, T, P, seed=seed + 1)
+    tok = int(z["style_token"])
+    loss, logits, alphas, theta, grads = O.forward_backward(dims, p, None, batch["features"],
+                                                            batch["captions"], style_token=tok)
+    assert abs(float(loss) - float(z["loss"])) < 5e-6
+    for i, (b, t) in enumerate(z["logit_rows_bt"]):
+        assert np.abs(logits[b, t].numpy() - z["logit_rows"][i]).max() < 5e-6
+        assert np.abs(alphas[b, t].numpy() - z["alphas_rows"][i]).max() < 1e-6
+    am = logits.argmax(-1).numpy()
+    safe = z["argmax_margin"] > 1e-5
+    assert (am[safe] == z["argmax_tokens"][safe]).all() and safe.mean() > 0.99
+    assert np.abs(theta.numpy()[z["theta_idx"]] - z["theta_vals"]).max() < 2e-6
+    assert np.abs(grads["dtheta"].numpy()[z["theta_idx"]] - z["dtheta_vals"]).max() < 2e-6
+    meta = json.load(open(os.path.join(GOLDEN, "meta.json")))
+    for k, n in meta["gru_full"]["grad_norms"].items():
+        mine = float(grads[k].double().norm())
+        assert abs(mine - n) < 1e-4 * max(n, 1e-3), (k, mine, n)
+        idx = z["gidx/" + k]
+        assert np.abs(grads[k].flatten().numpy()[idx] - z["gval/" + k]).max() < 2e-6, k

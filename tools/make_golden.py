@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Generate golden vectors under tests/golden/ by running the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference; the GPU box never sees it).
+It imports, from the reference tree:
+    models.decoderlstm.AttentionGru / AttentionLstm   (models/decoderlstm.py:11,188)
+    models.attention.BahdanauAttention                (models/attention.py:5)
+    utils.flip_parameters_to_tensors / set_all_parameters   (utils.py:24,44)
+after placing inert stub modules in sys.modules for packages that are merely not
+installed here (nltk, rouge_metric, torchvision) -- none is touched by the hot path.
+hypernet_attention.HyperNet.__init__ cannot run offline (it fetches metric scripts and
+ResNet weights, hypernet_attention.py:47,50), so its 45-line constructor rule (:55-99)
+and forward (:111-121) are restated here around the imported reference functions.
+
+Parameters come from oracle.init_params (numpy PCG64 seeds) and are LOADED INTO the
+reference modules, so reference and oracle/HIP paths compute with identical weights.
+Only data is written: inputs, parameters (tiny cases), expected outputs.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("CAPHN_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def _import_reference():
+    from transformers import BertTokenizer  # noqa: F401  (utils.py:20 imports it)
+    for name in ["nltk", "nltk.translate", "nltk.translate.bleu_score",
+                 "nltk.translate.meteor_score", "rouge_metric", "torchvision",
+                 "torchvision.models"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    for attr in ("corpus_bleu", "sentence_bleu", "SmoothingFunction"):
+        setattr(sys.modules["nltk.translate.bleu_score"], attr, None)
+    for attr in ("single_meteor_score", "meteor_score"):
+        setattr(sys.modules["nltk.translate.meteor_score"], attr, None)
+    sys.modules["rouge_metric"].PyRouge = None
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.path.insert(0, REF)
+    from models.decoderlstm import AttentionGru, AttentionLstm
+    from utils import flip_parameters_to_tensors, set_all_parameters
+    sys.path.pop(0)
+    return AttentionGru, AttentionLstm, flip_parameters_to_tensors, set_all_parameters
+
+
+AttentionGru, AttentionLstm, flip_parameters_to_tensors, set_all_parameters = _import_reference()
+sys.path.insert(0, REPO)
+from oracle import caphn_oracle as O  # noqa: E402
+
+
+def build_ref_hypernet(cell_module, he):
+    """hypernet_attention.py:55-99 restated (N=1, M=500) over cell_module.named_parameters()."""
+    N, M = 1, 500
+    hn_base = nn.Sequential(nn.Linear(he, N * he), nn.LeakyReLU(),
+                            nn.Linear(N * he, N * he), nn.LeakyReLU())
+    heads = []
+    for name, W in cell_module.named_parameters():
+        w_size = len(W.flatten())
+        if w_size < N * he:
+            heads.append(nn.Sequential(nn.Linear(N * he, N), nn.LeakyReLU(), nn.Linear(w_size, w_size)))
+        elif w_size // M < N * he:
+            heads.append(nn.Sequential(nn.Linear(N * he, N * he), nn.LeakyReLU(), nn.Linear(N * he, w_size)))
+        else:
+            heads.append(nn.Sequential(nn.Linear(N * he, w_size // M), nn.LeakyReLU(),
+                                       nn.Linear(w_size // M, w_size)))
+    return hn_base, nn.ModuleList(heads)
+
+
+def load_into(module, prefix, p):
+    sd = {k[len(prefix):]: v.clone() for k, v in p.items() if k.startswith(prefix)}
+    missing = module.load_state_dict(sd, strict=False)
+    return missing
+
+
+def ref_gru_step(dims, p, features, captions, x_style=None, style_token=None,
+                 sample_prob=0.0, want_grads=True):
+    """hypernet_attention.py:111-121 + :146,183 with reference modules."""
+    cap = AttentionGru(dims.D, dims.F, dims.E, dims.H, dims.V, p=0.0)
+    hn_base, hn_heads = build_ref_hypernet(cap.gru, dims.he)
+    order = [n for n, _ in cap.gru.named_parameters()]
+    # load shared parameters (cap.gru keeps its own init; it is overwritten by theta)
+    msd = {k[len("captioner."):]: v.clone() for k, v in p.items() if k.startswith("captioner.")}
+    res = cap.load_state_dict(msd, strict=False)
+    assert all(k.startswith("gru.") for k in res.missing_keys), res
+    assert not res.unexpected_keys, res
+    hn_base.load_state_dict({k[len("hn_base."):]: v.clone() for k, v in p.items() if k.startswith("hn_base.")})
+    hn_heads.load_state_dict({k[len("hn_heads."):]: v.clone() for k, v in p.items() if k.startswith("hn_heads.")})
+    if style_token is not None:
+        x = cap.embed(torch.tensor([style_token]))            # hypernet_attention.py:139-142
+    else:
+        x = x_style
+    base_feat = hn_base(x)
+    heads_out = torch.cat([h(base_feat).flatten() for h in hn_heads], dim=0)
+    flip_parameters_to_tensors(cap.gru)
+    n_set = set_all_parameters(cap.gru, heads_out.reshape(1, -1))
+    reg = list(cap.gru.registered_parameters_name)
+    logits, alphas = cap(features, captions.long(), sample_prob)
+    loss = F.cross_entropy(logits.view(-1, dims.V), captions.view(-1).long(), ignore_index=0)
+    out = {"theta": heads_out.detach(), "logits": logits.detach(), "alphas": alphas.detach(),
+           "loss": loss.detach(), "n_set": n_set, "order": order, "registered": reg}
+    if not want_grads:
+        return out, None
+    loss.backward()
+    lit = {"captioner." + n: q.grad.detach().clone() for n, q in cap.named_parameters()
+           if not n.startswith("gru.") and q.grad is not None}
+    hyper_none = all(q.grad is None for q in list(hn_base.parameters()) + list(hn_heads.parameters()))
+    dtheta = torch.cat([getattr(cap.gru, n).grad.flatten() for n in reg])
+    # (ii) intended grads: VJP of the hypernet with dtheta
+    heads_out.backward(dtheta)
+    intended = {}
+    for n, q in hn_base.named_parameters():
+        intended["hn_base." + n] = q.grad.detach().clone()
+    for n, q in hn_heads.named_parameters():
+        intended["hn_heads." + n] = q.grad.detach().clone()
+    if style_token is not None:
+        # embed.weight.grad now holds decoder grad + the style-row VJP
+        lit_plus = cap.embed.weight.grad.detach().clone()
+        intended["captioner.embed.weight"] = lit_plus
+    out.update({"hyper_grad_none_literal": hyper_none, "dtheta": dtheta})
+    return out, (lit, intended)
+
+
+def save_npz(path, **arrs):
+    flat = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        flat[k] = v
+    np.savez_compressed(path, **flat)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def tiny_case(name, dims, B, T, P, seed, flickr, max_norm):
+    p = O.init_params(dims, seed)
+    torch.manual_seed(seed)
+    batch = O.synth_batch(dims, B, T, P, seed=seed + 1)
+    feats, caps = batch["features"], batch["captions"]
+    if flickr:
+        style_token, x_style = 4 + batch["domain"], None
+    else:
+        style_token = None
+        x_style = torch.zeros(dims.he)
+        x_style[batch["domain"] % dims.he] = 1.0       # one-hot row, 1-D (cc_train_hypernet.py:142-144)
+    out, (lit, intended) = ref_gru_step(dims, p, feats, caps, x_style, style_token)
+    arrs = {"features": feats, "captions": caps, "style_token": np.int64(-1 if style_token is None else style_token)}
+    if x_style is not None:
+        arrs["x_style"] = x_style
+    for k, v in p.items():
+        arrs["p/" + k] = v
+    for k in ("theta", "logits", "alphas", "loss", "dtheta"):
+        arrs[k] = out[k]
+    for k, v in lit.items():
+        arrs["glit/" + k] = v
+    for k, v in intended.items():
+        arrs["gint/" + k] = v
+    # quirk vectors: caps[:,0] / caps[:,T-1] never influence logits,
+    # caps[:,1] first matters at t = 2
+    caps_a = caps.clone(); caps_a[:, 0] = (caps_a[:, 0] + 3) % dims.V; caps_a[:, T - 1] = (caps_a[:, T - 1] + 5) % dims.V
+    oa, _ = ref_gru_step(dims, p, feats, caps_a, x_style, style_token, want_grads=False)
+    caps_b = caps.clone(); caps_b[:, 1] = (caps_b[:, 1] + 7) % dims.V
+    ob, _ = ref_gru_step(dims, p, feats, caps_b, x_style, style_token, want_grads=False)
+    arrs["captions_q0"] = caps_a; arrs["logits_q0"] = oa["logits"]
+    arrs["captions_q1"] = caps_b; arrs["logits_q1"] = ob["logits"]
+    # free-running (sample_prob = 1.0 -> np.random.random() < 1.0 always true for t>=1)
+    of, _ = ref_gru_step(dims, p, feats, caps, x_style, style_token, sample_prob=1.0, want_grads=False)
+    arrs["logits_free"] = of["logits"]; arrs["alphas_free"] = of["alphas"]
+    arrs["tokens_free"] = of["logits"].argmax(-1)
+    # one clip + Adam step with torch's own implementations on the intended grads
+    names = O.trainable_names(p)
+    g_all = dict(lit); g_all.update(intended)
+    plist = []
+    for n in names:
+        q = nn.Parameter(p[n].clone()); q.grad = g_all[n].clone(); plist.append(q)
+    opt = torch.optim.Adam(plist, lr=1e-3)
+    tot = torch.nn.utils.clip_grad_norm_(plist, max_norm)
+    opt.step()
+    arrs["clip_total_norm"] = tot.detach()
+    arrs["clip_max_norm"] = np.float64(max_norm)
+    for n, q in zip(names, plist):
+        arrs["padam/" + n] = q.detach()
+    save_npz(os.path.join(OUT, name + ".npz"), **arrs)
+    return {"order": out["order"], "registered": out["registered"], "n_set": int(out["n_set"]),
+            "hyper_grad_none_literal": bool(out["hyper_grad_none_literal"]),
+            "heads": O.head_layout(dims)}
+
+
+def lstm_case(name, seed):
+    """Reference AttentionLstm (models/decoderlstm.py:188-261) at num_features = F, p = 0,
+    sample_prob = 0: pins the oracle's LSTM loop (use_feature_fc=False).  Hypernet
+    injection through flip/set_all_parameters on .lstm."""
+    dims = O.Dims(D=12, F=12, E=8, H=8, V=40, he=8, cell="lstm")
+    B, T, P = 3, 6, 5
+    p = O.init_params(dims, seed)
+    batch = O.synth_batch(dims, B, T, P, seed=seed + 1)
+    feats, caps = batch["features"], batch["captions"]
+    m = AttentionLstm(dims.F, dims.E, dims.H, dims.V, p=0.0)
+    sd = {"embeddings.weight": p["captioner.embed.weight"]}
+    for k in ("fc.weight", "fc.bias", "attention.W_a.weight", "attention.W_a.bias",
+              "attention.U_a.weight", "attention.U_a.bias", "attention.v_a.weight",
+              "attention.v_a.bias", "init_h.weight", "init_h.bias", "init_c.weight", "init_c.bias"):
+        sd[k] = p["captioner." + k]
+    res = m.load_state_dict(sd, strict=False)
+    assert all(k.startswith("lstm.") for k in res.missing_keys), res
+    hn_base, hn_heads = build_ref_hypernet(m.lstm, dims.he)
+    hn_base.load_state_dict({k[len("hn_base."):]: v.clone() for k, v in p.items() if k.startswith("hn_base.")})
+    hn_heads.load_state_dict({k[len("hn_heads."):]: v.clone() for k, v in p.items() if k.startswith("hn_heads.")})
+    x = torch.zeros(dims.he); x[batch["domain"]] = 1.0
+    theta = torch.cat([h(hn_base(x)).flatten() for h in hn_heads])
+    flip_parameters_to_tensors(m.lstm)
+    set_all_parameters(m.lstm, theta.reshape(1, -1))
+    reg = list(m.lstm.registered_parameters_name)
+    logits, alphas = m(caps, feats, 0.0)
+    loss = F.cross_entropy(logits.view(-1, dims.V), caps.view(-1), ignore_index=0)
+    loss.backward()
+    dtheta = torch.cat([getattr(m.lstm, n).grad.flatten() for n in reg])
+    arrs = {"features": feats, "captions": caps, "x_style": x, "theta": theta, "logits": logits,
+            "alphas": alphas, "loss": loss, "dtheta": dtheta}
+    for k, v in p.items():
+        arrs["p/" + k] = v
+    name_map = {"embeddings.weight": "captioner.embed.weight"}
+    for n, q in m.named_parameters():
+        if n.startswith("lstm."):
+            continue
+        arrs["glit/" + name_map.get(n, "captioner." + n)] = q.grad
+    save_npz(os.path.join(OUT, name + ".npz"), **arrs)
+    return {"registered": reg, "heads": O.head_layout(dims)}
+
+
+def full_case(name, seed):
+    """Full-size GRU (B=128,T=20,P=49,D=2048,F=E=H=200,V=9684,he=200): parameters are
+    regenerated from the seed on the test side; only samples and float64 checksums of the
+    reference's outputs are stored."""
+    dims = O.Dims()
+    B, T, P = 128, 20, 49
+    p = O.init_params(dims, seed)
+    batch = O.synth_batch(dims, B, T, P, seed=seed + 1)
+    feats, caps = batch["features"], batch["captions"]
+    style_token = 4 + batch["domain"]
+    out, (lit, intended) = ref_gru_step(dims, p, feats, caps, None, style_token)
+    rng = np.random.default_rng(seed + 2)
+    arrs = {"seed": np.int64(seed), "B": np.int64(B), "T": np.int64(T), "P": np.int64(P),
+            "style_token": np.int64(style_token), "loss": out["loss"]}
+    bt = np.stack([rng.integers(0, B, 6), rng.integers(0, T, 6)], 1)
+    arrs["logit_rows_bt"] = bt
+    arrs["logit_rows"] = np.stack([out["logits"][b, t].numpy() for b, t in bt])
+    arrs["logits_sum"] = np.float64(out["logits"].double().sum())
+    arrs["logits_sumsq"] = np.float64((out["logits"].double() ** 2).sum())
+    arrs["argmax_tokens"] = out["logits"].argmax(-1).numpy().astype(np.int32)
+    # top-2 margin, so the argmax bit-exactness test can skip genuine near-ties
+    top2 = out["logits"].topk(2, dim=-1).values
+    arrs["argmax_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+    arrs["alphas_rows"] = np.stack([out["alphas"][b, t].numpy() for b, t in bt])
+    ti = rng.integers(0, dims.theta_size, 512)
+    arrs["theta_idx"] = ti; arrs["theta_vals"] = out["theta"].numpy()[ti]
+    arrs["theta_sumsq"] = np.float64((out["theta"].double() ** 2).sum())
+    arrs["dtheta_vals"] = out["dtheta"].numpy()[ti]
+    arrs["dtheta_sumsq"] = np.float64((out["dtheta"].double() ** 2).sum())
+    gall = dict(lit); gall.update(intended)
+    norms = {}
+    for k, g in gall.items():
+        norms[k] = float(g.double().norm())
+        flat = g.flatten()
+        idx = rng.integers(0, flat.numel(), 64)
+        arrs["gidx/" + k] = idx
+        arrs["gval/" + k] = flat.numpy()[idx]
+    save_npz(os.path.join(OUT, name + ".npz"), **arrs)
+    return {"grad_norms": norms, "heads": O.head_layout(dims)}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    meta = {"torch": torch.__version__, "reference": "zacharie12/Hypernet-image-captioning @ /root/reference"}
+    tiny = O.Dims(D=32, F=16, E=16, H=16, V=50, he=16)
+    meta["gru_tiny_flickr"] = tiny_case("gru_tiny_flickr", tiny, B=3, T=6, P=7, seed=11, flickr=True, max_norm=5.0)
+    # he = 2 forces head branch 3 (w//500 >= he) for weight_ih and a 1-D CC-style x; max_norm small
+    # enough that clipping is active
+    tiny_cc = O.Dims(D=32, F=16, E=16, H=16, V=50, he=2)
+    meta["gru_tiny_cc"] = tiny_case("gru_tiny_cc", tiny_cc, B=4, T=7, P=7, seed=23, flickr=False, max_norm=0.05)
+    # odd sizes: nothing a multiple of 4/16/64
+    odd = O.Dims(D=37, F=13, E=11, H=19, V=83, he=5)
+    meta["gru_odd_cc"] = tiny_case("gru_odd_cc", odd, B=5, T=9, P=10, seed=31, flickr=False, max_norm=5.0)
+    meta["lstm_tiny"] = lstm_case("lstm_tiny", seed=41)
+    if os.environ.get("CAPHN_GOLDEN_FULL", "1") == "1":
+        meta["gru_full"] = full_case("gru_full", seed=2024)
+    with open(os.path.join(OUT, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(json.dumps({k: v for k, v in meta.items() if k != "gru_full"}, indent=1)[:2000])
+
+
+if __name__ == "__main__":
+    main()
