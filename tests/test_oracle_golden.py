@@ -102,15 +102,21 @@ def test_clip_and_adam(name):
     x, tok = style_args(g)
     p2 = {k: v.clone() for k, v in p.items()}
     state = {}
+    # feed the reference's own gradients: Adam's first step is lr * g / (|g| + eps), which turns
+    # rounding noise on near-zero gradients (|g| ~ eps = 1e-8) into visible differences, so the
+    # optimiser restatement is pinned on identical inputs
+    gold = {k[5:]: v for k, v in g.items() if k.startswith("glit/")}
+    gold.update({k[5:]: v for k, v in g.items() if k.startswith("gint/")})
     loss, tot, _, _ = O.train_step(dims, p2, state, 1, x, g["features"], g["captions"], lr=1e-3,
-                                   max_norm=float(g["clip_max_norm"]), style_token=tok)
+                                   max_norm=float(g["clip_max_norm"]), style_token=tok,
+                                   grads_override=gold)
     assert abs(tot - float(g["clip_total_norm"])) < 1e-5 * max(1.0, tot)
+    n = 0
     for k, v in g.items():
         if k.startswith("padam/"):
-            # d loss / d v_a.bias == 0 exactly (softmax is shift invariant): its gradient is rounding
-            # noise and Adam normalises noise to a +-lr step, so only |delta| <= 2 lr is meaningful
-            tol = 2.1e-3 if k.endswith("attention.v_a.bias") else ATOL
-            assert maxdiff(p2[k[6:]], v) < tol, k
+            assert maxdiff(p2[k[6:]], v) < 1e-7, k
+            n += 1
+    assert n == len(O.trainable_names(p))
     if name == "gru_tiny_cc":
         assert tot > float(g["clip_max_norm"])          # clipping really active in this case
 
