@@ -1,0 +1,136 @@
+"""ctypes binding of libcaphn.so (C ABI: include/caphn.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the HIP library is missing or a
+call fails, this module raises.  Build it with ``python __graft_entry__.py build`` (or
+``make -C hypernet-image-captioning_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcaphn.so")
+MAX_HEADS = 8
+
+c_fp = C.c_void_p  # device pointers travel as void*
+
+
+class HyperDesc(C.Structure):
+    _fields_ = [("he", C.c_int), ("n_heads", C.c_int),
+                ("k", C.c_int * MAX_HEADS), ("w", C.c_int * MAX_HEADS),
+                ("base_w0", c_fp), ("base_b0", c_fp), ("base_w2", c_fp), ("base_b2", c_fp),
+                ("w1", c_fp * MAX_HEADS), ("b1", c_fp * MAX_HEADS),
+                ("w2", c_fp * MAX_HEADS), ("b2", c_fp * MAX_HEADS)]
+
+
+class HyperGrads(C.Structure):
+    _fields_ = [("g_base_w0", c_fp), ("g_base_b0", c_fp), ("g_base_w2", c_fp), ("g_base_b2", c_fp),
+                ("g_w1", c_fp * MAX_HEADS), ("g_b1", c_fp * MAX_HEADS),
+                ("g_w2", c_fp * MAX_HEADS), ("g_b2", c_fp * MAX_HEADS),
+                ("g_x", c_fp)]
+
+
+class DecoderDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "T", "P", "D", "F", "E", "H", "V")]
+
+
+_DEC_FIELDS = ("fc0_w", "fc0_b", "fc2_w", "fc2_b", "embed_w", "out_w", "out_b", "Wa_w", "Wa_b",
+               "Ua_w", "Ua_b", "va_w", "va_b", "inith_w", "inith_b", "w_ih", "w_hh", "b_ih", "b_hh")
+
+
+class DecoderParams(C.Structure):
+    _fields_ = [(n, c_fp) for n in _DEC_FIELDS]
+
+
+class DecoderGrads(C.Structure):
+    _fields_ = [(n, c_fp) for n in _DEC_FIELDS]
+
+
+class AdamHParams(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("step", C.c_int)]
+
+
+# name -> (restype, argtypes); must list every symbol include/caphn.h declares
+SIGNATURES = {
+    "caphn_abi_version": (C.c_int, []),
+    "caphn_device_arch": (C.c_int, [C.c_char_p, C.c_int]),
+    "caphn_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_int,
+                                 c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
+    "caphn_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "caphn_colsum_f32": (C.c_int, [C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]),
+    "caphn_hyper_acts_floats": (C.c_int, [C.POINTER(HyperDesc)]),
+    "caphn_hyper_forward": (C.c_int, [C.POINTER(HyperDesc), c_fp, c_fp, c_fp, c_fp]),
+    "caphn_hyper_backward_workspace_bytes": (C.c_size_t, [C.POINTER(HyperDesc)]),
+    "caphn_hyper_backward": (C.c_int, [C.POINTER(HyperDesc), c_fp, c_fp, C.POINTER(HyperGrads), c_fp, c_fp]),
+    "caphn_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDims)]),
+    "caphn_decoder_forward": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
+                                        c_fp, c_fp, c_fp, c_fp]),
+    "caphn_decoder_backward": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
+                                         c_fp, c_fp, C.POINTER(DecoderGrads), c_fp, c_fp]),
+    "caphn_ce_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "caphn_cross_entropy_fwd_bwd": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_embedding_gather": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_embedding_scatter_add": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_sumsq_blocks": (C.c_int, [C.c_size_t]),
+    "caphn_sumsq_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp]),
+    "caphn_rank_sumsq_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, C.c_size_t, c_fp, C.c_size_t,
+                                       c_fp, c_fp, c_fp]),
+    "caphn_clip_coef": (C.c_int, [C.c_int, c_fp, c_fp, C.c_double, C.c_double, c_fp, c_fp]),
+    "caphn_adam_dense_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp, c_fp, c_fp, C.POINTER(AdamHParams), c_fp]),
+    "caphn_adam_rank_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_size_t,
+                                      c_fp, C.c_size_t, c_fp, C.POINTER(AdamHParams), c_fp]),
+    "caphn_outer_f32": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
+}
+
+_ERR = {-1: "CAPHN_EINVAL (bad argument)", -2: "CAPHN_ELAUNCH (HIP launch error)",
+        -3: "CAPHN_ELIMIT (problem exceeds a hardware limit, e.g. 160 KB LDS)"}
+
+_lib = None
+
+
+class CaphnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcaphn.so and attach signatures.  Raises if the library is missing: there is no
+    fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CaphnError(f"{LIB_PATH} not found: build the HIP extension first "
+                         "(python __graft_entry__.py build). There is no CPU/eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise CaphnError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=torch.float32, allow_none=False):
+    """Device pointer of a contiguous CUDA tensor (validated: the kernels trust shapes)."""
+    if t is None:
+        if allow_none:
+            return None
+        raise CaphnError("required tensor is None")
+    if not t.is_cuda:
+        raise CaphnError("libcaphn needs CUDA(HIP) tensors; got a CPU tensor (no CPU fallback exists)")
+    if t.dtype != dtype:
+        raise CaphnError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise CaphnError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,356 @@
+"""Tensor-level wrappers over the C ABI (include/caphn.h).  PyTorch is used for device memory
+and streams only; every arithmetic op below runs in libcaphn's hand-written HIP kernels."""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+GEMM_BIAS, GEMM_RELU, GEMM_ACCUM, GEMM_MASK = 1, 2, 4, 8
+
+
+def _f32(*shape, device):
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------ dense contraction
+def gemm(a: torch.Tensor, b: torch.Tensor, ta: bool = False, tb: bool = False,
+         bias: Optional[torch.Tensor] = None, relu: bool = False, out: Optional[torch.Tensor] = None,
+         accumulate: bool = False, mask: Optional[torch.Tensor] = None, splitk: int = 1) -> torch.Tensor:
+    """out[M,N] = epilogue(op(a) @ op(b)) on the fp32 MFMA pipe (caphn_gemm_f32).
+    a, b are 2-D row-major tensors whose last stride is 1 (leading stride = ld)."""
+    lib = L.load()
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+    N, Kb = (b.shape[0], b.shape[1]) if tb else (b.shape[1], b.shape[0])
+    if K != Kb:
+        raise L.CaphnError(f"gemm inner dims differ: {K} vs {Kb}")
+    if out is None:
+        out = _f32(M, N, device=a.device)
+        if splitk > 1:
+            out.zero_()
+    assert out.shape == (M, N) and out.stride(1) == 1
+    flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_RELU if relu else 0) | \
+            (GEMM_ACCUM if accumulate else 0) | (GEMM_MASK if mask is not None else 0)
+    for t in (a, b, out, bias, mask):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32):
+            raise L.CaphnError("gemm needs fp32 CUDA tensors")
+    rc = lib.caphn_gemm_f32(int(ta), int(tb), M, N, K, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
+                            out.data_ptr(), out.stride(0), bias.data_ptr() if bias is not None else None,
+                            mask.data_ptr() if mask is not None else None,
+                            mask.stride(0) if mask is not None else 0, flags, splitk, L.stream_ptr())
+    L.check(rc, "caphn_gemm_f32")
+    return out
+
+
+def colsum(a: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = L.load()
+    M, N = a.shape
+    ws = torch.empty(lib.caphn_colsum_workspace_bytes(M, N), dtype=torch.uint8, device=a.device)
+    if out is None:
+        out = _f32(N, device=a.device)
+    L.check(lib.caphn_colsum_f32(M, N, L.ptr(a), a.stride(0), L.ptr(out), C.c_void_p(ws.data_ptr()), L.stream_ptr()),
+            "caphn_colsum_f32")
+    return out
+
+
+# ------------------------------------------------------------------ hypernetwork
+HYPER_NAMES = ("hn_base.0.weight", "hn_base.0.bias", "hn_base.2.weight", "hn_base.2.bias")
+
+
+@dataclass
+class HyperShape:
+    """he and the (k_i, w_i) of every head (hypernet_attention.py:68-97)."""
+    he: int
+    heads: List[Tuple[int, int]]
+
+    @property
+    def theta_size(self) -> int:
+        return sum(w for _, w in self.heads)
+
+    def param_names(self) -> List[str]:
+        n = list(HYPER_NAMES)
+        for i in range(len(self.heads)):
+            n += [f"hn_heads.{i}.0.weight", f"hn_heads.{i}.0.bias", f"hn_heads.{i}.2.weight", f"hn_heads.{i}.2.bias"]
+        return n
+
+    def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        he = self.he
+        s = {"hn_base.0.weight": (he, he), "hn_base.0.bias": (he,), "hn_base.2.weight": (he, he), "hn_base.2.bias": (he,)}
+        for i, (k, w) in enumerate(self.heads):
+            s[f"hn_heads.{i}.0.weight"] = (k, he); s[f"hn_heads.{i}.0.bias"] = (k,)
+            s[f"hn_heads.{i}.2.weight"] = (w, k); s[f"hn_heads.{i}.2.bias"] = (w,)
+        return s
+
+
+def _hyper_desc(shape: HyperShape, p: Dict[str, torch.Tensor]) -> L.HyperDesc:
+    d = L.HyperDesc()
+    d.he = shape.he
+    d.n_heads = len(shape.heads)
+    exp = shape.param_shapes()
+    for n, s in exp.items():
+        if tuple(p[n].shape) != tuple(s):
+            raise L.CaphnError(f"{n}: expected shape {s}, got {tuple(p[n].shape)}")
+        L.ptr(p[n])
+    d.base_w0 = p["hn_base.0.weight"].data_ptr(); d.base_b0 = p["hn_base.0.bias"].data_ptr()
+    d.base_w2 = p["hn_base.2.weight"].data_ptr(); d.base_b2 = p["hn_base.2.bias"].data_ptr()
+    for i, (k, w) in enumerate(shape.heads):
+        d.k[i] = k; d.w[i] = w
+        d.w1[i] = p[f"hn_heads.{i}.0.weight"].data_ptr(); d.b1[i] = p[f"hn_heads.{i}.0.bias"].data_ptr()
+        d.w2[i] = p[f"hn_heads.{i}.2.weight"].data_ptr(); d.b2[i] = p[f"hn_heads.{i}.2.bias"].data_ptr()
+    return d
+
+
+def hyper_acts_layout(shape: HyperShape) -> Dict[str, Tuple[int, int]]:
+    """(offset, length) of x, a0, base and every a_i inside the acts buffer (segments padded to 4)."""
+    up4 = lambda v: (v + 3) & ~3
+    out, o = {}, 0
+    for name, n in [("x", shape.he), ("a0", shape.he), ("base", shape.he)] + \
+                   [(f"a{i}", k) for i, (k, _) in enumerate(shape.heads)]:
+        out[name] = (o, n)
+        o += up4(n)
+    out["_total"] = (0, o)
+    return out
+
+
+def hyper_forward(shape: HyperShape, p: Dict[str, torch.Tensor], x: torch.Tensor,
+                  theta: Optional[torch.Tensor] = None, acts: Optional[torch.Tensor] = None):
+    """theta = cat_i head_i(hn_base(x))   (hypernet_attention.py:111-118).  x: [he] or [1,he]."""
+    lib = L.load()
+    d = _hyper_desc(shape, p)
+    x = x.reshape(-1)
+    if x.numel() != shape.he:
+        raise L.CaphnError(f"hypernet input has {x.numel()} elements, expected {shape.he}")
+    dev = x.device
+    n_acts = lib.caphn_hyper_acts_floats(C.byref(d))
+    if theta is None:
+        theta = _f32(shape.theta_size, device=dev)
+    if acts is None:
+        acts = torch.zeros(n_acts, dtype=torch.float32, device=dev)
+    assert acts.numel() >= n_acts and theta.numel() == shape.theta_size
+    L.check(lib.caphn_hyper_forward(C.byref(d), L.ptr(x.contiguous()), L.ptr(theta), L.ptr(acts), L.stream_ptr()),
+            "caphn_hyper_forward")
+    return theta, acts
+
+
+def hyper_backward(shape: HyperShape, p: Dict[str, torch.Tensor], dtheta: torch.Tensor, acts: torch.Tensor,
+                   grads: Dict[str, torch.Tensor], want_x: bool = False,
+                   ws: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """VJP of hyper_forward.  `grads` maps parameter names to preallocated output tensors; missing
+    names are skipped (e.g. the dense 576 MB second-layer weight gradients)."""
+    lib = L.load()
+    d = _hyper_desc(shape, p)
+    g = L.HyperGrads()
+    gp = lambda n: (L.ptr(grads[n]).value if n in grads and grads[n] is not None else None)
+    g.g_base_w0 = gp("hn_base.0.weight"); g.g_base_b0 = gp("hn_base.0.bias")
+    g.g_base_w2 = gp("hn_base.2.weight"); g.g_base_b2 = gp("hn_base.2.bias")
+    for i in range(len(shape.heads)):
+        g.g_w1[i] = gp(f"hn_heads.{i}.0.weight"); g.g_b1[i] = gp(f"hn_heads.{i}.0.bias")
+        g.g_w2[i] = gp(f"hn_heads.{i}.2.weight"); g.g_b2[i] = gp(f"hn_heads.{i}.2.bias")
+    gx = _f32(shape.he, device=dtheta.device) if want_x else None
+    g.g_x = gx.data_ptr() if gx is not None else None
+    nbytes = lib.caphn_hyper_backward_workspace_bytes(C.byref(d))
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dtheta.device)
+    L.check(lib.caphn_hyper_backward(C.byref(d), L.ptr(dtheta), L.ptr(acts), C.byref(g),
+                                     C.c_void_p(ws.data_ptr()), L.stream_ptr()), "caphn_hyper_backward")
+    return gx
+
+
+# ------------------------------------------------------------------ decoder
+DEC_FIELD_TO_NAME = {
+    "fc0_w": "feature_fc.0.weight", "fc0_b": "feature_fc.0.bias",
+    "fc2_w": "feature_fc.2.weight", "fc2_b": "feature_fc.2.bias",
+    "embed_w": "embed.weight", "out_w": "fc.weight", "out_b": "fc.bias",
+    "Wa_w": "attention.W_a.weight", "Wa_b": "attention.W_a.bias",
+    "Ua_w": "attention.U_a.weight", "Ua_b": "attention.U_a.bias",
+    "va_w": "attention.v_a.weight", "va_b": "attention.v_a.bias",
+    "inith_w": "init_h.weight", "inith_b": "init_h.bias",
+    "w_ih": "gru.weight_ih", "w_hh": "gru.weight_hh", "b_ih": "gru.bias_ih", "b_hh": "gru.bias_hh",
+}
+
+
+@dataclass(frozen=True)
+class DecDims:
+    B: int
+    T: int
+    P: int
+    D: int
+    F: int
+    E: int
+    H: int
+    V: int
+
+    def c(self) -> L.DecoderDims:
+        return L.DecoderDims(self.B, self.T, self.P, self.D, self.F, self.E, self.H, self.V)
+
+    def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        D, F, E, H, V = self.D, self.F, self.E, self.H, self.V
+        return {"feature_fc.0.weight": (F, D), "feature_fc.0.bias": (F,), "feature_fc.2.weight": (F, F),
+                "feature_fc.2.bias": (F,), "embed.weight": (V, E), "fc.weight": (V, H), "fc.bias": (V,),
+                "attention.W_a.weight": (H, F), "attention.W_a.bias": (H,), "attention.U_a.weight": (H, H),
+                "attention.U_a.bias": (H,), "attention.v_a.weight": (1, H), "attention.v_a.bias": (1,),
+                "init_h.weight": (H, F), "init_h.bias": (H,),
+                "gru.weight_ih": (3 * H, E + F), "gru.weight_hh": (3 * H, H), "gru.bias_ih": (3 * H,),
+                "gru.bias_hh": (3 * H,)}
+
+
+def _dec_struct(cls, dims: DecDims, t: Dict[str, torch.Tensor]):
+    s = cls()
+    shapes = dims.param_shapes()
+    for field, name in DEC_FIELD_TO_NAME.items():
+        ten = t[name]
+        if tuple(ten.shape) != shapes[name]:
+            raise L.CaphnError(f"{name}: expected shape {shapes[name]}, got {tuple(ten.shape)}")
+        setattr(s, field, L.ptr(ten).value)
+    return s
+
+
+def decoder_workspace(dims: DecDims, device) -> torch.Tensor:
+    lib = L.load()
+    cd = dims.c()
+    n = lib.caphn_decoder_workspace_bytes(C.byref(cd))
+    if n == 0:
+        raise L.CaphnError("bad decoder dims")
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def decoder_forward(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,
+                    ws: torch.Tensor, logits: Optional[torch.Tensor] = None, alphas: Optional[torch.Tensor] = None,
+                    validate: bool = True):
+    """AttentionGru.forward(features, captions, sample_prob=0.0) (models/decoderlstm.py:49-120).
+    validate=True range-checks the token ids (one host sync); the fused engine checks its batches once."""
+    lib = L.load()
+    if tuple(features.shape) != (dims.B, dims.P, dims.D) or tuple(captions.shape) != (dims.B, dims.T):
+        raise L.CaphnError(f"features {tuple(features.shape)} / captions {tuple(captions.shape)} do not match {dims}")
+    if validate and (bool((captions < 0).any()) or bool((captions >= dims.V).any())):
+        raise IndexError("caption token id out of range")       # torch's embedding raises IndexError too
+    cd = dims.c()
+    ps = _dec_struct(L.DecoderParams, dims, params)
+    dev = features.device
+    if logits is None:
+        logits = _f32(dims.B, dims.T, dims.V, device=dev)
+    if alphas is None:
+        alphas = _f32(dims.B, dims.T, dims.P, device=dev)
+    L.check(lib.caphn_decoder_forward(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64),
+                                      L.ptr(logits), L.ptr(alphas), C.c_void_p(ws.data_ptr()), L.stream_ptr()),
+            "caphn_decoder_forward")
+    return logits, alphas
+
+
+def decoder_backward(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,
+                     dlogits: torch.Tensor, grads: Dict[str, torch.Tensor], ws: torch.Tensor,
+                     dalphas: Optional[torch.Tensor] = None) -> None:
+    """Backward of decoder_forward; `grads` holds one preallocated tensor per parameter name.
+    dlogits is consumed (may be overwritten)."""
+    lib = L.load()
+    cd = dims.c()
+    ps = _dec_struct(L.DecoderParams, dims, params)
+    gs = _dec_struct(L.DecoderGrads, dims, grads)
+    L.check(lib.caphn_decoder_backward(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64),
+                                       L.ptr(dlogits), L.ptr(dalphas, allow_none=True), C.byref(gs),
+                                       C.c_void_p(ws.data_ptr()), L.stream_ptr()), "caphn_decoder_backward")
+
+
+# ------------------------------------------------------------------ loss
+def cross_entropy_fwd_bwd(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int = 0,
+                          dlogits: Optional[torch.Tensor] = None):
+    """F.cross_entropy(logits.view(-1,V), targets.view(-1), ignore_index) and its gradient.
+    Returns (loss_out[2] = {mean loss, n_valid}, dlogits).  dlogits may alias logits."""
+    lib = L.load()
+    V = logits.shape[-1]
+    rows = logits.numel() // V
+    if dlogits is None:
+        dlogits = torch.empty_like(logits)
+    ws = torch.empty(lib.caphn_ce_workspace_bytes(rows), dtype=torch.uint8, device=logits.device)
+    out = _f32(2, device=logits.device)
+    L.check(lib.caphn_cross_entropy_fwd_bwd(rows, V, L.ptr(logits), L.ptr(targets.reshape(-1), torch.int64),
+                                            ignore_index, L.ptr(dlogits), L.ptr(out), C.c_void_p(ws.data_ptr()),
+                                            L.stream_ptr()), "caphn_cross_entropy_fwd_bwd")
+    return out, dlogits
+
+
+# ------------------------------------------------------------------ embedding
+def embedding_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    lib = L.load()
+    rows, E = idx.numel(), table.shape[1]
+    out = _f32(rows, E, device=table.device)
+    L.check(lib.caphn_embedding_gather(rows, E, L.ptr(table), L.ptr(idx.reshape(-1), torch.int64), L.ptr(out),
+                                       L.stream_ptr()), "caphn_embedding_gather")
+    return out
+
+
+def embedding_scatter_add(g: torch.Tensor, idx: torch.Tensor, table_grad: torch.Tensor) -> None:
+    lib = L.load()
+    rows, E = g.shape
+    L.check(lib.caphn_embedding_scatter_add(rows, E, L.ptr(g), L.ptr(idx.reshape(-1), torch.int64),
+                                            L.ptr(table_grad), L.stream_ptr()), "caphn_embedding_scatter_add")
+
+
+# ------------------------------------------------------------------ optimiser
+def sumsq_partials(x: torch.Tensor, partial: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = L.load()
+    nb = lib.caphn_sumsq_blocks(x.numel())
+    if partial is None:
+        partial = torch.empty(nb, dtype=torch.float64, device=x.device)
+    L.check(lib.caphn_sumsq_f32(x.numel(), L.ptr(x), L.ptr(partial, torch.float64), L.stream_ptr()), "caphn_sumsq_f32")
+    return partial[:nb]
+
+
+def rank_sumsq(gfac: torch.Tensor, afac: torch.Tensor, acc: torch.Tensor) -> None:
+    """acc[0] += || sum_r gfac[r] (x) afac[r] ||_F^2   (gfac [R,rows], afac [R,k], last stride 1)."""
+    lib = L.load()
+    R, rows = gfac.shape
+    k = afac.shape[1]
+    ws = torch.empty(2 * R * R, dtype=torch.float64, device=gfac.device)
+    L.check(lib.caphn_rank_sumsq_f32(R, rows, k, gfac.data_ptr(), gfac.stride(0), afac.data_ptr(), afac.stride(0),
+                                     L.ptr(acc, torch.float64), L.ptr(ws, torch.float64), L.stream_ptr()),
+            "caphn_rank_sumsq_f32")
+
+
+def clip_coef(partial: torch.Tensor, extra: Optional[torch.Tensor], max_norm: float, scale: float,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = L.load()
+    if out is None:
+        out = _f32(2, device=partial.device)
+    L.check(lib.caphn_clip_coef(partial.numel(), L.ptr(partial, torch.float64),
+                                L.ptr(extra, torch.float64, allow_none=True), float(max_norm), float(scale),
+                                L.ptr(out), L.stream_ptr()), "caphn_clip_coef")
+    return out
+
+
+def _hp(lr, betas, eps, step):
+    return L.AdamHParams(float(lr), float(betas[0]), float(betas[1]), float(eps), int(step))
+
+
+def adam_dense(p, m, v, g, coef, lr, step, betas=(0.9, 0.999), eps=1e-8) -> None:
+    lib = L.load()
+    hp = _hp(lr, betas, eps, step)
+    n = p.numel()
+    assert m.numel() == n and v.numel() == n and g.numel() == n
+    L.check(lib.caphn_adam_dense_f32(n, L.ptr(p), L.ptr(m), L.ptr(v), L.ptr(g), L.ptr(coef), C.byref(hp),
+                                     L.stream_ptr()), "caphn_adam_dense_f32")
+
+
+def adam_rank(W, m, v, gfac, afac, coef, lr, step, betas=(0.9, 0.999), eps=1e-8) -> None:
+    """Adam on W [rows,k] with gradient coef * sum_r gfac[r,:,None] * afac[r,None,:] (never materialised)."""
+    lib = L.load()
+    hp = _hp(lr, betas, eps, step)
+    rows, k = W.shape
+    R = gfac.shape[0]
+    assert gfac.shape[1] == rows and afac.shape[1] == k and afac.shape[0] == R
+    assert gfac.stride(1) == 1 and afac.stride(1) == 1
+    L.check(lib.caphn_adam_rank_f32(R, rows, k, L.ptr(W), L.ptr(m), L.ptr(v), gfac.data_ptr(), gfac.stride(0),
+                                    afac.data_ptr(), afac.stride(0), L.ptr(coef), C.byref(hp), L.stream_ptr()),
+            "caphn_adam_rank_f32")
+
+
+def outer(g: torch.Tensor, a: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = L.load()
+    rows, k = g.numel(), a.numel()
+    if out is None:
+        out = _f32(rows, k, device=g.device)
+    L.check(lib.caphn_outer_f32(rows, k, L.ptr(g), L.ptr(a), L.ptr(out), L.stream_ptr()), "caphn_outer_f32")
+    return out

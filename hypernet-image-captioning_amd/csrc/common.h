@@ -1,0 +1,48 @@
+// Shared device/host helpers for libcaphn (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/caphn.h"
+
+#define CAPHN_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int caphn_launch_status() {
+    return hipGetLastError() == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+}
+static inline bool caphn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline size_t caphn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device math: transcendental forms with absolute error ~1e-7 (v_exp_f32 / v_rcp_f32) ----
+__device__ __forceinline__ float caphn_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float caphn_sigmoid(float x) {
+    // 1/(1+e^-x); for x << 0 e^-x overflows to inf -> 0, for x >> 0 -> 1
+    return __builtin_amdgcn_rcpf(1.0f + caphn_exp(-x));
+}
+__device__ __forceinline__ float caphn_tanh(float x) {
+    // (1-e)/(1+e), e = exp(-2|x|) in (0,1]: no overflow, |err| ~ 1e-7
+    float ax = __builtin_fabsf(x);
+    float e = __builtin_amdgcn_exp2f(ax * -2.88539008177792681f);
+    float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    return __builtin_copysignf(t, x);
+}
+
+// ---- wave reductions (64 lanes) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}

@@ -1,0 +1,218 @@
+// fp32 GEMM on the gfx950 matrix pipe: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
+// accumulate -- bit-for-bit a k-ordered fmaf chain, so fp32 parity with the reference holds).
+//
+// One kernel template covers the three operand layouts of an nn.Linear forward/backward
+// (include/caphn.h: caphn_gemm_f32).  Tiling is for 64-lane waves: 256 threads = 4 waves in a
+// 2x2 grid, each wave owns a (BM/2)x(BN/2) block of 32x32 MFMA tiles.  K is consumed in slabs of
+// 32 staged through LDS; an operand whose K index is contiguous in memory keeps K contiguous in
+// LDS so one ds_read_b128 feeds four MFMA steps (the K order inside a slab is permuted
+// identically for A and B, which a sum does not care about).  Global loads of slab t+1 are
+// issued before the MFMAs of slab t and written to LDS after them.
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+    int M, N, K;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    const float* bias;
+    const float* mask; int ldmask;
+    int flags;
+    int splitk, slabs_per_split;
+    int vecA, vecB;
+};
+
+constexpr int BK = 32;
+constexpr int KPAD = BK + 4;      // K-contiguous LDS rows: 144 B pitch -> conflict-free ds_read_b128
+
+template <int BMN, bool KC>
+struct Tile {
+    static constexpr int NV = BMN / 32;   // float4 per thread per slab
+    static constexpr int LDM = BMN + 4;
+    static constexpr int FLOATS = KC ? BMN * KPAD : BK * LDM;
+
+    // global -> registers.  rows = extent of the M/N index, base row r0, slab start k0.
+    __device__ static __forceinline__ void load(f32x4 (&r)[NV], const float* __restrict__ G, int ld,
+                                                int rows, int K, int r0, int k0, int vec, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (KC) {               // memory [rows, K]
+                int row = r0 + (tid >> 3) + 32 * i;
+                int k = k0 + (tid & 7) * 4;
+                if (row < rows) {
+                    const float* p = G + (size_t)row * ld + k;
+                    if (vec && k + 3 < K) v = *reinterpret_cast<const f32x4*>(p);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (k + e < K) v[e] = p[e];
+                    }
+                }
+            } else {                // memory [K, rows]
+                int idx = tid + 256 * i;
+                int m = r0 + (idx % (BMN / 4)) * 4;
+                int k = k0 + idx / (BMN / 4);
+                if (k < K) {
+                    const float* p = G + (size_t)k * ld + m;
+                    if (vec && m + 3 < rows) v = *reinterpret_cast<const f32x4*>(p);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (m + e < rows) v[e] = p[e];
+                    }
+                }
+            }
+            r[i] = v;
+        }
+    }
+    __device__ static __forceinline__ void store(const f32x4 (&r)[NV], float* __restrict__ S, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (KC) {
+                int row = (tid >> 3) + 32 * i;
+                *reinterpret_cast<f32x4*>(S + row * KPAD + (tid & 7) * 4) = r[i];
+            } else {
+                int idx = tid + 256 * i;
+                *reinterpret_cast<f32x4*>(S + (idx / (BMN / 4)) * LDM + (idx % (BMN / 4)) * 4) = r[i];
+            }
+        }
+    }
+    // fragment of 4 k-steps for the 32 rows starting at `row` (lane i = lane&31, kh = lane>>5)
+    __device__ static __forceinline__ f32x4 frag(const float* __restrict__ S, int row, int kq, int kh) {
+        if (KC) return *reinterpret_cast<const f32x4*>(S + row * KPAD + kq * 8 + kh * 4);
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = S[(kq * 8 + kh * 4 + s) * LDM + row];
+        return v;
+    }
+};
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    using TileA = Tile<BM, !TA>;     // A [M,K] is K-contiguous unless transposed
+    using TileB = Tile<BN, TB>;      // B stored [N,K] (tb) is K-contiguous
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) float lds[TileA::FLOATS + TileB::FLOATS];
+    float* As = lds;
+    float* Bs = lds + TileA::FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    const int nslab_total = (g.K + BK - 1) / BK;
+    int slab0 = 0, slab1 = nslab_total;
+    if (g.splitk > 1) {
+        slab0 = blockIdx.z * g.slabs_per_split;
+        slab1 = min(nslab_total, slab0 + g.slabs_per_split);
+        if (slab0 >= slab1) return;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    f32x4 ra[TileA::NV], rb[TileB::NV];
+    TileA::load(ra, g.A, g.lda, g.M, g.K, m0, slab0 * BK, g.vecA, tid);
+    TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, slab0 * BK, g.vecB, tid);
+    TileA::store(ra, As, tid);
+    TileB::store(rb, Bs, tid);
+    __syncthreads();
+
+    for (int slab = slab0; slab < slab1; ++slab) {
+        const bool more = slab + 1 < slab1;
+        if (more) {
+            TileA::load(ra, g.A, g.lda, g.M, g.K, m0, (slab + 1) * BK, g.vecA, tid);
+            TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, (slab + 1) * BK, g.vecB, tid);
+        }
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = TileA::frag(As, wm * WM + a * 32 + li, kq, kh);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = TileB::frag(Bs, wn * WN + b * 32 + li, kq, kh);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            TileA::store(ra, As, tid);
+            TileB::store(rb, Bs, tid);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: acc register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+    const bool atomic = g.splitk > 1;
+    const bool add_bias = (g.flags & CAPHN_GEMM_BIAS) && (!atomic || blockIdx.z == 0);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = n0 + wn * WN + b * 32 + li;
+            if (col >= g.N) continue;
+            const float bv = add_bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row >= g.M) continue;
+                float v = acc[a][b][r] + bv;
+                float* c = g.C + (size_t)row * g.ldc + col;
+                if (atomic) { atomicAdd(c, v); continue; }
+                if (g.flags & CAPHN_GEMM_ACCUM) v += *c;
+                if (g.flags & CAPHN_GEMM_RELU) v = fmaxf(v, 0.f);
+                if (g.flags & CAPHN_GEMM_MASK) v = (g.mask[(size_t)row * g.ldmask + col] > 0.f) ? v : 0.f;
+                *c = v;
+            }
+        }
+}
+
+template <int BM, int BN>
+int launch_cfg(const GemmArgs& g, int ta, int tb, hipStream_t s) {
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk > 1 ? g.splitk : 1);
+    dim3 block(256);
+    if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, s, g);
+    else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, s, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, s, g);
+    return caphn_launch_status();
+}
+
+}  // namespace
+
+extern "C" int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
+                              const float* A, int lda, const float* B, int ldb,
+                              float* C, int ldc, const float* bias,
+                              const float* mask, int ldmask, int flags, int splitk,
+                              caphn_stream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return CAPHN_EINVAL;
+    if ((flags & CAPHN_GEMM_BIAS) && !bias) return CAPHN_EINVAL;
+    if ((flags & CAPHN_GEMM_MASK) && !mask) return CAPHN_EINVAL;
+    if (splitk > 1 && (flags & ~CAPHN_GEMM_BIAS)) return CAPHN_EINVAL;
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.bias = bias; g.mask = mask; g.ldmask = ldmask; g.flags = flags;
+    const int nslab = (K + BK - 1) / BK;
+    if (splitk > nslab) splitk = nslab;
+    g.splitk = splitk > 1 ? splitk : 1;
+    g.slabs_per_split = (nslab + g.splitk - 1) / g.splitk;
+    g.vecA = caphn_aligned16(A) && (lda % 4 == 0);
+    g.vecB = caphn_aligned16(B) && (ldb % 4 == 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // 128x128 tiles once they alone fill the 256 CUs; otherwise 64x64 for more workgroups
+    const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * g.splitk;
+    if (tiles128 >= 256) return launch_cfg<128, 128>(g, ta, tb, s);
+    return launch_cfg<64, 64>(g, ta, tb, s);
+}

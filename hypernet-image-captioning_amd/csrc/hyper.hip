@@ -1,0 +1,405 @@
+// Hypernetwork forward / backward for ONE input row (M = 1): every Linear is a GEMV.
+// Reference: hypernet_attention.py:55-99 (shapes), :111-118 (forward).
+//
+// The two large second-layer matrices (240000x480 and 120000x240 fp32 = 576 MB at the canonical
+// size) dominate: each is streamed from HBM exactly once per pass with 16-byte coalesced loads, one
+// wave per row (a 480-float row is 1920 contiguous bytes = two wave-wide dwordx4 loads), several
+// rows in flight per wave, wave-shuffle reduction.  Nothing here is MFMA-shaped: it is HBM-bound.
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr float LRELU = 0.01f;   // nn.LeakyReLU() default slope
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LRELU * v; }
+__device__ __forceinline__ float lrelu_grad(float post) { return post > 0.f ? 1.f : LRELU; }
+
+struct GemvJob {
+    const float* W; const float* b; const float* x; float* y;
+    int rows, k, act, vec;   // act: 1 = LeakyReLU; vec: 16-byte loads legal
+    int block0, nblocks;
+};
+struct GemvJobs { GemvJob j[CAPHN_MAX_HEADS]; int n; };
+
+// ---------------------------------------------------------------- forward: y = act(W x + b)
+// wave per row, RB rows per iteration, QMAX dwordx4 per lane per row (k <= 256*QMAX)
+template <int QMAX>
+__device__ __forceinline__ void gemv_rows_wave(const GemvJob& J, int wave_g, int nwaves, int lane) {
+    constexpr int RB = 4;
+    const int k4 = J.k >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(J.x);
+    f32x4 xr[QMAX];
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+        int c = lane + 64 * q;
+        xr[q] = c < k4 ? x4[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int r0 = wave_g * RB; r0 < J.rows; r0 += nwaves * RB) {
+        f32x4 w[RB][QMAX];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const f32x4* row = reinterpret_cast<const f32x4*>(J.W + (size_t)(r0 + i) * J.k);
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) {
+                int c = lane + 64 * q;
+                w[i][q] = (r0 + i < J.rows && c < k4) ? row[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q)
+                s += w[i][q][0] * xr[q][0] + w[i][q][1] * xr[q][1] + w[i][q][2] * xr[q][2] + w[i][q][3] * xr[q][3];
+            s = wave_sum(s);
+            if (lane == i) mine = s;
+        }
+        if (lane < RB && r0 + lane < J.rows) {
+            float v = mine + (J.b ? J.b[r0 + lane] : 0.f);
+            J.y[r0 + lane] = J.act ? lrelu(v) : v;
+        }
+    }
+}
+
+// 8 lanes per row: any k, vector or scalar loads
+__device__ __forceinline__ void gemv_rows_oct(const GemvJob& J, int lb, int tid) {
+    const int grp = tid >> 3, s = tid & 7;
+    for (int r = lb * 32 + grp; r < J.rows; r += J.nblocks * 32) {
+        const float* row = J.W + (size_t)r * J.k;
+        float sum = 0.f;
+        if (J.vec) {
+            const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+            const f32x4* x4 = reinterpret_cast<const f32x4*>(J.x);
+            for (int c = s; c < (J.k >> 2); c += 8) {
+                f32x4 a = r4[c], b = x4[c];
+                sum += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+            }
+        } else {
+            for (int c = s; c < J.k; c += 8) sum += row[c] * J.x[c];
+        }
+        sum += __shfl_xor(sum, 4, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        sum += __shfl_xor(sum, 1, 64);
+        if (s == 0) {
+            float v = sum + (J.b ? J.b[r] : 0.f);
+            J.y[r] = J.act ? lrelu(v) : v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemv_fwd_kernel(GemvJobs jobs) {
+    int ji = 0;
+    for (int i = 1; i < jobs.n; ++i) if ((int)blockIdx.x >= jobs.j[i].block0) ji = i;
+    const GemvJob& J = jobs.j[ji];
+    const int lb = blockIdx.x - J.block0, tid = threadIdx.x;
+    if (J.vec && J.k >= 128 && J.k <= 2048) {
+        const int wave_g = lb * 4 + (tid >> 6), nwaves = J.nblocks * 4, lane = tid & 63;
+        if (J.k <= 256) gemv_rows_wave<1>(J, wave_g, nwaves, lane);
+        else if (J.k <= 512) gemv_rows_wave<2>(J, wave_g, nwaves, lane);
+        else if (J.k <= 1024) gemv_rows_wave<4>(J, wave_g, nwaves, lane);
+        else gemv_rows_wave<8>(J, wave_g, nwaves, lane);
+    } else {
+        gemv_rows_oct(J, lb, tid);
+    }
+}
+
+// ---------------------------------------------------------------- backward: y = W^T d (W [rows,k])
+// large matrices: lanes own column chunks, waves own rows; per-block partial sums -> ws, then reduce
+struct GemvTJob {
+    const float* W; const float* d; float* partial;   // partial [nblocks, k]
+    int rows, k, vec, block0, nblocks;
+};
+struct GemvTJobs { GemvTJob j[CAPHN_MAX_HEADS]; int n; };
+
+template <int QMAX>
+__device__ __forceinline__ void gemv_t_wave(const GemvTJob& J, int lb, int tid, float* red /* [4][k] */) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int k4 = J.k >> 2;
+    f32x4 acc[QMAX];
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int RB = 4;
+    const int wave_g = lb * 4 + wave, nwaves = J.nblocks * 4;
+    for (int r0 = wave_g * RB; r0 < J.rows; r0 += nwaves * RB) {
+        f32x4 w[RB][QMAX];
+        float dv[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const bool ok = r0 + i < J.rows;
+            dv[i] = ok ? J.d[r0 + i] : 0.f;
+            const f32x4* row = reinterpret_cast<const f32x4*>(J.W + (size_t)(r0 + i) * J.k);
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) {
+                int c = lane + 64 * q;
+                w[i][q] = (ok && c < k4) ? row[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) acc[q] += w[i][q] * dv[i];
+    }
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+        int c = lane + 64 * q;
+        if (c < k4) *reinterpret_cast<f32x4*>(red + wave * J.k + c * 4) = acc[q];
+    }
+    __syncthreads();
+    for (int c = tid; c < J.k; c += 256)
+        J.partial[(size_t)lb * J.k + c] = red[c] + red[J.k + c] + red[2 * J.k + c] + red[3 * J.k + c];
+}
+
+__global__ __launch_bounds__(256) void gemv_t_partial_kernel(GemvTJobs jobs) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    int ji = 0;
+    for (int i = 1; i < jobs.n; ++i) if ((int)blockIdx.x >= jobs.j[i].block0) ji = i;
+    const GemvTJob& J = jobs.j[ji];
+    const int lb = blockIdx.x - J.block0, tid = threadIdx.x;
+    if (J.vec && J.k <= 2048) {
+        if (J.k <= 256) gemv_t_wave<1>(J, lb, tid, red);
+        else if (J.k <= 512) gemv_t_wave<2>(J, lb, tid, red);
+        else if (J.k <= 1024) gemv_t_wave<4>(J, lb, tid, red);
+        else gemv_t_wave<8>(J, lb, tid, red);
+    } else {
+        // generic: thread per column, this block's row range
+        const int per = (J.rows + J.nblocks - 1) / J.nblocks;
+        const int ra = lb * per, rb = min(J.rows, ra + per);
+        for (int c = tid; c < J.k; c += 256) {
+            float s = 0.f;
+            for (int r = ra; r < rb; ++r) s += J.W[(size_t)r * J.k + c] * J.d[r];
+            J.partial[(size_t)lb * J.k + c] = s;
+        }
+    }
+}
+
+// out[c] = (sum_blocks partial[blk][c]) * lrelu'(post[c]); written to up to two sinks
+struct ReduceJob { const float* partial; const float* post; float* out0; float* out1; int k, nblocks; };
+struct ReduceJobs { ReduceJob j[CAPHN_MAX_HEADS]; int n; };
+__global__ void gemv_t_reduce_kernel(ReduceJobs jobs) {
+    const ReduceJob& J = jobs.j[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= J.k) return;
+    float s = 0.f;
+    for (int b = 0; b < J.nblocks; ++b) s += J.partial[(size_t)b * J.k + c];
+    if (J.post) s *= lrelu_grad(J.post[c]);
+    if (J.out0) J.out0[c] = s;
+    if (J.out1) J.out1[c] = s;
+}
+
+// small matrices: y[c] = (sum_jobs sum_r W_j[r][c] d_j[r]) * lrelu'(post[c]); one thread per column
+struct SmallTJob { const float* W; const float* d; int rows; };
+struct SmallTArgs { SmallTJob j[CAPHN_MAX_HEADS]; int n; int k; const float* post; float* out0; float* out1; };
+__global__ void gemv_t_small_kernel(SmallTArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.k) return;
+    float s = 0.f;
+    for (int i = 0; i < a.n; ++i) {
+        const SmallTJob& J = a.j[i];
+        float t = 0.f;
+        for (int r = 0; r < J.rows; ++r) t += J.W[(size_t)r * a.k + c] * J.d[r];
+        s += t;
+    }
+    if (a.post) s *= lrelu_grad(a.post[c]);
+    if (a.out0) a.out0[c] = s;
+    if (a.out1) a.out1[c] = s;
+}
+
+// dense outer products out_j[r][c] = g_j[r] * a_j[c]
+struct OuterJob { const float* g; const float* a; float* out; int rows, k; long block0; };
+struct OuterJobs { OuterJob j[2 * CAPHN_MAX_HEADS]; int n; };
+__global__ __launch_bounds__(256) void outer_kernel(OuterJobs jobs) {
+    int ji = 0;
+    for (int i = 1; i < jobs.n; ++i) if ((long)blockIdx.x >= jobs.j[i].block0) ji = i;
+    const OuterJob& J = jobs.j[ji];
+    const size_t n = (size_t)J.rows * J.k;
+    size_t idx = ((size_t)blockIdx.x - J.block0) * 1024 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i, idx += 256)
+        if (idx < n) J.out[idx] = J.g[idx / J.k] * J.a[idx % J.k];
+}
+
+inline int gemv_blocks(int rows, int k, int vec) {
+    // enough waves to cover the chip; big jobs grid-stride
+    long want = (vec && k >= 128) ? ((long)rows + 15) / 16 : ((long)rows + 31) / 32;
+    if (want < 1) want = 1;
+    if (want > 2048) want = 2048;
+    return (int)want;
+}
+
+struct ActsLayout { int x, a0, base, a[CAPHN_MAX_HEADS], total; };
+inline ActsLayout acts_layout(const caphn_hyper_desc* d) {
+    ActsLayout L;
+    // every segment starts 16-byte aligned so the GEMVs may use dwordx4 loads of their input
+    auto up4 = [](int v) { return (v + 3) & ~3; };
+    int o = 0;
+    L.x = o; o += up4(d->he); L.a0 = o; o += up4(d->he); L.base = o; o += up4(d->he);
+    for (int i = 0; i < d->n_heads; ++i) { L.a[i] = o; o += up4(d->k[i]); }
+    L.total = o;
+    return L;
+}
+inline bool desc_ok(const caphn_hyper_desc* d) {
+    if (!d || d->he <= 0 || d->n_heads <= 0 || d->n_heads > CAPHN_MAX_HEADS) return false;
+    if (!d->base_w0 || !d->base_b0 || !d->base_w2 || !d->base_b2) return false;
+    for (int i = 0; i < d->n_heads; ++i)
+        if (d->k[i] <= 0 || d->w[i] <= 0 || !d->w1[i] || !d->b1[i] || !d->w2[i] || !d->b2[i]) return false;
+    return true;
+}
+inline int vec_ok(const float* W, const float* x, int k) {
+    return (k % 4 == 0) && caphn_aligned16(W) && caphn_aligned16(x);
+}
+
+}  // namespace
+
+extern "C" int caphn_hyper_acts_floats(const caphn_hyper_desc* d) {
+    if (!d) return CAPHN_EINVAL;
+    return acts_layout(d).total;
+}
+
+extern "C" int caphn_hyper_forward(const caphn_hyper_desc* d, const float* x, float* theta, float* acts,
+                                   caphn_stream_t stream) {
+    if (!desc_ok(d) || !x || !theta || !acts) return CAPHN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const ActsLayout L = acts_layout(d);
+    if (hipMemcpyAsync(acts + L.x, x, sizeof(float) * d->he, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return CAPHN_ELAUNCH;
+    auto one = [&](const float* W, const float* b, const float* in, float* out, int rows, int k, int act) {
+        GemvJobs jobs; jobs.n = 1;
+        GemvJob& J = jobs.j[0];
+        J.W = W; J.b = b; J.x = in; J.y = out; J.rows = rows; J.k = k; J.act = act;
+        J.vec = vec_ok(W, in, k); J.block0 = 0; J.nblocks = gemv_blocks(rows, k, J.vec);
+        hipLaunchKernelGGL(gemv_fwd_kernel, dim3(J.nblocks), dim3(256), 0, s, jobs);
+    };
+    one(d->base_w0, d->base_b0, acts + L.x, acts + L.a0, d->he, d->he, 1);
+    one(d->base_w2, d->base_b2, acts + L.a0, acts + L.base, d->he, d->he, 1);
+    {   // first layers of all heads in one launch
+        GemvJobs jobs; jobs.n = d->n_heads; int b0 = 0;
+        for (int i = 0; i < d->n_heads; ++i) {
+            GemvJob& J = jobs.j[i];
+            J.W = d->w1[i]; J.b = d->b1[i]; J.x = acts + L.base; J.y = acts + L.a[i];
+            J.rows = d->k[i]; J.k = d->he; J.act = 1; J.vec = vec_ok(J.W, J.x, J.k);
+            J.block0 = b0; J.nblocks = gemv_blocks(J.rows, J.k, J.vec); b0 += J.nblocks;
+        }
+        hipLaunchKernelGGL(gemv_fwd_kernel, dim3(b0), dim3(256), 0, s, jobs);
+    }
+    {   // second layers: theta = cat_i (W2_i a_i + b2_i)
+        GemvJobs jobs; jobs.n = d->n_heads; int b0 = 0; size_t off = 0;
+        for (int i = 0; i < d->n_heads; ++i) {
+            GemvJob& J = jobs.j[i];
+            J.W = d->w2[i]; J.b = d->b2[i]; J.x = acts + L.a[i]; J.y = theta + off; off += d->w[i];
+            J.rows = d->w[i]; J.k = d->k[i]; J.act = 0; J.vec = vec_ok(J.W, J.x, J.k);
+            J.block0 = b0; J.nblocks = gemv_blocks(J.rows, J.k, J.vec); b0 += J.nblocks;
+        }
+        hipLaunchKernelGGL(gemv_fwd_kernel, dim3(b0), dim3(256), 0, s, jobs);
+    }
+    return caphn_launch_status();
+}
+
+namespace {
+struct BwdWs { size_t partial[CAPHN_MAX_HEADS]; int nblocks[CAPHN_MAX_HEADS]; size_t dz[CAPHN_MAX_HEADS];
+               size_t dzb2, dzb0, total; };
+inline BwdWs bwd_ws(const caphn_hyper_desc* d) {
+    BwdWs w; size_t o = 0;
+    for (int i = 0; i < d->n_heads; ++i) {
+        int nb = (int)std::min<long>(1024, ((long)d->w[i] + 15) / 16);
+        if (nb < 1) nb = 1;
+        w.nblocks[i] = nb;
+        w.partial[i] = o; o += caphn_align_up((size_t)nb * d->k[i], 4);
+    }
+    for (int i = 0; i < d->n_heads; ++i) { w.dz[i] = o; o += caphn_align_up(d->k[i], 4); }
+    w.dzb2 = o; o += caphn_align_up(d->he, 4);
+    w.dzb0 = o; o += caphn_align_up(d->he, 4);
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t caphn_hyper_backward_workspace_bytes(const caphn_hyper_desc* d) {
+    if (!d || d->n_heads <= 0 || d->n_heads > CAPHN_MAX_HEADS) return 0;
+    return bwd_ws(d).total * sizeof(float);
+}
+
+extern "C" int caphn_hyper_backward(const caphn_hyper_desc* d, const float* dtheta, const float* acts,
+                                    const caphn_hyper_grads* g, void* ws_, caphn_stream_t stream) {
+    if (!desc_ok(d) || !dtheta || !acts || !g || !ws_) return CAPHN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const ActsLayout L = acts_layout(d);
+    const BwdWs W = bwd_ws(d);
+    float* ws = static_cast<float*>(ws_);
+    const int nh = d->n_heads;
+    size_t toff[CAPHN_MAX_HEADS]; { size_t o = 0; for (int i = 0; i < nh; ++i) { toff[i] = o; o += d->w[i]; } }
+
+    // bias grads of the second layers are dtheta itself
+    for (int i = 0; i < nh; ++i)
+        if (g->g_b2[i] && g->g_b2[i] != dtheta + toff[i])
+            if (hipMemcpyAsync(g->g_b2[i], dtheta + toff[i], sizeof(float) * d->w[i], hipMemcpyDeviceToDevice, s) != hipSuccess)
+                return CAPHN_ELAUNCH;
+
+    {   // da_i = W2_i^T dtheta_i  (streams the big matrices once), partial sums per block
+        GemvTJobs jobs; jobs.n = nh; int b0 = 0; int kmax = 0;
+        for (int i = 0; i < nh; ++i) {
+            GemvTJob& J = jobs.j[i];
+            J.W = d->w2[i]; J.d = dtheta + toff[i]; J.partial = ws + W.partial[i];
+            J.rows = d->w[i]; J.k = d->k[i]; J.vec = (J.k % 4 == 0) && caphn_aligned16(J.W);
+            J.block0 = b0; J.nblocks = W.nblocks[i]; b0 += J.nblocks;
+            kmax = std::max(kmax, J.k);
+        }
+        hipLaunchKernelGGL(gemv_t_partial_kernel, dim3(b0), dim3(256), sizeof(float) * 4 * kmax, s, jobs);
+        // dz_i = da_i * lrelu'(a_i)  (also the first-layer bias grad)
+        ReduceJobs rj; rj.n = nh;
+        for (int i = 0; i < nh; ++i) {
+            ReduceJob& R = rj.j[i];
+            R.partial = ws + W.partial[i]; R.post = acts + L.a[i]; R.out0 = ws + W.dz[i]; R.out1 = g->g_b1[i];
+            R.k = d->k[i]; R.nblocks = W.nblocks[i];
+        }
+        hipLaunchKernelGGL(gemv_t_reduce_kernel, dim3((kmax + 127) / 128, nh), dim3(128), 0, s, rj);
+    }
+    {   // dbase = sum_i W1_i^T dz_i ; dzb2 = dbase * lrelu'(base)
+        SmallTArgs a; a.n = nh; a.k = d->he; a.post = acts + L.base; a.out0 = ws + W.dzb2; a.out1 = g->g_base_b2;
+        for (int i = 0; i < nh; ++i) { a.j[i].W = d->w1[i]; a.j[i].d = ws + W.dz[i]; a.j[i].rows = d->k[i]; }
+        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(64), 0, s, a);
+    }
+    {   // da0 = Wb2^T dzb2 ; dzb0 = da0 * lrelu'(a0)
+        SmallTArgs a; a.n = 1; a.k = d->he; a.post = acts + L.a0; a.out0 = ws + W.dzb0; a.out1 = g->g_base_b0;
+        a.j[0].W = d->base_w2; a.j[0].d = ws + W.dzb2; a.j[0].rows = d->he;
+        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(64), 0, s, a);
+    }
+    if (g->g_x) {   // dx = Wb0^T dzb0
+        SmallTArgs a; a.n = 1; a.k = d->he; a.post = nullptr; a.out0 = g->g_x; a.out1 = nullptr;
+        a.j[0].W = d->base_w0; a.j[0].d = ws + W.dzb0; a.j[0].rows = d->he;
+        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(64), 0, s, a);
+    }
+    {   // dense weight grads (rank-1 outer products)
+        OuterJobs oj; oj.n = 0; long b0 = 0;
+        auto add = [&](const float* gv, const float* av, float* out, int rows, int k) {
+            if (!out) return;
+            OuterJob& J = oj.j[oj.n++];
+            J.g = gv; J.a = av; J.out = out; J.rows = rows; J.k = k; J.block0 = b0;
+            b0 += ((long)rows * k + 1023) / 1024;
+        };
+        add(ws + W.dzb0, acts + L.x, g->g_base_w0, d->he, d->he);
+        add(ws + W.dzb2, acts + L.a0, g->g_base_w2, d->he, d->he);
+        for (int i = 0; i < nh; ++i) add(ws + W.dz[i], acts + L.base, g->g_w1[i], d->k[i], d->he);
+        if (oj.n) hipLaunchKernelGGL(outer_kernel, dim3((unsigned)b0), dim3(256), 0, s, oj);
+        // second-layer weight grads only when asked for (dense 576 MB at the canonical size)
+        for (int i = 0; i < nh; ++i)
+            if (g->g_w2[i]) {
+                OuterJobs o2; o2.n = 1;
+                OuterJob& J = o2.j[0];
+                J.g = dtheta + toff[i]; J.a = acts + L.a[i]; J.out = g->g_w2[i]; J.rows = d->w[i]; J.k = d->k[i]; J.block0 = 0;
+                long nb = ((long)J.rows * J.k + 1023) / 1024;
+                hipLaunchKernelGGL(outer_kernel, dim3((unsigned)nb), dim3(256), 0, s, o2);
+            }
+    }
+    return caphn_launch_status();
+}
+
+extern "C" int caphn_outer_f32(int rows, int k, const float* gv, const float* av, float* out, caphn_stream_t stream) {
+    if (rows <= 0 || k <= 0 || !gv || !av || !out) return CAPHN_EINVAL;
+    OuterJobs o2; o2.n = 1;
+    OuterJob& J = o2.j[0];
+    J.g = gv; J.a = av; J.out = out; J.rows = rows; J.k = k; J.block0 = 0;
+    long nb = ((long)rows * k + 1023) / 1024;
+    hipLaunchKernelGGL(outer_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), o2);
+    return caphn_launch_status();
+}

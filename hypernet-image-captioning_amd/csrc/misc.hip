@@ -1,0 +1,374 @@
+// Loss, bias-gradient column sums, embedding gather/scatter, gradient-norm clipping and Adam.
+// All of these are HBM-bound streams: 16-byte coalesced accesses, grid-stride, no MFMA.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// ------------------------------------------------------------------ cross entropy (fwd + bwd)
+// F.cross_entropy(logits.view(-1,V), caps.view(-1), ignore_index)   hypernet_attention.py:183
+// One workgroup per row: max, sum-exp, then d logits = (softmax - onehot) / n_valid.
+__global__ __launch_bounds__(256) void ce_count_kernel(int rows, const int64_t* __restrict__ tgt, int64_t ignore, float* nvalid) {
+    __shared__ int cnt[4];
+    int c = 0;
+    for (int i = threadIdx.x; i < rows; i += 256) c += (tgt[i] != ignore);
+    float cf = wave_sum((float)c);
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = (int)cf;
+    __syncthreads();
+    if (threadIdx.x == 0) nvalid[0] = (float)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+}
+
+__global__ __launch_bounds__(256) void ce_row_kernel(int V, const float* logits, const int64_t* __restrict__ tgt,
+                                                     int64_t ignore, const float* __restrict__ nvalid,
+                                                     float* dlogits, float* __restrict__ row_loss, int vec) {
+    __shared__ float red[4];
+    __shared__ float bc[2];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* x = logits + (size_t)row * V;
+    float* dx = dlogits + (size_t)row * V;
+    const int64_t t = tgt[row];
+    if (t == ignore) {                       // ignored rows contribute neither loss nor gradient
+        for (int i = tid; i < V; i += 256) dx[i] = 0.f;
+        if (tid == 0) row_loss[row] = 0.f;
+        return;
+    }
+    const float xt = x[t];                   // read before anybody overwrites (dlogits may alias logits)
+    float m = -INFINITY;
+    if (vec) { const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        for (int i = tid; i < (V >> 2); i += 256) { f32x4 v = x4[i]; m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3])); } }
+    else for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) bc[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    m = bc[0];
+    float s = 0.f;
+    if (vec) { const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        for (int i = tid; i < (V >> 2); i += 256) { f32x4 v = x4[i];
+            s += caphn_exp(v[0] - m) + caphn_exp(v[1] - m) + caphn_exp(v[2] - m) + caphn_exp(v[3] - m); } }
+    else for (int i = tid; i < V; i += 256) s += caphn_exp(x[i] - m);
+    s = wave_sum(s);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) bc[1] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    s = bc[1];
+    const float inv = 1.0f / s, scale = 1.0f / nvalid[0];
+    if (vec) { const f32x4* x4 = reinterpret_cast<const f32x4*>(x); f32x4* d4 = reinterpret_cast<f32x4*>(dx);
+        for (int i = tid; i < (V >> 2); i += 256) { f32x4 v = x4[i], o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (caphn_exp(v[e] - m) * inv - ((int64_t)(4 * i + e) == t ? 1.f : 0.f)) * scale;
+            d4[i] = o; } }
+    else for (int i = tid; i < V; i += 256) dx[i] = (caphn_exp(x[i] - m) * inv - ((int64_t)i == t ? 1.f : 0.f)) * scale;
+    if (tid == 0) row_loss[row] = (logf(s) + m - xt);
+}
+
+__global__ __launch_bounds__(256) void ce_finish_kernel(int rows, const float* __restrict__ row_loss, const float* nvalid, float* out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < rows; i += 256) s += (double)row_loss[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { out[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)nvalid[0]); out[1] = nvalid[0]; }
+}
+
+// ------------------------------------------------------------------ column sums
+// stage 1: part[s][n] = sum over row slice s ; stage 2: out[n] = sum_s part[s][n]
+__global__ __launch_bounds__(256) void colsum_part_kernel(int M, int N, const float* __restrict__ A, int lda, float* __restrict__ part, int rows_per) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int m = m0;
+    for (; m + 3 < m1; m += 4) {
+        s0 += A[(size_t)m * lda + n]; s1 += A[(size_t)(m + 1) * lda + n];
+        s2 += A[(size_t)(m + 2) * lda + n]; s3 += A[(size_t)(m + 3) * lda + n];
+    }
+    for (; m < m1; ++m) s0 += A[(size_t)m * lda + n];
+    part[(size_t)blockIdx.y * N + n] = (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(int S, int N, const float* __restrict__ part, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += part[(size_t)i * N + n];
+    out[n] = s;
+}
+inline int colsum_slices(int M, int N) {
+    const int colblocks = (N + 255) / 256;
+    int S = 1024 / colblocks;            // aim at ~1024 workgroups
+    if (S < 1) S = 1;
+    if (S > (M + 7) / 8) S = (M + 7) / 8;
+    if (S < 1) S = 1;
+    return S;
+}
+
+// ------------------------------------------------------------------ embedding
+__global__ __launch_bounds__(256) void embed_gather_kernel(int rows, int E, const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ out) {
+    const int r = blockIdx.x;
+    const int64_t id = idx[r];
+    for (int e = threadIdx.x; e < E; e += 256) out[(size_t)r * E + e] = id < 0 ? 0.f : table[(size_t)id * E + e];
+}
+__global__ __launch_bounds__(256) void embed_scatter_kernel(int rows, int E, const float* __restrict__ g, const int64_t* __restrict__ idx, float* __restrict__ tg) {
+    const int r = blockIdx.x;
+    const int64_t id = idx[r];
+    if (id < 0) return;
+    for (int e = threadIdx.x; e < E; e += 256) atomicAdd(&tg[(size_t)id * E + e], g[(size_t)r * E + e]);
+}
+
+// ------------------------------------------------------------------ gradient norm
+constexpr int SUMSQ_CHUNK = 256 * 4 * 8;   // elements per workgroup
+__global__ __launch_bounds__(256) void sumsq_kernel(size_t n, const float* __restrict__ x, double* __restrict__ partial, int vec) {
+    __shared__ double red[4];
+    const size_t base = (size_t)blockIdx.x * SUMSQ_CHUNK;
+    float s = 0.f;
+    if (vec && base + SUMSQ_CHUNK <= n) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x + base);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { f32x4 v = x4[threadIdx.x + 256 * i]; s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+    } else {
+        for (size_t i = base + threadIdx.x; i < n && i < base + SUMSQ_CHUNK; i += 256) s += x[i] * x[i];
+    }
+    double d = wave_sum_d((double)s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// Gram matrices of R rank-1 factors: ws[r*R+s] = g_r . g_s ; ws[R*R + r*R+s] = a_r . a_s
+__global__ __launch_bounds__(256) void rank_gram_kernel(int R, int rows, int k, const float* __restrict__ gfac, size_t ldg,
+                                                        const float* __restrict__ afac, size_t lda, double* __restrict__ ws) {
+    __shared__ double red[4];
+    const int pair = blockIdx.x, which = blockIdx.y;      // which: 0 = g, 1 = a
+    const int r = pair / R, s = pair % R;
+    const float* u = which ? afac + (size_t)r * lda : gfac + (size_t)r * ldg;
+    const float* v = which ? afac + (size_t)s * lda : gfac + (size_t)s * ldg;
+    const int n = which ? k : rows;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += (double)u[i] * (double)v[i];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[(size_t)which * R * R + pair] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void rank_gram_finish_kernel(int R, const double* __restrict__ ws, double* acc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < R * R; ++i) t += ws[i] * ws[R * R + i];
+        acc[0] += t;
+    }
+}
+__global__ __launch_bounds__(256) void clip_coef_kernel(int nparts, const double* __restrict__ partial, const double* extra,
+                                                        double max_norm, double scale, float* coef_out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += partial[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = red[0] + red[1] + red[2] + red[3] + (extra ? extra[0] : 0.0);
+        double norm = scale * sqrt(tot);
+        double c = max_norm / (norm + 1e-6);          // torch.nn.utils.clip_grad_norm_
+        if (c > 1.0) c = 1.0;
+        coef_out[0] = (float)(scale * c);
+        coef_out[1] = (float)norm;
+    }
+}
+
+// ------------------------------------------------------------------ Adam (torch.optim.Adam, single-tensor form)
+struct AdamK { float lr_bc1, b1, b2, eps, sqrt_bc2; };
+__device__ __forceinline__ float adam_elem(float p, float g, float& m, float& v, const AdamK& k) {
+    m = m + (g - m) * (1.0f - k.b1);                       // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * k.b2 + (1.0f - k.b2) * g * g;                  // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+    const float denom = sqrtf(v) / k.sqrt_bc2 + k.eps;     // (sqrt(v) / sqrt(bc2)).add_(eps)
+    return p - k.lr_bc1 * (m / denom);                     // addcdiv_(m, denom, -lr / bc1)
+}
+__global__ __launch_bounds__(256) void adam_dense_kernel(size_t n, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                         const float* __restrict__ g, const float* __restrict__ coef, AdamK k, int vec) {
+    const float c = coef[0];
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (vec) {
+        f32x4* p4 = reinterpret_cast<f32x4*>(p); f32x4* m4 = reinterpret_cast<f32x4*>(m); f32x4* v4 = reinterpret_cast<f32x4*>(v);
+        const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+        const size_t n4 = n >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            f32x4 pp = p4[i], mm = m4[i], vv = v4[i], gg = g4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float me = mm[e], ve = vv[e]; pp[e] = adam_elem(pp[e], gg[e] * c, me, ve, k); mm[e] = me; vv[e] = ve; }
+            p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        }
+        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            float me = m[i], ve = v[i]; p[i] = adam_elem(p[i], g[i] * c, me, ve, k); m[i] = me; v[i] = ve;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            float me = m[i], ve = v[i]; p[i] = adam_elem(p[i], g[i] * c, me, ve, k); m[i] = me; v[i] = ve;
+        }
+    }
+}
+
+// W,m,v [rows,k]; grad[row][col] = coef * sum_r gfac[r][row] * afac[r][col].  One wave per row
+// (row-contiguous dwordx4 streams of W, m and v: read 12 B, write 12 B per element).
+constexpr int RMAX = 8;
+template <int QMAX>
+__device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W, float* m, float* v,
+                                               const float* gfac, size_t ldg, const float* afac, size_t lda,
+                                               float c, const AdamK& K, int wave_g, int nwaves, int lane) {
+    const int k4 = k >> 2;
+    for (int row = wave_g; row < rows; row += nwaves) {
+        float gr[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) gr[r] = r < R ? gfac[(size_t)r * ldg + row] * c : 0.f;
+        f32x4* W4 = reinterpret_cast<f32x4*>(W + (size_t)row * k);
+        f32x4* m4 = reinterpret_cast<f32x4*>(m + (size_t)row * k);
+        f32x4* v4 = reinterpret_cast<f32x4*>(v + (size_t)row * k);
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) {
+            const int cidx = lane + 64 * q;
+            if (cidx < k4) {
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r)
+                    if (r < R) g += reinterpret_cast<const f32x4*>(afac + (size_t)r * lda)[cidx] * gr[r];
+                f32x4 pp = W4[cidx], mm = m4[cidx], vv = v4[cidx];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float me = mm[e], ve = vv[e]; pp[e] = adam_elem(pp[e], g[e], me, ve, K); mm[e] = me; vv[e] = ve; }
+                W4[cidx] = pp; m4[cidx] = mm; v4[cidx] = vv;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void adam_rank_kernel(int R, int rows, int k, float* W, float* m, float* v,
+                                                        const float* gfac, size_t ldg, const float* afac, size_t lda,
+                                                        const float* coef, AdamK K, int vec) {
+    const float c = coef[0];
+    if (vec && k <= 2048) {
+        const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4, lane = threadIdx.x & 63;
+        if (k <= 256) adam_rank_rows<1>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
+        else if (k <= 512) adam_rank_rows<2>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
+        else if (k <= 1024) adam_rank_rows<4>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
+        else adam_rank_rows<8>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
+    } else {
+        const size_t n = (size_t)rows * k, stride = (size_t)gridDim.x * 256;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const size_t row = i / k, col = i % k;
+            float g = 0.f;
+            for (int r = 0; r < R; ++r) g += gfac[(size_t)r * ldg + row] * afac[(size_t)r * lda + col];
+            float me = m[i], ve = v[i]; W[i] = adam_elem(W[i], g * c, me, ve, K); m[i] = me; v[i] = ve;
+        }
+    }
+}
+
+inline AdamK make_adam(const caphn_adam_hparams* hp) {
+    AdamK k;
+    const double bc1 = 1.0 - pow((double)hp->beta1, (double)hp->step);
+    const double bc2 = 1.0 - pow((double)hp->beta2, (double)hp->step);
+    k.lr_bc1 = (float)((double)hp->lr / bc1);
+    k.b1 = hp->beta1; k.b2 = hp->beta2; k.eps = hp->eps;
+    k.sqrt_bc2 = (float)sqrt(bc2);
+    return k;
+}
+
+}  // namespace
+
+extern "C" size_t caphn_ce_workspace_bytes(int rows) { return sizeof(float) * (size_t)(rows + 4); }
+
+extern "C" int caphn_cross_entropy_fwd_bwd(int rows, int V, const float* logits, const int64_t* targets,
+                                           int64_t ignore_index, float* dlogits, float* loss_out,
+                                           void* ws, caphn_stream_t stream) {
+    if (rows <= 0 || V <= 0 || !logits || !targets || !dlogits || !loss_out || !ws) return CAPHN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* nvalid = static_cast<float*>(ws);
+    float* row_loss = nvalid + 4;
+    const int vec = (V % 4 == 0) && caphn_aligned16(logits) && caphn_aligned16(dlogits);
+    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, rows, targets, ignore_index, nvalid);
+    hipLaunchKernelGGL(ce_row_kernel, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, dlogits, row_loss, vec);
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, s, rows, row_loss, nvalid, loss_out);
+    return caphn_launch_status();
+}
+
+extern "C" size_t caphn_colsum_workspace_bytes(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return sizeof(float) * (size_t)colsum_slices(M, N) * N;
+}
+extern "C" int caphn_colsum_f32(int M, int N, const float* A, int lda, float* out, void* ws, caphn_stream_t stream) {
+    if (M <= 0 || N <= 0 || !A || !out || !ws) return CAPHN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int S = colsum_slices(M, N);
+    const int rows_per = (M + S - 1) / S;
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 255) / 256, S), dim3(256), 0, s, M, N, A, lda, part, rows_per);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, S, N, part, out);
+    return caphn_launch_status();
+}
+
+extern "C" int caphn_embedding_gather(int rows, int E, const float* table, const int64_t* idx, float* out, caphn_stream_t stream) {
+    if (rows <= 0 || E <= 0 || !table || !idx || !out) return CAPHN_EINVAL;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), rows, E, table, idx, out);
+    return caphn_launch_status();
+}
+extern "C" int caphn_embedding_scatter_add(int rows, int E, const float* g, const int64_t* idx, float* table_grad, caphn_stream_t stream) {
+    if (rows <= 0 || E <= 0 || !g || !idx || !table_grad) return CAPHN_EINVAL;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), rows, E, g, idx, table_grad);
+    return caphn_launch_status();
+}
+
+extern "C" int caphn_sumsq_blocks(size_t n) { return (int)((n + SUMSQ_CHUNK - 1) / SUMSQ_CHUNK); }
+extern "C" int caphn_sumsq_f32(size_t n, const float* x, double* partial, caphn_stream_t stream) {
+    if (n == 0 || !x || !partial) return CAPHN_EINVAL;
+    const int nb = caphn_sumsq_blocks(n);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), n, x, partial, (int)caphn_aligned16(x));
+    return caphn_launch_status();
+}
+extern "C" int caphn_rank_sumsq_f32(int R, int rows, int k, const float* gfac, size_t ldg, const float* afac, size_t lda,
+                                    double* acc, double* ws, caphn_stream_t stream) {
+    if (R <= 0 || R > RMAX || rows <= 0 || k <= 0 || !gfac || !afac || !acc || !ws) return CAPHN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(rank_gram_kernel, dim3(R * R, 2), dim3(256), 0, s, R, rows, k, gfac, ldg, afac, lda, ws);
+    hipLaunchKernelGGL(rank_gram_finish_kernel, dim3(1), dim3(64), 0, s, R, ws, acc);
+    return caphn_launch_status();
+}
+extern "C" int caphn_clip_coef(int nparts, const double* partial, const double* extra, double max_norm, double scale,
+                               float* coef_out, caphn_stream_t stream) {
+    if (nparts < 0 || (nparts > 0 && !partial) || !coef_out) return CAPHN_EINVAL;
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), nparts, partial, extra, max_norm, scale, coef_out);
+    return caphn_launch_status();
+}
+
+extern "C" int caphn_adam_dense_f32(size_t n, float* p, float* m, float* v, const float* g, const float* coef,
+                                    const caphn_adam_hparams* hp, caphn_stream_t stream) {
+    if (n == 0 || !p || !m || !v || !g || !coef || !hp || hp->step < 1) return CAPHN_EINVAL;
+    const int vec = caphn_aligned16(p) && caphn_aligned16(m) && caphn_aligned16(v) && caphn_aligned16(g);
+    size_t nb = (n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), n, p, m, v, g, coef, make_adam(hp), vec);
+    return caphn_launch_status();
+}
+extern "C" int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, float* v,
+                                   const float* gfac, size_t ldg, const float* afac, size_t lda,
+                                   const float* coef, const caphn_adam_hparams* hp, caphn_stream_t stream) {
+    if (R <= 0 || R > RMAX || rows <= 0 || k <= 0 || !W || !m || !v || !gfac || !afac || !coef || !hp || hp->step < 1) return CAPHN_EINVAL;
+    const int vec = (k % 4 == 0) && (lda % 4 == 0) && caphn_aligned16(W) && caphn_aligned16(m) && caphn_aligned16(v) && caphn_aligned16(afac);
+    long nb = ((long)rows + 3) / 4;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(adam_rank_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, make_adam(hp), vec);
+    return caphn_launch_status();
+}
+
+extern "C" int caphn_abi_version(void) { return 1; }
+extern "C" int caphn_device_arch(char* buf, int buflen) {
+    if (!buf || buflen <= 0) return CAPHN_EINVAL;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CAPHN_ELAUNCH;
+    int i = 0;
+    for (; i < buflen - 1 && prop.gcnArchName[i] && prop.gcnArchName[i] != ':'; ++i) buf[i] = prop.gcnArchName[i];
+    buf[i] = 0;
+    return CAPHN_OK;
+}

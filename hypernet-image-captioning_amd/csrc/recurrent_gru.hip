@@ -1,0 +1,377 @@
+// Teacher-forced recurrent loop of AttentionGru (models/decoderlstm.py:78-108) fused with
+// BahdanauAttention (models/attention.py:21-46) and the GRUCell arithmetic: one persistent
+// workgroup per caption walks all T steps (no per-step launches).
+//
+// MI355X mapping (160 KB LDS per CU, one workgroup per CU):
+//  * t-invariant projections are hoisted out of the loop as MFMA GEMMs (decoder.hip):
+//      Waf = W_a f + b_Wa  [B,P,H]   and   G = f W_ih[:,E:]^T  [B,P,3H]
+//    so the context never has to be multiplied by W_ih inside the loop:
+//      gi_ctx = (sum_p alpha_p f_p) W_ih_ctx^T = sum_p alpha_p G_p.
+//    A caption's Waf (39 KB) and G (118 KB) slabs are read from HBM once, coalesced, and stay in
+//    LDS for all T steps; h, U_a h and the gate pre-activations live in LDS too.
+//  * per step the only global traffic is W_hh and U_a (640 KB, L2-resident, shared by all
+//    workgroups) streamed with 16-byte loads, 8 lanes per weight row;
+//  * attention scores: one wave per position p, lanes over H, v_a . tanh(.) reduced with wave
+//    shuffles; the softmax over P = 49 (< 64 lanes) is a single-wave shuffle reduction.
+#include "common.h"
+#include "decoder_internal.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n, int vec, int tid) {
+    if (vec) {
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+        f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+        for (int i = tid; i < (n >> 2); i += NT) d4[i] = s4[i];
+    } else {
+        for (int i = tid; i < n; i += NT) dst[i] = src[i];
+    }
+}
+
+// y[row] = dot(W[row,:], x_s) + bias[row] for `rows` rows; 8 lanes per row, result to out_s
+__device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const float* __restrict__ bias,
+                                            const float* x_s, float* out_s, int rows, int K, int vec, int tid) {
+    const int grp = tid >> 3, s = tid & 7;
+    for (int r = grp; r < rows; r += NT / 8) {
+        const float* row = W + (size_t)r * K;
+        float sum = 0.f;
+        if (vec) {
+            const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+            const f32x4* x4 = reinterpret_cast<const f32x4*>(x_s);
+            for (int c = s; c < (K >> 2); c += 8) {
+                f32x4 a = r4[c], b = x4[c];
+                sum += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+            }
+        } else {
+            for (int c = s; c < K; c += 8) sum += row[c] * x_s[c];
+        }
+        sum += __shfl_xor(sum, 4, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        sum += __shfl_xor(sum, 1, 64);
+        if (s == 0) out_s[r] = sum + bias[r];
+    }
+}
+
+__global__ __launch_bounds__(NT) void gru_attn_fwd_kernel(GruFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P, H = a.H, H3 = 3 * a.H, T = a.T;
+    float* Waf_s = lds;
+    float* G_s = Waf_s + P * H;
+    float* h_s = G_s + P * H3;
+    float* uah_s = h_s + H;
+    float* va_s = uah_s + H;
+    float* gh_s = va_s + H;
+    float* e_s = gh_s + H3;
+
+    copy_to_lds(Waf_s, a.Waf + (size_t)b * P * H, P * H, a.vecS, tid);
+    copy_to_lds(G_s, a.G + (size_t)b * P * H3, P * H3, a.vecS, tid);
+    for (int k = tid; k < H; k += NT) { h_s[k] = a.h0[(size_t)b * H + k]; va_s[k] = a.v_a[k]; }
+    const float bva = a.b_va[0];
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        const size_t bt = (size_t)b * T + t;
+        // A: U_a h + b_Ua -> uah_s ; W_hh h + b_hh -> gh_s
+        matvec_rows(a.U_a, a.b_Ua, h_s, uah_s, H, H, a.vecW, tid);
+        matvec_rows(a.W_hh, a.b_hh, h_s, gh_s, H3, H, a.vecW, tid);
+        __syncthreads();
+        // B: e_p = v_a . tanh(Waf_p + uah) + b_va
+        for (int p = wave; p < P; p += NT / 64) {
+            float s = 0.f;
+            for (int k = lane; k < H; k += 64) s += va_s[k] * caphn_tanh(Waf_s[p * H + k] + uah_s[k]);
+            s = wave_sum(s);
+            if (lane == 0) e_s[p] = s + bva;
+        }
+        __syncthreads();
+        // C: softmax over P (one wave)
+        if (wave == 0) {
+            float m = -INFINITY;
+            for (int p = lane; p < P; p += 64) m = fmaxf(m, e_s[p]);
+            m = wave_max(m);
+            float sum = 0.f;
+            for (int p = lane; p < P; p += 64) { float ex = caphn_exp(e_s[p] - m); e_s[p] = ex; sum += ex; }
+            sum = wave_sum(sum);
+            const float inv = 1.0f / sum;
+            for (int p = lane; p < P; p += 64) { float al = e_s[p] * inv; e_s[p] = al; a.alphas[bt * P + p] = al; }
+        }
+        __syncthreads();
+        // D: gi = Xg + sum_p alpha_p G_p ; gates ; h'
+        for (int k = tid; k < H; k += NT) {
+            float gr = 0.f, gz = 0.f, gn = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const float al = e_s[p];
+                const float* gp = G_s + p * H3 + k;
+                gr += al * gp[0]; gz += al * gp[H]; gn += al * gp[2 * H];
+            }
+            const float* xg = a.Xg + bt * H3;
+            const float hp = h_s[k];
+            const float r = caphn_sigmoid(xg[k] + gr + gh_s[k]);
+            const float z = caphn_sigmoid(xg[H + k] + gz + gh_s[H + k]);
+            const float hnv = gh_s[2 * H + k];
+            const float n = caphn_tanh(xg[2 * H + k] + gn + r * hnv);
+            const float hnew = (1.0f - z) * n + z * hp;
+            a.Hprev[bt * H + k] = hp;
+            a.Hs[bt * H + k] = hnew;
+            a.gates[bt * H3 + k] = r; a.gates[bt * H3 + H + k] = z; a.gates[bt * H3 + 2 * H + k] = n;
+            a.hn[bt * H + k] = hnv;
+            a.uah[bt * H + k] = uah_s[k];
+            gh_s[k] = hnew;                    // stash: h_s is still being read by other threads' hp? no -- only [k]
+        }
+        __syncthreads();
+        for (int k = tid; k < H; k += NT) h_s[k] = gh_s[k];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BPTT.  Walks t = T-1 .. 0 with dh carried in LDS.  G stays LDS-resident (d alpha_p = G_p . dgi);
+// Waf is re-read from L2 (39 KB/step) because the gradient vectors take the remaining LDS.
+// Emits per-step dgi, dgh, d(U_a h), d e -- the weight gradients are batched MFMA GEMMs afterwards.
+template <int CH>   // CH = 4: dwordx4 column chunks, CH = 1: scalar columns (H % 4 != 0)
+__device__ __forceinline__ void matvec_t_accum(const float* __restrict__ W, const float* d_s, int rows, int H,
+                                               int chunk, int slice, int nslices, float (&acc)[CH]) {
+    for (int j = slice; j < rows; j += nslices) {
+        const float dj = d_s[j];
+        const float* row = W + (size_t)j * H + chunk * CH;
+        if (CH == 4) {
+            f32x4 w = *reinterpret_cast<const f32x4*>(row);
+            acc[0] += w[0] * dj; acc[1 % CH] += w[1] * dj; acc[2 % CH] += w[2] * dj; acc[3 % CH] += w[3] * dj;
+        } else {
+            acc[0] += row[0] * dj;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void gru_attn_bwd_kernel(GruBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P, H = a.H, H3 = 3 * a.H, T = a.T;
+    const int Ppad = (P + 63) & ~63;
+    float* G_s = lds;
+    float* dh_s = G_s + P * H3;
+    float* duah_s = dh_s + H;
+    float* uah_s = duah_s + H;
+    float* va_s = uah_s + H;
+    float* dgh_s = va_s + H;
+    float* dgi_s = dgh_s + H3;
+    float* dal_s = dgi_s + H3;
+    float* al_s = dal_s + Ppad;
+    float* part_s = al_s + Ppad;     // [nslices][H]
+
+    copy_to_lds(G_s, a.G + (size_t)b * P * H3, P * H3, a.vecS, tid);
+    for (int k = tid; k < H; k += NT) { dh_s[k] = 0.f; va_s[k] = a.v_a[k]; }
+    const float* Waf_b = a.Waf + (size_t)b * P * H;
+    // transposed mat-vec thread map: chunk of CH columns x row slice
+    const int CH = a.vecW ? 4 : 1;
+    const int nch = (H + CH - 1) / CH;
+    const int nch_eff = min(nch, NT);
+    const int nslices = NT / nch_eff;
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t bt = (size_t)b * T + t;
+        for (int p = tid; p < P; p += NT) al_s[p] = a.alphas[bt * P + p];
+        // GRU cell backward (pointwise), thread k
+        for (int k = tid; k < H; k += NT) {
+            const float r = a.gates[bt * H3 + k], z = a.gates[bt * H3 + H + k], n = a.gates[bt * H3 + 2 * H + k];
+            const float hnv = a.hn[bt * H + k], hp = a.Hprev[bt * H + k];
+            const float dh = dh_s[k] + a.dHs[bt * H + k];
+            const float dn = dh * (1.0f - z);
+            const float dz = dh * (hp - n);
+            const float dnp = dn * (1.0f - n * n);
+            const float drp = dnp * hnv * r * (1.0f - r);
+            const float dzp = dz * z * (1.0f - z);
+            dh_s[k] = dh * z;                              // direct path h_{t-1} -> h_t
+            uah_s[k] = a.uah[bt * H + k];
+            dgi_s[k] = drp; dgi_s[H + k] = dzp; dgi_s[2 * H + k] = dnp;
+            dgh_s[k] = drp; dgh_s[H + k] = dzp; dgh_s[2 * H + k] = dnp * r;
+            a.dgi[bt * H3 + k] = drp; a.dgi[bt * H3 + H + k] = dzp; a.dgi[bt * H3 + 2 * H + k] = dnp;
+            a.dgh[bt * H3 + k] = drp; a.dgh[bt * H3 + H + k] = dzp; a.dgh[bt * H3 + 2 * H + k] = dnp * r;
+        }
+        __syncthreads();
+        // d alpha_p = G_p . dgi  (+ external gradient on the returned attention weights)
+        for (int p = wave; p < P; p += NT / 64) {
+            float s = 0.f;
+            for (int j = lane; j < H3; j += 64) s += G_s[p * H3 + j] * dgi_s[j];
+            s = wave_sum(s);
+            if (lane == 0) dal_s[p] = s + (a.dalphas ? a.dalphas[bt * P + p] : 0.f);
+        }
+        __syncthreads();
+        // softmax backward: de_p = alpha_p (dalpha_p - sum_q alpha_q dalpha_q)
+        if (wave == 0) {
+            float dot = 0.f;
+            for (int p = lane; p < P; p += 64) dot += al_s[p] * dal_s[p];
+            dot = wave_sum(dot);
+            for (int p = lane; p < P; p += 64) {
+                const float de = al_s[p] * (dal_s[p] - dot);
+                dal_s[p] = de;
+                a.de[bt * P + p] = de;
+            }
+        }
+        __syncthreads();
+        // d(U_a h)[k] = v_k sum_p de_p (1 - tanh^2(Waf_pk + uah_k))
+        for (int k = tid; k < H; k += NT) {
+            const float u = uah_s[k];
+            float s = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const float tv = caphn_tanh(Waf_b[p * H + k] + u);
+                s += dal_s[p] * (1.0f - tv * tv);
+            }
+            const float du = s * va_s[k];
+            duah_s[k] = du;
+            a.duah[bt * H + k] = du;
+        }
+        __syncthreads();
+        // dh_{t-1} += W_hh^T dgh + U_a^T duah
+        {
+            const int chunk = tid % nch_eff, slice = tid / nch_eff;
+            if (slice < nslices) {
+                for (int c = chunk; c < nch; c += nch_eff) {
+                    if (CH == 4) {
+                        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                        matvec_t_accum<4>(a.W_hh, dgh_s, H3, H, c, slice, nslices, acc);
+                        matvec_t_accum<4>(a.U_a, duah_s, H, H, c, slice, nslices, acc);
+                        *reinterpret_cast<f32x4*>(part_s + slice * H + c * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+                    } else {
+                        float acc[1] = {0.f};
+                        matvec_t_accum<1>(a.W_hh, dgh_s, H3, H, c, slice, nslices, acc);
+                        matvec_t_accum<1>(a.U_a, duah_s, H, H, c, slice, nslices, acc);
+                        part_s[slice * H + c] = acc[0];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < H; k += NT) {
+            float s = dh_s[k];
+            for (int sl = 0; sl < nslices; ++sl) s += part_s[sl * H + k];
+            dh_s[k] = s;
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < H; k += NT) a.dh0[(size_t)b * H + k] = dh_s[k];
+}
+
+// dWaf[b,p,k] = v_k sum_t de[b,t,p] (1 - tanh^2(Waf[b,p,k] + uah[b,t,k]))
+// part[(b,pc)][k] = sum_{t, p in chunk} de tanh(.)   (-> d v_a) ; part[..][H] = sum de (-> d b_va)
+__global__ void attn_param_grads_kernel(AttnGradArgs a) {
+    const int b = blockIdx.x, pc = blockIdx.y;
+    const int P = a.P, H = a.H, T = a.T;
+    const int p0 = pc * a.pchunk, p1 = min(P, p0 + a.pchunk);
+    const size_t blk = (size_t)b * gridDim.y + pc;
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        const float vk = a.v_a[k];
+        float dv = 0.f;
+        for (int p = p0; p < p1; ++p) {
+            const float w = a.Waf[((size_t)b * P + p) * H + k];
+            float s = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float de = a.de[((size_t)b * T + t) * P + p];
+                const float tv = caphn_tanh(w + a.uah[((size_t)b * T + t) * H + k]);
+                s += de * (1.0f - tv * tv);
+                dv += de * tv;
+            }
+            a.dWaf[((size_t)b * P + p) * H + k] = s * vk;
+        }
+        a.part[blk * (H + 1) + k] = dv;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int p = p0; p < p1; ++p)
+            for (int t = 0; t < T; ++t) s += a.de[((size_t)b * T + t) * P + p];
+        a.part[blk * (H + 1) + H] = s;
+    }
+}
+
+// ctx[b,t,k] = sum_p alpha[b,t,p] f[b,p,k]
+__global__ void ctx_kernel(int P, int F, int T, const float* __restrict__ alphas, const float* __restrict__ f, float* __restrict__ ctx) {
+    const int b = blockIdx.x, t = blockIdx.y;
+    const float* al = alphas + ((size_t)b * T + t) * P;
+    for (int k = threadIdx.x; k < F; k += blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += al[p] * f[((size_t)b * P + p) * F + k];
+        ctx[((size_t)b * T + t) * F + k] = s;
+    }
+}
+// df[b,p,k] = sum_t alpha[b,t,p] dctx[b,t,k] + dmean[b,k] / P
+__global__ void df_kernel(int P, int F, int T, const float* __restrict__ alphas, const float* __restrict__ dctx,
+                          const float* __restrict__ dmean, float* __restrict__ df) {
+    const int b = blockIdx.x, p = blockIdx.y;
+    const float invP = 1.0f / (float)P;
+    for (int k = threadIdx.x; k < F; k += blockDim.x) {
+        float s = dmean[(size_t)b * F + k] * invP;
+        for (int t = 0; t < T; ++t) s += alphas[((size_t)b * T + t) * P + p] * dctx[((size_t)b * T + t) * F + k];
+        df[((size_t)b * P + p) * F + k] = s;
+    }
+}
+// mean over positions
+__global__ void mean_p_kernel(int P, int F, const float* __restrict__ f, float* __restrict__ out) {
+    const int b = blockIdx.x;
+    const float invP = 1.0f / (float)P;
+    for (int k = threadIdx.x; k < F; k += blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += f[((size_t)b * P + p) * F + k];
+        out[(size_t)b * F + k] = s * invP;
+    }
+}
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+bool g_attr_set = false;
+int ensure_lds_attr() {
+    if (g_attr_set) return CAPHN_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_attn_fwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess) return CAPHN_ELAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_attn_bwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess) return CAPHN_ELAUNCH;
+    g_attr_set = true;
+    return CAPHN_OK;
+}
+
+}  // namespace
+
+size_t caphn_gru_fwd_lds_bytes(int P, int H) {
+    const size_t Ppad = (P + 63) & ~63;
+    return sizeof(float) * ((size_t)4 * P * H + 6 * (size_t)H + Ppad);
+}
+size_t caphn_gru_bwd_lds_bytes(int P, int H) {
+    const size_t Ppad = (P + 63) & ~63;
+    const int CH = (H % 4 == 0) ? 4 : 1;
+    const int nch = (H + CH - 1) / CH;
+    const int nch_eff = nch < NT ? nch : NT;
+    const int nslices = NT / nch_eff;
+    return sizeof(float) * ((size_t)3 * P * H + 10 * (size_t)H + 2 * Ppad + (size_t)nslices * H);
+}
+
+int caphn_launch_gru_fwd(const GruFwdArgs& a, hipStream_t s) {
+    const size_t lds = caphn_gru_fwd_lds_bytes(a.P, a.H);
+    if (lds > LDS_LIMIT) return CAPHN_ELIMIT;
+    int rc = ensure_lds_attr(); if (rc) return rc;
+    hipLaunchKernelGGL(gru_attn_fwd_kernel, dim3(a.B), dim3(NT), lds, s, a);
+    return caphn_launch_status();
+}
+int caphn_launch_gru_bwd(const GruBwdArgs& a, hipStream_t s) {
+    const size_t lds = caphn_gru_bwd_lds_bytes(a.P, a.H);
+    if (lds > LDS_LIMIT) return CAPHN_ELIMIT;
+    int rc = ensure_lds_attr(); if (rc) return rc;
+    hipLaunchKernelGGL(gru_attn_bwd_kernel, dim3(a.B), dim3(NT), lds, s, a);
+    return caphn_launch_status();
+}
+int caphn_launch_attn_param_grads(const AttnGradArgs& a, int B, int npc, hipStream_t s) {
+    hipLaunchKernelGGL(attn_param_grads_kernel, dim3(B, npc), dim3(a.H >= 192 ? 256 : 64), 0, s, a);
+    return caphn_launch_status();
+}
+int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const float* f, float* ctx, hipStream_t s) {
+    hipLaunchKernelGGL(ctx_kernel, dim3(B, T), dim3(F >= 192 ? 256 : 64), 0, s, P, F, T, alphas, f, ctx);
+    return caphn_launch_status();
+}
+int caphn_launch_df(int B, int T, int P, int F, const float* alphas, const float* dctx, const float* dmean, float* df, hipStream_t s) {
+    hipLaunchKernelGGL(df_kernel, dim3(B, P), dim3(F >= 192 ? 256 : 64), 0, s, P, F, T, alphas, dctx, dmean, df);
+    return caphn_launch_status();
+}
+int caphn_launch_mean_p(int B, int P, int F, const float* f, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(mean_p_kernel, dim3(B), dim3(F >= 192 ? 256 : 64), 0, s, P, F, f, out);
+    return caphn_launch_status();
+}

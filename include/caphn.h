@@ -1,0 +1,209 @@
+/*
+ * caphn.h -- C ABI of libcaphn.so: the MI355X (gfx950) hot path of the
+ * hypernetwork-conditioned captioning training step.
+ *
+ * The reference (zacharie12/Hypernet-image-captioning) has no FFI layer: its hot path is
+ * Python nn.Modules.  Each entry point below replaces the arithmetic of one reference
+ * function; the Python modules under hypernet-image-captioning_amd/ (same names and
+ * signatures as the reference's) bind these symbols with ctypes.  File:line citations are
+ * relative to the reference root.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 (or int64 where stated) unless marked host;
+ *    matrices are row-major with explicit leading dimensions (in elements);
+ *  - every function enqueues work on `stream` and returns immediately: 0 on success,
+ *    a negative CAPHN_E* code otherwise; nothing throws, nothing allocates, nothing
+ *    synchronises (graph-capture safe); scratch comes from the caller (`*_workspace_bytes`);
+ *  - parameter tensors keep the reference's layout: nn.Linear weight [out,in], GRUCell
+ *    weight_ih [3H,E+F] / weight_hh [3H,H], gate order r,z,n.
+ */
+#ifndef CAPHN_H
+#define CAPHN_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* caphn_stream_t; /* hipStream_t */
+
+#define CAPHN_OK 0
+#define CAPHN_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported combination) */
+#define CAPHN_ELAUNCH (-2)   /* HIP reported a launch error */
+#define CAPHN_ELIMIT (-3)    /* problem does not fit a hardware limit (e.g. LDS) */
+
+/* Library / device probe.  Returns the ABI version (>0).  */
+int caphn_abi_version(void);
+/* Writes the gfx arch name of the current device into buf (host); 0 on success. */
+int caphn_device_arch(char* buf, int buflen);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense contraction on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32 products,
+ * fp32 accumulate).  C[M,N] = epilogue( op(A) . op(B) ).
+ *   ta == 0: A is [M,K] (lda)   ta == 1: A is stored [K,M] (lda) and used transposed
+ *   tb == 0: B is [K,N] (ldb)   tb == 1: B is stored [N,K] (ldb) and used transposed
+ * so nn.Linear forward  y = x W^T + b  is (ta=0,tb=1)            [models/decoderlstm.py:22-26,38,105]
+ *    its input gradient dx = dy W      is (ta=0,tb=0)
+ *    its weight gradient dW = dy^T x   is (ta=1,tb=0).
+ * flags: CAPHN_GEMM_*.  bias is [N] or NULL.  mask (CAPHN_GEMM_MASK) is [M,N] with ldmask: the
+ * result is zeroed where mask <= 0 (ReLU backward).  splitk > 1 partitions K over grid.z and
+ * accumulates into C with fp32 atomics: C must be pre-initialised (zero, or the value to add to)
+ * and only CAPHN_GEMM_BIAS is honoured (added by slice 0).
+ */
+#define CAPHN_GEMM_BIAS 1
+#define CAPHN_GEMM_RELU 2
+#define CAPHN_GEMM_ACCUM 4   /* C += result (read-modify-write, no atomics) */
+#define CAPHN_GEMM_MASK 8
+int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
+                   const float* A, int lda, const float* B, int ldb,
+                   float* C, int ldc, const float* bias,
+                   const float* mask, int ldmask, int flags, int splitk,
+                   caphn_stream_t stream);
+
+/* out[n] = sum_m A[m,n]  (bias gradients).  ws: caphn_colsum_workspace_bytes(M,N). */
+size_t caphn_colsum_workspace_bytes(int M, int N);
+int caphn_colsum_f32(int M, int N, const float* A, int lda, float* out, void* ws, caphn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Hypernetwork: hn_base (2 x Linear+LeakyReLU) and per-parameter heads
+ * Linear(he,k_i)+LeakyReLU+Linear(k_i,w_i), input is ONE row (M = 1): every product is a
+ * GEMV and the second head layers (w_i x k_i, 576 MB fp32 at the canonical size) are streamed
+ * from HBM exactly once per call.        [hypernet_attention.py:55-99 (shapes), :111-118 (forward)]
+ */
+#define CAPHN_MAX_HEADS 8
+typedef struct caphn_hyper_desc {
+    int he;                       /* hypernet input width                        */
+    int n_heads;                  /* 4 for GRUCell / LSTMCell                    */
+    int k[CAPHN_MAX_HEADS];       /* hidden width of head i                      */
+    int w[CAPHN_MAX_HEADS];       /* output size of head i (= numel of the generated parameter) */
+    const float* base_w0; const float* base_b0;   /* hn_base.0  [he,he],[he] */
+    const float* base_w2; const float* base_b2;   /* hn_base.2  [he,he],[he] */
+    const float* w1[CAPHN_MAX_HEADS]; const float* b1[CAPHN_MAX_HEADS]; /* hn_heads.i.0 [k_i,he],[k_i] */
+    const float* w2[CAPHN_MAX_HEADS]; const float* b2[CAPHN_MAX_HEADS]; /* hn_heads.i.2 [w_i,k_i],[w_i] */
+} caphn_hyper_desc;
+
+/* acts layout (floats), every segment padded to a multiple of 4 floats:
+ * [x (he) | a0 (he) | base (he) | a_0 (k_0) | ... | a_{n-1}] ; size = caphn_hyper_acts_floats; acts must be 16-byte aligned */
+int caphn_hyper_acts_floats(const caphn_hyper_desc* d);
+/* theta[sum w_i] = cat_i head_i(hn_base(x)); acts receives the post-LeakyReLU activations
+ * needed by the backward (and, data-parallel, exchanged as rank-1 factors). */
+int caphn_hyper_forward(const caphn_hyper_desc* d, const float* x, float* theta, float* acts,
+                        caphn_stream_t stream);
+
+/* Gradient sinks of caphn_hyper_backward.  Any pointer may be NULL (that gradient is skipped),
+ * except that the chain needs what lies downstream of a requested gradient.  The second-layer
+ * weight gradient dW2_i = dtheta_i (x) a_i is rank-1 and is only materialised when g_w2[i] != NULL
+ * (the module API / torch optimisers need it dense; the fused optimiser does not). */
+typedef struct caphn_hyper_grads {
+    float* g_base_w0; float* g_base_b0; float* g_base_w2; float* g_base_b2;
+    float* g_w1[CAPHN_MAX_HEADS]; float* g_b1[CAPHN_MAX_HEADS];
+    float* g_w2[CAPHN_MAX_HEADS]; float* g_b2[CAPHN_MAX_HEADS];
+    float* g_x;                   /* [he] gradient w.r.t. the style/domain embedding row */
+} caphn_hyper_grads;
+size_t caphn_hyper_backward_workspace_bytes(const caphn_hyper_desc* d);
+/* VJP of caphn_hyper_forward with dtheta (what autograd would give the reference had utils.py:57
+ * not detached theta; SURVEY.md 8a H3 "intended" gradients). */
+int caphn_hyper_backward(const caphn_hyper_desc* d, const float* dtheta, const float* acts,
+                         const caphn_hyper_grads* g, void* ws, caphn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Decoder: AttentionGru.forward with teacher forcing            [models/decoderlstm.py:49-120]
+ * + BahdanauAttention.forward                                   [models/attention.py:21-46]
+ * + nn.GRUCell arithmetic                                       [decoderlstm.py:32,100]
+ */
+typedef struct caphn_decoder_dims {
+    int B, T, P;        /* batch, caption length, attention positions (49) */
+    int D, F, E, H, V;  /* encoder channels, feature_out, embedding_dim, hidden_dim, vocab */
+} caphn_decoder_dims;
+
+typedef struct caphn_decoder_params {   /* reference state_dict names in comments */
+    const float* fc0_w; const float* fc0_b;   /* captioner.feature_fc.0  [F,D],[F] */
+    const float* fc2_w; const float* fc2_b;   /* captioner.feature_fc.2  [F,F],[F] */
+    const float* embed_w;                     /* captioner.embed.weight  [V,E]     */
+    const float* out_w; const float* out_b;   /* captioner.fc            [V,H],[V] */
+    const float* Wa_w; const float* Wa_b;     /* captioner.attention.W_a [H,F],[H] */
+    const float* Ua_w; const float* Ua_b;     /* captioner.attention.U_a [H,H],[H] */
+    const float* va_w; const float* va_b;     /* captioner.attention.v_a [1,H],[1] */
+    const float* inith_w; const float* inith_b; /* captioner.init_h      [H,F],[H] */
+    const float* w_ih; const float* w_hh;     /* gru.weight_ih [3H,E+F], gru.weight_hh [3H,H] (slices of theta) */
+    const float* b_ih; const float* b_hh;     /* gru.bias_ih [3H], gru.bias_hh [3H] */
+} caphn_decoder_params;
+
+typedef struct caphn_decoder_grads {    /* same shapes as the parameters; all required */
+    float* fc0_w; float* fc0_b; float* fc2_w; float* fc2_b;
+    float* embed_w;                     /* fully overwritten (zero + scatter-add) */
+    float* out_w; float* out_b;
+    float* Wa_w; float* Wa_b; float* Ua_w; float* Ua_b; float* va_w; float* va_b;
+    float* inith_w; float* inith_b;
+    float* w_ih; float* w_hh; float* b_ih; float* b_hh;   /* = dtheta, in theta order when contiguous */
+} caphn_decoder_grads;
+
+/* Saved-activation workspace shared by forward and backward (one training step). */
+size_t caphn_decoder_workspace_bytes(const caphn_decoder_dims* d);
+/* features [B,P,D] fp32, captions [B,T] int64 -> logits [B,T,V], alphas [B,T,P].
+ * Implements the reference's input quirk: x_0 = x_1 = 0, x_t = embed[caps[:,t-1]] for t >= 2
+ * (decoderlstm.py:82-88, in-place zero of a view). */
+int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_decoder_params* p,
+                          const float* features, const int64_t* captions,
+                          float* logits, float* alphas, void* ws, caphn_stream_t stream);
+/* dlogits [B,T,V] (may be overwritten) -> parameter gradients.  ws must be the workspace the
+ * matching forward filled.  dalphas (gradient w.r.t. the returned attention weights) may be NULL. */
+int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_decoder_params* p,
+                           const float* features, const int64_t* captions,
+                           float* dlogits, const float* dalphas,
+                           const caphn_decoder_grads* g, void* ws, caphn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Loss: F.cross_entropy(logits.view(-1,V), caps.view(-1), ignore_index)   [hypernet_attention.py:183,
+ * cc_train_hypernet.py:153].  Writes the mean loss to loss_out[0], the number of non-ignored
+ * targets to loss_out[1], and d loss / d logits to dlogits (may alias logits).
+ * ws: caphn_ce_workspace_bytes(rows).
+ */
+size_t caphn_ce_workspace_bytes(int rows);
+int caphn_cross_entropy_fwd_bwd(int rows, int V, const float* logits, const int64_t* targets,
+                                int64_t ignore_index, float* dlogits, float* loss_out,
+                                void* ws, caphn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Embedding                                                     [decoderlstm.py:28,62]
+ * gather: out[r,:] = (idx[r] < 0) ? 0 : table[idx[r],:]      scatter_add: table_grad[idx[r],:] += g[r,:]
+ */
+int caphn_embedding_gather(int rows, int E, const float* table, const int64_t* idx, float* out,
+                           caphn_stream_t stream);
+int caphn_embedding_scatter_add(int rows, int E, const float* g, const int64_t* idx, float* table_grad,
+                                caphn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimiser: clip_grad_norm_(5.0) + torch.optim.Adam            [cc_train_hypernet.py:120,405]
+ */
+/* partial[0..caphn_sumsq_blocks(n)) = block partial sums of squares (double). */
+int caphn_sumsq_blocks(size_t n);
+int caphn_sumsq_f32(size_t n, const float* x, double* partial, caphn_stream_t stream);
+/* || sum_r g_r (x) a_r ||_F^2 = sum_{r,s} (g_r.g_s)(a_r.a_s) for R rank-1 terms; gfac [R,rows] (ldg),
+ * afac [R,k] (lda).  Adds the value (double) to acc[0].  ws: R*R*2 doubles. */
+int caphn_rank_sumsq_f32(int R, int rows, int k, const float* gfac, size_t ldg, const float* afac, size_t lda,
+                         double* acc, double* ws, caphn_stream_t stream);
+/* coef_out[0] = scale * min(1, max_norm / (scale * sqrt(sum partial + extra[0]) + 1e-6));
+ * coef_out[1] = scale * sqrt(...) (the total norm).  `scale` = 1/world_size. */
+int caphn_clip_coef(int nparts, const double* partial, const double* extra, double max_norm, double scale,
+                    float* coef_out, caphn_stream_t stream);
+
+typedef struct caphn_adam_hparams {
+    float lr, beta1, beta2, eps;
+    int step;                          /* 1-based, bias corrections computed from it */
+} caphn_adam_hparams;
+/* p,m,v,g flat [n]; g is multiplied by coef[0] (device) first. */
+int caphn_adam_dense_f32(size_t n, float* p, float* m, float* v, const float* g, const float* coef,
+                         const caphn_adam_hparams* hp, caphn_stream_t stream);
+/* W,m,v [rows,k]; gradient = coef[0] * sum_r gfac[r,row] * afac[r,col], never materialised. */
+int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, float* v,
+                        const float* gfac, size_t ldg, const float* afac, size_t lda,
+                        const float* coef, const caphn_adam_hparams* hp, caphn_stream_t stream);
+/* dense outer product out[rows,k] = g[rows] (x) a[k]  (module API: torch optimisers want dW2 dense) */
+int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out, caphn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPHN_H */

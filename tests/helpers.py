@@ -32,3 +32,35 @@ def style_args(g):
 
 def maxdiff(a, b):
     return float((a.double() - b.double()).abs().max())
+
+
+# ---- GPU-side helpers ------------------------------------------------------------------
+def dec_params_from_oracle(p, theta, dims, device):
+    """oracle names ('captioner.x') + theta -> the decoder's parameter dict on `device`."""
+    out = {k[len("captioner."):]: v.to(device).contiguous() for k, v in p.items() if k.startswith("captioner.")}
+    th = theta.to(device).contiguous()
+    off = 0
+    for name, shape in dims.cell_param_shapes():
+        n = int(np.prod(shape))
+        out["gru." + name] = th[off:off + n].view(shape)
+        off += n
+    return out
+
+
+def hyper_params_from_oracle(p, device):
+    return {k: v.to(device).contiguous() for k, v in p.items() if k.startswith("hn_")}
+
+
+def hyper_shape(dims):
+    from caphn import ops
+    return ops.HyperShape(dims.he, [(k, w) for _, k, w in O.head_layout(dims)])
+
+
+def dec_dims(dims, B, T, P):
+    from caphn import ops
+    return ops.DecDims(B, T, P, dims.D, dims.F, dims.E, dims.H, dims.V)
+
+
+def rel_err(a, b):
+    a = a.double().cpu(); b = b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))

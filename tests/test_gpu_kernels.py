@@ -1,0 +1,210 @@
+"""GPU parity tests of the individual C-ABI entry points against fp64/torch references and the
+oracle.  Run with -m gpu on an MI355X.  Tolerances are fp32: products are exact fp32 (MFMA
+f32 / VALU fma), only summation order differs from the CPU reference."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import caphn_oracle as O
+from helpers import (TINY_DIMS, load_case, maxdiff, style_args, dec_params_from_oracle,
+                     hyper_params_from_oracle, hyper_shape, dec_dims, rel_err)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from caphn import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (37, 83, 19), (130, 200, 200), (2560, 200, 333), (300, 1000, 64)])
+def test_gemm_layouts(ops, ta, tb, M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    tol = 2e-6 * math.sqrt(K) * 4
+    out = ops.gemm(A.to(DEV), B.to(DEV), ta, tb)
+    assert maxdiff(out.cpu(), ref) < tol
+    out = ops.gemm(A.to(DEV), B.to(DEV), ta, tb, bias=bias.to(DEV), relu=True)
+    assert maxdiff(out.cpu(), torch.relu(ref + bias.double())) < tol
+    # accumulate + mask
+    C0 = torch.randn(M, N, generator=g)
+    mask = torch.randn(M, N, generator=g)
+    out = ops.gemm(A.to(DEV), B.to(DEV), ta, tb, out=C0.to(DEV).clone(), accumulate=True, mask=mask.to(DEV))
+    assert maxdiff(out.cpu(), (ref + C0.double()) * (mask > 0)) < tol
+    # split-K (atomic accumulate into zeros) with bias
+    out = ops.gemm(A.to(DEV), B.to(DEV), ta, tb, bias=bias.to(DEV), splitk=3)
+    assert maxdiff(out.cpu(), ref + bias.double()) < tol
+
+
+def test_gemm_strided_views(ops):
+    """leading dimensions larger than the logical width (W_ih[:, E:] style views)."""
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(48, 40, generator=g).to(DEV)      # [3H, E+F]
+    X = torch.randn(21, 24, generator=g).to(DEV)
+    out = ops.gemm(X, W[:, 16:], False, True)          # X @ W[:,16:]^T
+    assert maxdiff(out.cpu(), X.cpu().double() @ W[:, 16:].cpu().double().t()) < 1e-5
+    big = torch.zeros(48, 40, device=DEV)
+    D = torch.randn(21, 48, generator=g).to(DEV)
+    ops.gemm(D, X, True, False, out=big[:, 16:])       # dW[:,16:] = D^T X
+    assert maxdiff(big[:, 16:].cpu(), D.cpu().double().t() @ X.cpu().double()) < 1e-5
+    assert float(big[:, :16].abs().max()) == 0.0
+
+
+def test_colsum(ops):
+    g = torch.Generator().manual_seed(9)
+    for M, N in [(5, 3), (2560, 600), (6272, 200), (100, 9684)]:
+        A = torch.randn(M, N, generator=g)
+        assert maxdiff(ops.colsum(A.to(DEV)).cpu(), A.double().sum(0)) < 1e-5 * math.sqrt(M) * 4
+
+
+@pytest.mark.parametrize("name", ["gru_tiny_flickr", "gru_tiny_cc", "gru_odd_cc"])
+def test_hyper_forward_backward_tiny(ops, name):
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    xs = p["captioner.embed.weight"][tok] if tok is not None else x
+    shape = hyper_shape(dims)
+    hp = hyper_params_from_oracle(p, DEV)
+    theta, acts = ops.hyper_forward(shape, hp, xs.to(DEV))
+    assert maxdiff(theta.cpu(), g["theta"]) < 2e-6
+    grads = {n: torch.empty(s, device=DEV) for n, s in shape.param_shapes().items()}
+    gx = ops.hyper_backward(shape, hp, g["dtheta"].to(DEV), acts, grads, want_x=True)
+    for n in grads:
+        assert maxdiff(grads[n].cpu(), g["gint/" + n]) < 2e-6, n
+    # dx against autograd on the oracle
+    xr = xs.clone().reshape(-1).requires_grad_(True)
+    O.hyper_forward(p, xr).backward(g["dtheta"])
+    assert maxdiff(gx.cpu(), xr.grad) < 2e-6
+
+
+def test_hyper_forward_backward_canonical_shape(ops):
+    """he=200 with the canonical head widths (480/240/200/200) but fewer rows: exercises the
+    wave-per-row dwordx4 paths (k >= 128) incl. the 2-chunk 480 case and row tails."""
+    torch.manual_seed(3)
+    he, heads = 200, [(480, 4001), (240, 1999), (200, 600), (200, 600)]
+    shape = ops.HyperShape(he, heads)
+    p = {n: (torch.rand(s) - 0.5) * 0.2 for n, s in shape.param_shapes().items()}
+    x = torch.randn(he)
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    theta_ref = O.hyper_forward(q, xr)
+    dth = torch.randn(theta_ref.numel())
+    theta_ref.backward(dth)
+    pd = {k: v.to(DEV) for k, v in p.items()}
+    theta, acts = ops.hyper_forward(shape, pd, x.to(DEV))
+    assert maxdiff(theta.cpu(), theta_ref.detach()) < 5e-6
+    grads = {n: torch.empty(s, device=DEV) for n, s in shape.param_shapes().items()}
+    gx = ops.hyper_backward(shape, pd, dth.to(DEV), acts, grads, want_x=True)
+    for n in grads:
+        assert rel_err(grads[n], q[n].grad) < 2e-5, n
+    assert rel_err(gx, xr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["gru_tiny_flickr", "gru_tiny_cc", "gru_odd_cc"])
+def test_decoder_forward_backward_tiny(ops, name):
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    B, T = g["captions"].shape
+    P = g["features"].shape[1]
+    dd = dec_dims(dims, B, T, P)
+    params = dec_params_from_oracle(p, g["theta"], dims, DEV)
+    ws = ops.decoder_workspace(dd, DEV)
+    feats, caps = g["features"].to(DEV), g["captions"].to(DEV)
+    logits, alphas = ops.decoder_forward(dd, params, feats, caps, ws)
+    assert maxdiff(logits.cpu(), g["logits"]) < 2e-6
+    assert maxdiff(alphas.cpu(), g["alphas"]) < 1e-6
+    lo, dlogits = ops.cross_entropy_fwd_bwd(logits, caps, 0)
+    assert abs(float(lo[0]) - float(g["loss"])) < 2e-6
+    grads = {n: torch.full(s, float("nan"), device=DEV) for n, s in dd.param_shapes().items()}
+    ops.decoder_backward(dd, params, feats, caps, dlogits, grads, ws)
+    for n, gt in grads.items():
+        if n.startswith("gru."):
+            continue
+        assert maxdiff(gt.cpu(), g["glit/captioner." + n]) < 2e-6, n
+    dth = torch.cat([grads["gru." + n].flatten() for n, _ in dims.cell_param_shapes()])
+    assert maxdiff(dth.cpu(), g["dtheta"]) < 2e-6
+    # quirk: caps[:,0] / caps[:,T-1] do not influence logits
+    l2, _ = ops.decoder_forward(dd, params, feats, g["captions_q0"].to(DEV), ws)
+    assert torch.equal(l2, logits)
+    l3, _ = ops.decoder_forward(dd, params, feats, g["captions_q1"].to(DEV), ws)
+    assert maxdiff(l3.cpu(), g["logits_q1"]) < 2e-6
+
+
+def test_cross_entropy_matches_torch(ops):
+    torch.manual_seed(1)
+    rows, V = 77, 9684
+    logits = torch.randn(rows, V) * 3
+    tgt = torch.randint(0, V, (rows,))
+    tgt[::5] = 0
+    lr = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, tgt, ignore_index=0)
+    ref.backward()
+    out, dl = ops.cross_entropy_fwd_bwd(logits.to(DEV), tgt.to(DEV), 0)
+    assert abs(float(out[0]) - float(ref)) < 2e-6
+    assert int(out[1]) == int((tgt != 0).sum())
+    assert maxdiff(dl.cpu(), lr.grad) < 1e-8
+    # in place
+    lg = logits.to(DEV)
+    out2, dl2 = ops.cross_entropy_fwd_bwd(lg, tgt.to(DEV), 0, dlogits=lg)
+    assert torch.equal(dl2, dl) and float(out2[0]) == float(out[0])
+
+
+def test_embedding(ops):
+    torch.manual_seed(2)
+    table = torch.randn(50, 13)
+    idx = torch.tensor([3, -1, 7, 3, 49, -1, 0])
+    out = ops.embedding_gather(table.to(DEV), idx.to(DEV))
+    ref = torch.where(idx[:, None] >= 0, table[idx.clamp(min=0)], torch.zeros(1))
+    assert torch.equal(out.cpu(), ref)
+    g = torch.randn(7, 13)
+    tg = torch.zeros(50, 13, device=DEV)
+    ops.embedding_scatter_add(g.to(DEV), idx.to(DEV), tg)
+    r = torch.zeros(50, 13)
+    for i, j in enumerate(idx.tolist()):
+        if j >= 0:
+            r[j] += g[i]
+    assert maxdiff(tg.cpu(), r) < 1e-6
+
+
+def test_adam_and_clip(ops):
+    torch.manual_seed(4)
+    n = 100003
+    p, g = torch.randn(n), torch.randn(n) * 0.1
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, md, vd, gd = p.to(DEV), m.to(DEV), v.to(DEV), g.to(DEV)
+    part = ops.sumsq_partials(gd)
+    assert abs(float(part.sum()) - float((g.double() ** 2).sum())) < 1e-6 * float((g.double() ** 2).sum())
+    coef = ops.clip_coef(part, None, 5.0, 1.0)
+    tot, c = O.clip_coef([g], 5.0)
+    assert abs(float(coef[1]) - tot) < 1e-5 * tot and abs(float(coef[0]) - c) < 1e-6
+    for step in (1, 2, 3):
+        O.adam_step(p, g * c, m, v, step, 1e-3)
+        ops.adam_dense(pd, md, vd, gd, coef, 1e-3, step)
+    assert maxdiff(pd.cpu(), p) < 1e-6 and maxdiff(md.cpu(), m) < 1e-7 and maxdiff(vd.cpu(), v) < 1e-8
+
+
+@pytest.mark.parametrize("R,rows,k", [(1, 1000, 480), (2, 333, 240), (3, 57, 5), (1, 4001, 200)])
+def test_adam_rank_equals_dense(ops, R, rows, k):
+    torch.manual_seed(R * 100 + k)
+    W = torch.randn(rows, k)
+    gf, af = torch.randn(R, rows) * 0.1, torch.randn(R, k)
+    dense = torch.einsum("rm,rk->mk", gf.double(), af.double())
+    acc = torch.zeros(1, dtype=torch.float64, device=DEV)
+    ops.rank_sumsq(gf.to(DEV), af.to(DEV), acc)
+    assert abs(float(acc) - float((dense ** 2).sum())) < 1e-9 * float((dense ** 2).sum()) + 1e-12
+    coef = torch.tensor([0.37, 0.0], device=DEV)
+    Wd, md, vd = W.to(DEV), torch.zeros(rows, k, device=DEV), torch.zeros(rows, k, device=DEV)
+    m, v = torch.zeros(rows, k), torch.zeros(rows, k)
+    for step in (1, 2):
+        O.adam_step(W, (dense * 0.37).float(), m, v, step, 1e-3)
+        ops.adam_rank(Wd, md, vd, gf.to(DEV), af.to(DEV), coef, 1e-3, step)
+    assert maxdiff(Wd.cpu(), W) < 2e-6
+    assert maxdiff(ops.outer(gf[0].to(DEV), af[0].to(DEV)).cpu(), torch.outer(gf[0], af[0])) < 1e-7
