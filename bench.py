@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- training images/sec of the hypernet-conditioned captioning step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = hypernet forward -> decoder forward -> cross entropy -> backward -> gradient exchange
+-> global-norm clip -> Adam on one synthetic Flickr30k-shaped minibatch already resident in HBM
+(BASELINE.json configs[1]: GRU decoder + hypernet, 3 style domains, bs=128 per GPU).  Weak scaling:
+the per-GPU batch is fixed.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     the dominant kernel (adam_rank_kernel on hn_heads.0.2.weight, 115.2 M parameters):
+               algorithmic bytes = 24 B/parameter (read W,m,v + write W,m,v) / its measured duration
+               (HIP events on the launch stream), against 8 TB/s HBM peak.
+  cpu_baseline the CPU oracle (oracle/caphn_oracle.py, a port of the reference's PyTorch path) timed
+               on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "hypernet-image-captioning_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+METRIC = "training images/sec at 1/2/4/8 MI355X, Flickr30k GRU+hypernet bs=128"
+HBM_PEAK = 8.0e12           # B/s, MI355X_MICROARCH.md chip table
+STEP_ALGO_BYTES = 5.228e9   # whole-step algorithmic HBM bytes at B=128
+
+
+class _Vocab:
+    w2i = {"<pad>": 0, "<s>": 1, "</s>": 2, "<unk>": 3, "factual": 4, "humorous": 5, "romantic": 6}
+
+    def __call__(self, w):
+        return self.w2i.get(w, 3)
+
+
+def synth_batches(n, B, T, P, D, V, device, seed):
+    """SURVEY.md 8d synthetic inputs, generated on the device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = []
+    for _ in range(n):
+        feats = torch.relu(torch.randn(B, P, D, generator=g, device=device)) * 0.45
+        L = torch.clamp(torch.round(torch.randn(B, generator=g, device=device) * 4.0 + 12.9), 5, T).long()
+        toks = torch.randint(7, V, (B, T), generator=g, device=device)
+        pos = torch.arange(T, device=device)[None, :]
+        caps = torch.where(pos < (L[:, None] - 1), toks, torch.zeros_like(toks))
+        caps[:, 0] = 1
+        caps.scatter_(1, (L - 1)[:, None], 2)
+        out.append((feats.contiguous(), caps.contiguous()))
+    return out
+
+
+def cpu_baseline(B, T, P, steps=4):
+    """Oracle (port of the reference's path) on the host cores: forward, backward, clip, Adam."""
+    from oracle import caphn_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    dims = O.Dims()
+    p = O.init_params(dims, seed=1)
+    batch = O.synth_batch(dims, B, T, P, seed=2)
+    state = {}
+    O.train_step(dims, p, state, 1, None, batch["features"], batch["captions"], lr=1e-3, style_token=4)  # warm-up
+    ts = []
+    for s in range(steps):
+        t0 = time.perf_counter()
+        O.train_step(dims, p, state, s + 2, None, batch["features"], batch["captions"], lr=1e-3, style_token=4)
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"value": B / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full steps (fwd+bwd+clip+Adam) at B={B}, T={T}, fp32, median {med * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from hypernet_attention import HyperNet
+    from caphn.engine import FusedTrainer
+
+    B, T, P, D, F, E, H, V = args.batch, 20, 49, 2048, 200, 200, 200, 9684
+    torch.manual_seed(1234)                       # identical replicas on every rank
+    net = HyperNet(F, E, H, V, _Vocab()).to(dev)
+    tr = FusedTrainer(net, lr=1e-3, max_norm=5.0)
+    batches = synth_batches(4, B, T, P, D, V, dev, seed=1234 + rank)
+    style = 4 + (rank % 3)                        # one style domain per rank-batch
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        f, c = batches[i % len(batches)]
+        tr.step(f, c, style_token=style)
+    # dominant-kernel timing: HIP events on the launch stream around the adam_rank launch of head 0
+    from caphn import ops
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    orig = ops.adam_rank
+    cnt = {"i": 0}
+
+    def timed_adam_rank(W, *a, **k):
+        if W.shape[0] * W.shape[1] >= 100_000_000 and cnt["i"] < len(ev):
+            ev[cnt["i"]][0].record()
+            orig(W, *a, **k)
+            ev[cnt["i"]][1].record()
+            cnt["i"] += 1
+        else:
+            orig(W, *a, **k)
+    ops.adam_rank = timed_adam_rank
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        f, c = batches[i % len(batches)]
+        loss = tr.step(f, c, style_token=style)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.adam_rank = orig
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+
+    if args.phases and rank == 0:
+        phase_report(tr, batches, style)
+
+    if rank == 0:
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[:cnt["i"]]])) if cnt["i"] else float("nan")
+        k0, w0 = tr.shape.heads[0]
+        kbytes = 24.0 * k0 * w0
+        achieved = kbytes / (kern_ms * 1e-3) / 1e9
+        ms_step = dt / args.steps * 1e3
+        line = {
+            "metric": METRIC, "value": B * world * args.steps / dt, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Flickr30k-shaped GRU+additive-attention decoder + hypernet (3 style domains), "
+                                   "full training step (fwd, CE, bwd, clip 5.0, Adam)",
+                       "per_gpu_batch": B, "global_batch": B * world, "T": T, "P": P, "D": D, "F": F, "E": E, "H": H,
+                       "V": V, "hypernet_params": int(sum(q.numel() for q in net.hn_base.parameters()) +
+                                                      sum(q.numel() for q in net.hn_heads.parameters())),
+                       "parallelism": f"dp{world}", "final_loss": float(loss[0])},
+            "roofline": {"bound": "hbm", "kernel": "adam_rank_kernel(hn_heads.0.2.weight)",
+                         "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
+                         "kernel_ms": kern_ms, "algorithmic_bytes": kbytes,
+                         "step_frac": STEP_ALGO_BYTES / (ms_step * 1e-3) / HBM_PEAK if B == 128 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(B, T, P)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def phase_report(tr, batches, style):
+    """Coarse per-phase GPU times (events around the composite calls) -- a tuning aid, stderr only."""
+    from caphn import ops
+    names = ["hyper_forward", "decoder_forward", "cross_entropy_fwd_bwd", "decoder_backward", "hyper_backward",
+             "sumsq_partials", "rank_sumsq", "clip_coef", "adam_dense", "adam_rank"]
+    acc = {n: [] for n in names}
+    origs = {n: getattr(ops, n) for n in names}
+
+    def wrap(n):
+        def f(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); r = origs[n](*a, **k); e.record()
+            acc[n].append((s, e))
+            return r
+        return f
+    for n in names:
+        setattr(ops, n, wrap(n))
+    t_all = []
+    for i in range(5):
+        f, c = batches[i % len(batches)]
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); tr.step(f, c, style_token=style); e.record()
+        t_all.append((s, e))
+    torch.cuda.synchronize()
+    for n in names:
+        setattr(ops, n, origs[n])
+    tot = np.mean([a.elapsed_time(b) for a, b in t_all])
+    print(f"[phases] step {tot:.3f} ms", file=sys.stderr)
+    for n in names:
+        ms = sum(a.elapsed_time(b) for a, b in acc[n]) / 5
+        print(f"[phases]   {n:24s} {ms:8.3f} ms", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

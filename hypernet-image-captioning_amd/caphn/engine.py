@@ -1,0 +1,281 @@
+"""Fused training step: hypernet forward -> decoder forward -> cross entropy -> backward ->
+gradient exchange -> global-norm clip -> Adam, every arithmetic step a libcaphn kernel.
+
+Call stack it replaces: HyperNetCC.training_step + Lightning's backward / clip_grad_norm_(5.0) /
+Adam.step (cc_train_hypernet.py:134-166, :120, :405; hypernet_attention.py:136-204).
+
+Memory layout (sized for HBM streaming):
+  * "dense" arena: one flat fp32 buffer each for parameters, gradients, Adam m and v.  It starts
+    with the four second-layer biases in head order -- exactly the layout of theta -- so the
+    decoder backward writes dL/dtheta straight into that region: it is at once the bias gradient
+    and the row factor of the rank-1 weight gradients.  Then hn_base, the heads' first layers and
+    the captioner's non-generated parameters.  Module parameters are re-pointed at arena views,
+    so state_dict / sub-module calls keep working and nothing is ever copied per step.
+  * the big second-layer weights W2_i [w_i, k_i] keep their own tensors plus m, v; their gradient
+    dtheta_i (x) a_i is never materialised: caphn_adam_rank_f32 forms it on the fly while streaming
+    W, m, v once (24 B/parameter).
+"""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import dp, ops
+from ._lib import CaphnError
+
+_DEC_NAMES = [n for n in ops.DEC_FIELD_TO_NAME.values() if not n.startswith("gru.")]
+
+
+def _up4(n: int) -> int:
+    return (n + 3) & ~3
+
+
+class FusedTrainer:
+    def __init__(self, hypernet, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 max_norm: float = 5.0, group=None):
+        """hypernet: a hypernet_attention.HyperNet (this package's) already on a CUDA device."""
+        self.net = hypernet
+        self.cap = hypernet.captioner
+        self.shape: ops.HyperShape = hypernet._shape
+        self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
+        self.group = group
+        self.step_count = 0
+        dev = self.cap.fc.weight.device
+        if dev.type != "cuda":
+            raise CaphnError("FusedTrainer needs the model on a CUDA(HIP) device")
+        self.dev = dev
+        if self.cap.layers or self.cap.drop.p > 0:
+            raise NotImplementedError("fused step supports num_layers=1, dropout p=0")
+        self._build_arena()
+        self._bufs: Dict[Tuple[int, int, int], dict] = {}
+        nh = len(self.shape.heads)
+        self._acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._coef = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._part = torch.empty(L_sumsq_blocks(self.n_dense), dtype=torch.float64, device=dev)
+        self._acts_layout = ops.hyper_acts_layout(self.shape)
+        self._acts = torch.zeros(self._acts_layout["_total"][1], dtype=torch.float32, device=dev)
+        self._hyper_ws = None
+        self._tok = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._nh = nh
+
+    # ------------------------------------------------------------------ parameter arenas
+    def _build_arena(self):
+        net, cap = self.net, self.cap
+        hyper = net.hyper_named_tensors()
+        dec = {n: t for n, t in cap._named_tensors().items() if not n.startswith("gru.")}
+        nh = len(self.shape.heads)
+        order: List[Tuple[str, torch.nn.Parameter]] = []
+        for i in range(nh):                                   # theta-ordered second-layer biases
+            order.append((f"hn_heads.{i}.2.bias", hyper[f"hn_heads.{i}.2.bias"]))
+        self.theta_size = sum(p.numel() for _, p in order)
+        small = ["hn_base.0.weight", "hn_base.0.bias", "hn_base.2.weight", "hn_base.2.bias"]
+        for i in range(nh):
+            small += [f"hn_heads.{i}.0.weight", f"hn_heads.{i}.0.bias"]
+        for n in small:
+            order.append((n, hyper[n]))
+        self._hyper_small_end = None
+        offs, o = {}, 0
+        for k, (n, p) in enumerate(order):
+            # the theta block must be contiguous (no padding between the four biases)
+            if k >= nh:
+                o = _up4(o)
+            offs[n] = (o, p.numel(), tuple(p.shape))
+            o += p.numel()
+        self._hyper_small_end = _up4(o)
+        o = self._hyper_small_end
+        for n in _DEC_NAMES:
+            p = dec[n]
+            offs["captioner." + n] = (o, p.numel(), tuple(p.shape))
+            o = _up4(o + p.numel())
+        self.n_dense = o
+        self.offs = offs
+        dev = self.dev
+        self.flat_p = torch.zeros(o, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(o, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(o, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(o, dtype=torch.float32, device=dev)
+        self._owned: Dict[str, torch.nn.Parameter] = {}
+        for n, p in order:
+            self._adopt(n, p)
+        for n in _DEC_NAMES:
+            self._adopt("captioner." + n, dec[n])
+        # rank-1 group
+        self.W2 = [hyper[f"hn_heads.{i}.2.weight"] for i in range(nh)]
+        for w in self.W2:
+            w.data = w.data.contiguous()
+        self.W2_m = [torch.zeros_like(w.data) for w in self.W2]
+        self.W2_v = [torch.zeros_like(w.data) for w in self.W2]
+
+    def _view(self, flat, name):
+        o, n, shape = self.offs[name]
+        return flat[o:o + n].view(shape)
+
+    def _adopt(self, name, p):
+        v = self._view(self.flat_p, name)
+        v.copy_(p.data)
+        p.data = v
+        p.grad = self._view(self.flat_g, name)
+        self._owned[name] = p
+
+    def _sync_params(self):
+        """Callers may swap sub-modules (captioner.embed = ...from_pretrained, hypernet_attention.py:108;
+        sub-module transplant :424-428).  Re-adopt any parameter whose storage left the arena."""
+        hyper = self.net.hyper_named_tensors()
+        dec = {"captioner." + n: t for n, t in self.cap._named_tensors().items() if not n.startswith("gru.")}
+        for name in self.offs:
+            cur = hyper.get(name, dec.get(name))
+            o, n, shape = self.offs[name]
+            if cur.data_ptr() != self.flat_p.data_ptr() + 4 * o or tuple(cur.shape) != shape:
+                if tuple(cur.shape) != shape:
+                    raise CaphnError(f"{name}: shape changed to {tuple(cur.shape)}, arena holds {shape}")
+                self._adopt(name, cur)
+        for i in range(self._nh):
+            w = hyper[f"hn_heads.{i}.2.weight"]
+            if w is not self.W2[i] or not w.data.is_contiguous():
+                w.data = w.data.contiguous()
+                self.W2[i] = w
+
+    # ------------------------------------------------------------------ per-shape buffers
+    def _buffers(self, B, T, P):
+        key = (B, T, P)
+        b = self._bufs.get(key)
+        if b is None:
+            c = self.cap
+            dims = ops.DecDims(B, T, P, c.num_features, c.feature_out, c.embedding_dim, c.hidden_dim, c.vocab_size)
+            b = {"dims": dims, "ws": ops.decoder_workspace(dims, self.dev),
+                 "logits": torch.empty(B, T, dims.V, dtype=torch.float32, device=self.dev),
+                 "alphas": torch.empty(B, T, P, dtype=torch.float32, device=self.dev),
+                 "loss": torch.zeros(2, dtype=torch.float32, device=self.dev)}
+            self._bufs[key] = b
+        return b
+
+    def _dec_tensors(self, theta_flat, grads: bool):
+        """decoder parameter (or gradient) dict; the GRU entries are slices of theta / dtheta."""
+        flat = self.flat_g if grads else self.flat_p
+        d = {n: self._view(flat, "captioner." + n) for n in _DEC_NAMES}
+        c = self.cap
+        H3, EF, H = 3 * c.hidden_dim, c.embedding_dim + c.feature_out, c.hidden_dim
+        o = 0
+        for n, shape in (("gru.weight_ih", (H3, EF)), ("gru.weight_hh", (H3, H)), ("gru.bias_ih", (H3,)),
+                         ("gru.bias_hh", (H3,))):
+            k = 1
+            for s in shape:
+                k *= s
+            d[n] = theta_flat[o:o + k].view(shape)
+            o += k
+        assert o == self.theta_size, "hypernet heads do not match the GRUCell parameter sizes"
+        return d
+
+    # ------------------------------------------------------------------ the step
+    def forward_backward(self, features, captions, x_style=None, style_token: Optional[int] = None,
+                         validate: bool = False):
+        """Fills the gradient arena (and the rank-1 factors) for one minibatch; returns the device
+        tensor [loss, n_valid_targets].  Exactly one of x_style ([he] or [1,he]) / style_token (Flickr
+        path: x = captioner.embed.weight[token], hypernet_attention.py:139-142)."""
+        if (x_style is None) == (style_token is None):
+            raise CaphnError("pass exactly one of x_style / style_token")
+        self._sync_params()
+        B, P, _ = features.shape
+        T = captions.shape[1]
+        buf = self._buffers(B, T, P)
+        dims = buf["dims"]
+        hp = {n: self._owned[n].data for n in self.shape.param_names() if n in self._owned}
+        for i in range(self._nh):
+            hp[f"hn_heads.{i}.2.weight"] = self.W2[i].data
+        if style_token is not None:
+            x = self._view(self.flat_p, "captioner.embed.weight")[style_token]
+        else:
+            x = x_style.reshape(-1).to(device=self.dev, dtype=torch.float32)
+        theta = getattr(self, "_theta", None)
+        if theta is None:
+            theta = self._theta = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)
+        ops.hyper_forward(self.shape, hp, x, theta=theta, acts=self._acts)
+        params = self._dec_tensors(theta, grads=False)
+        ops.decoder_forward(dims, params, features, captions, buf["ws"], logits=buf["logits"], alphas=buf["alphas"],
+                            validate=validate)
+        lib_loss, dlogits = ops.cross_entropy_fwd_bwd(buf["logits"], captions, 0, dlogits=buf["logits"])
+        buf["loss"].copy_(lib_loss)
+        dtheta = self.flat_g[:self.theta_size]
+        grads = self._dec_tensors(dtheta, grads=True)
+        ops.decoder_backward(dims, params, features, captions, dlogits, grads, buf["ws"])
+        hg = {n: self._view(self.flat_g, n) for n in self.offs if n.startswith("hn_")}
+        if self._hyper_ws is None:
+            import ctypes as C
+            from . import _lib as L
+            d = ops._hyper_desc(self.shape, hp)
+            self._hyper_ws = torch.empty(L.load().caphn_hyper_backward_workspace_bytes(C.byref(d)),
+                                         dtype=torch.uint8, device=self.dev)
+        work = None
+        if style_token is None:
+            # the decoder part of the arena is final: start its all-reduce so it overlaps the
+            # hypernet VJP, which streams the 576 MB of second-layer weights
+            work = dp.all_reduce_dense(self.flat_g[self._hyper_small_end:], self.group, async_op=True)
+        gx = ops.hyper_backward(self.shape, hp, dtheta, self._acts, hg, want_x=style_token is not None,
+                                ws=self._hyper_ws)
+        if style_token is not None:
+            # Flickr path: the style row of the embedding also feeds the hypernet -- add its VJP to the
+            # embedding gradient before that gradient is reduced
+            self._tok.fill_(int(style_token))
+            ops.embedding_scatter_add(gx.view(1, -1), self._tok, self._view(self.flat_g, "captioner.embed.weight"))
+            work = dp.all_reduce_dense(self.flat_g[self._hyper_small_end:], self.group, async_op=True)
+        self._pending = work
+        return buf["loss"]
+
+    def _exchange(self):
+        """All-gather the rank-1 factors, finish the dense all-reduce.  Returns (gfac [R,theta], acts_all [R,L])."""
+        R = dp.world(self.group)
+        L_acts = self._acts.numel()
+        if R == 1:
+            return self.flat_g[:self.theta_size].view(1, -1), self._acts.view(1, -1)
+        pack = torch.cat([self.flat_g[:self.theta_size], self._acts])
+        allp = dp.all_gather_factors(pack, group=self.group)                    # [R, theta + L]
+        hs = dp.all_reduce_dense(self.flat_g[:self._hyper_small_end], self.group, async_op=True)
+        if self._pending is not None:
+            self._pending.wait()
+        if hs is not None:
+            hs.wait()
+        self._pending = None
+        return allp[:, :self.theta_size], allp[:, self.theta_size:self.theta_size + L_acts]
+
+    def optimizer_step(self):
+        """clip_grad_norm_(max_norm) over ALL gradients + Adam, on device, no host sync."""
+        R = dp.world(self.group)
+        gfac, acts_all = self._exchange()
+        self.step_count += 1
+        part = ops.sumsq_partials(self.flat_g, self._part)
+        self._acc.zero_()
+        o = 0
+        segs = []
+        for i, (k, w) in enumerate(self.shape.heads):
+            ao, an = self._acts_layout[f"a{i}"]
+            gi, ai = gfac[:, o:o + w], acts_all[:, ao:ao + an]
+            ops.rank_sumsq(gi, ai, self._acc)
+            segs.append((gi, ai))
+            o += w
+        ops.clip_coef(part, self._acc, self.max_norm, 1.0 / R, out=self._coef)
+        ops.adam_dense(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self._coef, self.lr, self.step_count,
+                       self.betas, self.eps)
+        for i, (gi, ai) in enumerate(segs):
+            ops.adam_rank(self.W2[i].data, self.W2_m[i], self.W2_v[i], gi, ai, self._coef, self.lr, self.step_count,
+                          self.betas, self.eps)
+        return self._coef
+
+    def step(self, features, captions, x_style=None, style_token=None):
+        loss = self.forward_backward(features, captions, x_style, style_token)
+        self.optimizer_step()
+        return loss
+
+    # ------------------------------------------------------------------ introspection for tests
+    def grad(self, name):
+        return self._view(self.flat_g, name)
+
+    def w2_grad_dense(self, i):
+        """Materialise dW2_i (tests only): sum_r dtheta_r (x) a_r of the LOCAL rank."""
+        o = sum(w for _, w in self.shape.heads[:i])
+        k, w = self.shape.heads[i]
+        ao, an = self._acts_layout[f"a{i}"]
+        return ops.outer(self.flat_g[o:o + w].contiguous(), self._acts[ao:ao + an].contiguous())
+
+
+def L_sumsq_blocks(n):
+    from . import _lib as L
+    return L.load().caphn_sumsq_blocks(n)

@@ -1,0 +1,73 @@
+"""torch.autograd.Function wrappers: the reference's module API on top of the C ABI.
+
+Autograd only carries graph edges here; every forward/backward body is a libcaphn call.
+"""
+from typing import Dict, List
+
+import torch
+
+from . import ops
+from ._lib import CaphnError
+
+_DEC_ORDER: List[str] = list(ops.DEC_FIELD_TO_NAME.values())
+
+
+class _DecoderFn(torch.autograd.Function):
+    """AttentionGru.forward(features, captions, sample_prob=0.0)   models/decoderlstm.py:49-120"""
+
+    @staticmethod
+    def forward(ctx, dims, features, captions, *tensors):
+        params = {n: t.detach().contiguous() for n, t in zip(_DEC_ORDER, tensors)}
+        features = features.detach().contiguous()
+        captions = captions.contiguous()
+        ws = ops.decoder_workspace(dims, features.device)
+        logits, alphas = ops.decoder_forward(dims, params, features, captions, ws)
+        ctx.dims, ctx.ws, ctx.params, ctx.features, ctx.captions = dims, ws, params, features, captions
+        return logits, alphas
+
+    @staticmethod
+    def backward(ctx, dlogits, dalphas):
+        dims = ctx.dims
+        dev = ctx.features.device
+        if dlogits is None:
+            dlogits = torch.zeros(dims.B, dims.T, dims.V, device=dev)
+        grads = {n: torch.empty(s, dtype=torch.float32, device=dev) for n, s in dims.param_shapes().items()}
+        ops.decoder_backward(dims, ctx.params, ctx.features, ctx.captions, dlogits.contiguous(), grads, ctx.ws,
+                             dalphas.contiguous() if dalphas is not None else None)
+        ctx.ws = None
+        return (None, None, None) + tuple(grads[n] for n in _DEC_ORDER)
+
+
+def attention_gru_forward(dims: ops.DecDims, features: torch.Tensor, captions: torch.Tensor,
+                          named: Dict[str, torch.Tensor]):
+    if not features.is_cuda:
+        raise CaphnError("AttentionGru.forward runs on libcaphn's HIP kernels only: move the module and its "
+                         "inputs to a CUDA(HIP) device (there is no CPU fallback)")
+    return _DecoderFn.apply(dims, features.float(), captions.long(), *[named[n] for n in _DEC_ORDER])
+
+
+class _HyperFn(torch.autograd.Function):
+    """theta = cat_i head_i(hn_base(x))   hypernet_attention.py:111-118"""
+
+    @staticmethod
+    def forward(ctx, shape, x, *tensors):
+        names = shape.param_names()
+        params = {n: t.detach().contiguous() for n, t in zip(names, tensors)}
+        theta, acts = ops.hyper_forward(shape, params, x.detach().float())
+        ctx.shape, ctx.params, ctx.acts, ctx.xshape = shape, params, acts, x.shape
+        ctx.need_x = x.requires_grad
+        return theta
+
+    @staticmethod
+    def backward(ctx, dtheta):
+        shape = ctx.shape
+        dev = dtheta.device
+        grads = {n: torch.empty(s, dtype=torch.float32, device=dev) for n, s in shape.param_shapes().items()}
+        gx = ops.hyper_backward(shape, ctx.params, dtheta.contiguous(), ctx.acts, grads, want_x=ctx.need_x)
+        return (None, gx.reshape(ctx.xshape) if gx is not None else None) + tuple(grads[n] for n in shape.param_names())
+
+
+def hyper_forward(shape: ops.HyperShape, x: torch.Tensor, named: Dict[str, torch.Tensor]) -> torch.Tensor:
+    if not x.is_cuda:
+        raise CaphnError("HyperNet.forward runs on libcaphn's HIP kernels only (no CPU fallback)")
+    return _HyperFn.apply(shape, x, *[named[n] for n in shape.param_names()])

@@ -1,0 +1,108 @@
+"""HyperNet with the reference's constructor, attributes and forward contract
+(hypernet_attention.py:32-121): hn_base + per-parameter heads emit the GRUCell weights of
+`captioner` for one style/domain row; forward(x) injects them and returns the captioner.
+
+The metric/beam-search/wandb parts of the reference class are out of scope;
+pytorch_lightning is optional (the class is a plain nn.Module without it).
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from caphn import functional as CF
+from caphn import ops
+from models.decoderlstm import AttentionGru
+from models.encoder import EncoderCNN
+from utils import flip_parameters_to_tensors, set_all_parameters
+
+try:  # the reference subclasses pl.LightningModule; keep that when Lightning is installed
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    pl = None
+    _Base = nn.Module
+
+
+def build_hypernet_layers(cell: nn.Module, hyper_emb: int):
+    """Head-sizing rule of hypernet_attention.py:55-99 (N = 1, M = 500)."""
+    N, M = 1, 500
+    hn_base = nn.Sequential(nn.Linear(hyper_emb, N * hyper_emb), nn.LeakyReLU(),
+                            nn.Linear(N * hyper_emb, N * hyper_emb), nn.LeakyReLU())
+    heads = []
+    for name, W in cell.named_parameters():
+        if name in ('embed.weight', 'fc_out.weight', 'fc_out.bias'):
+            continue
+        w_size = len(W.flatten())
+        if w_size < N * hyper_emb:
+            raise ValueError("head rule branch 'w < hyper_emb' (hypernet_attention.py:78-83) builds "
+                             "Linear(he,1)->Linear(w,w), which cannot run; unsupported")
+        if w_size // M < N * hyper_emb:
+            heads.append(nn.Sequential(nn.Linear(N * hyper_emb, N * hyper_emb), nn.LeakyReLU(),
+                                       nn.Linear(N * hyper_emb, w_size)))
+        else:
+            heads.append(nn.Sequential(nn.Linear(N * hyper_emb, w_size // M), nn.LeakyReLU(),
+                                       nn.Linear(w_size // M, w_size)))
+    return hn_base, nn.ModuleList(heads)
+
+
+class HyperNet(_Base):
+    def __init__(self, feature_size, embed_size, hidden_size, vocab_size, vocab, num_layers=1, lr=1e-6,
+                 mixup=False, alpha=0.3, cc=False, hyper_emb=10):
+        super().__init__()
+        hp = self.hparams if pl is not None else {}
+        hp['feature_size'] = feature_size; hp['vocab_size'] = vocab_size; hp['embed_size'] = embed_size
+        hp['hidden_size'] = hidden_size; hp['lr'] = lr; hp['num_layers'] = num_layers
+        if pl is None:
+            self.hparams = hp
+        self.vocab = vocab
+        self.teacher_forcing_proba = 0.0
+        self.beam_size = 3
+        self.mixup = mixup
+        self.alpha = alpha
+        self.image_encoder = EncoderCNN()
+        self.captioner = AttentionGru(2048, feature_size, embed_size, hidden_size, vocab_size, p=0.0)
+        if not cc:
+            hyper_emb = embed_size
+        self.hyper_emb = hyper_emb
+        self.hn_base, self.hn_heads = build_hypernet_layers(self.captioner.gru, hyper_emb)
+        self._shape = ops.HyperShape(hyper_emb, [(h[0].out_features, h[2].out_features) for h in self.hn_heads])
+
+    def hyper_named_tensors(self):
+        t = {"hn_base.0.weight": self.hn_base[0].weight, "hn_base.0.bias": self.hn_base[0].bias,
+             "hn_base.2.weight": self.hn_base[2].weight, "hn_base.2.bias": self.hn_base[2].bias}
+        for i, h in enumerate(self.hn_heads):
+            t[f"hn_heads.{i}.0.weight"] = h[0].weight; t[f"hn_heads.{i}.0.bias"] = h[0].bias
+            t[f"hn_heads.{i}.2.weight"] = h[2].weight; t[f"hn_heads.{i}.2.bias"] = h[2].bias
+        return t
+
+    def forward(self, x):
+        """hypernet_attention.py:111-121.  x: [1,he] (Flickr) or [he] (CC one-hot row)."""
+        heads_out = CF.hyper_forward(self._shape, x, self.hyper_named_tensors())
+        flip_parameters_to_tensors(self.captioner.gru)
+        set_all_parameters(self.captioner.gru, heads_out.reshape(1, -1))
+        return self.captioner
+
+    def configure_optimizers(self):
+        """hypernet_attention.py:123-133 (parameter order kept)."""
+        params = list(self.hn_heads.parameters())
+        params.extend(list(self.hn_base.parameters()))
+        params.extend(list(self.captioner.feature_fc.parameters()))
+        params.extend(list(self.captioner.embed.parameters()))
+        params.extend(list(self.captioner.fc.parameters()))
+        params.extend(list(self.captioner.attention.parameters()))
+        params.extend(list(self.captioner.init_h.parameters()))
+        optimizer = torch.optim.Adam(params, lr=self.hparams['lr'])
+        scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, cooldown=2, factor=0.5)
+        return [optimizer], [{'scheduler': scheduler, 'monitor': 'val_loss with TF', 'interval': 'epoch'}]
+
+    def training_step(self, train_batch, batch_idx):
+        """hypernet_attention.py:136-204 without the mixup/BERT and text-metric parts."""
+        imgs, (style, (caps, lengths)) = train_batch
+        dev = self.captioner.embed.weight.device
+        style = torch.tensor([self.vocab(style)], dtype=torch.long, device=dev)
+        style_embed = self.captioner.embed(style)
+        self.forward(style_embed)
+        img_feats = self.image_encoder(imgs.float())
+        caps_pred, _ = self.captioner(img_feats, caps.long(), self.teacher_forcing_proba)
+        return F.cross_entropy(caps_pred.view(-1, self.hparams['vocab_size']), caps.view(-1).long(),
+                               ignore_index=self.vocab.w2i['<pad>'])

@@ -150,7 +150,7 @@ def test_cross_entropy_matches_torch(ops):
     out, dl = ops.cross_entropy_fwd_bwd(logits.to(DEV), tgt.to(DEV), 0)
     assert abs(float(out[0]) - float(ref)) < 2e-6
     assert int(out[1]) == int((tgt != 0).sum())
-    assert maxdiff(dl.cpu(), lr.grad) < 1e-8
+    assert maxdiff(dl.cpu(), lr.grad) < 1e-7      # values ~1e-2: fp32 rounding
     # in place
     lg = logits.to(DEV)
     out2, dl2 = ops.cross_entropy_fwd_bwd(lg, tgt.to(DEV), 0, dlogits=lg)

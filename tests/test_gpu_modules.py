@@ -1,0 +1,169 @@
+"""GPU parity of the drop-in module API (models.decoderlstm / hypernet_attention / utils) and of the
+fused training engine against the golden vectors produced by the reference's modules."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import caphn_oracle as O
+from helpers import TINY_DIMS, load_case, maxdiff, style_args
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CASES = ["gru_tiny_flickr", "gru_tiny_cc", "gru_odd_cc"]
+
+
+class _Vocab:
+    w2i = {"<pad>": 0, "<s>": 1, "</s>": 2, "<unk>": 3, "factual": 4, "humorous": 5, "romantic": 6}
+
+    def __call__(self, w):
+        return self.w2i.get(w, 3)
+
+
+def build_net(dims, p, cc):
+    from hypernet_attention import HyperNet
+    from models.decoderlstm import AttentionGru
+    net = HyperNet(dims.F, dims.E, dims.H, dims.V, _Vocab(), cc=cc, hyper_emb=dims.he)
+    net.captioner = AttentionGru(dims.D, dims.F, dims.E, dims.H, dims.V, p=0.0)   # tiny D instead of 2048
+    res = net.load_state_dict(p, strict=False)
+    assert all(k.startswith("captioner.gru.") for k in res.missing_keys), res
+    assert not res.unexpected_keys, res
+    return net.to(DEV)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_module_api_forward_backward(name):
+    from caphn import config
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    net = build_net(dims, p, cc=tok is None)
+    feats, caps = g["features"].to(DEV), g["captions"].to(DEV)
+    config.DETACH_THETA = False
+    xs = net.captioner.embed(torch.tensor([tok], device=DEV)) if tok is not None else x.to(DEV)
+    captioner = net.forward(xs)
+    assert captioner is net.captioner
+    assert net.captioner.gru.registered_parameters_name == ["weight_ih", "weight_hh", "bias_ih", "bias_hh"]
+    logits, alphas = captioner(feats, caps.long(), 0.0)
+    assert logits.shape == g["logits"].shape and alphas.shape == g["alphas"].shape
+    assert maxdiff(logits.detach().cpu(), g["logits"]) < 2e-6
+    assert maxdiff(alphas.detach().cpu(), g["alphas"]) < 1e-6
+    loss = F.cross_entropy(logits.view(-1, dims.V), caps.view(-1).long(), ignore_index=0)
+    loss.backward()
+    sd = dict(net.named_parameters())
+    for k, v in g.items():
+        if k.startswith("gint/"):
+            assert maxdiff(sd[k[5:]].grad.cpu(), v) < 2e-6, k
+        elif k.startswith("glit/") and not (tok is not None and k.endswith("embed.weight")):
+            assert maxdiff(sd[k[5:]].grad.cpu(), v) < 2e-6, k
+    # second forward: injection is idempotent (flip finds the attached tensors)
+    net.forward(xs.detach())
+    l2, _ = net.captioner(feats, caps.long(), 0.0)
+    assert maxdiff(l2.detach().cpu(), g["logits"]) < 2e-6
+
+
+@pytest.mark.parametrize("name", CASES[:2])
+def test_module_api_literal_detached(name):
+    """DETACH_THETA=True reproduces utils.py:57: generated weights are fresh leaf Parameters, the
+    hypernet gets no gradient, captioner.gru.weight_ih.grad holds dL/dtheta."""
+    from caphn import config
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    net = build_net(dims, p, cc=tok is None)
+    config.DETACH_THETA = True
+    try:
+        xs = net.captioner.embed(torch.tensor([tok], device=DEV)) if tok is not None else x.to(DEV)
+        net.forward(xs)
+        gru = net.captioner.gru
+        assert all(isinstance(getattr(gru, n), torch.nn.Parameter) for n in gru.registered_parameters_name)
+        logits, _ = net.captioner(g["features"].to(DEV), g["captions"].to(DEV), 0.0)
+        F.cross_entropy(logits.view(-1, dims.V), g["captions"].to(DEV).view(-1), ignore_index=0).backward()
+        assert all(q.grad is None for q in list(net.hn_base.parameters()) + list(net.hn_heads.parameters()))
+        dth = torch.cat([getattr(gru, n).grad.flatten() for n in gru.registered_parameters_name])
+        assert maxdiff(dth.cpu(), g["dtheta"]) < 2e-6
+        assert maxdiff(net.captioner.embed.weight.grad.cpu(), g["glit/captioner.embed.weight"]) < 2e-6
+        net.forward(xs)          # re-registration keeps working step after step
+        assert "weight_ih" in dict(gru.named_parameters())
+    finally:
+        config.DETACH_THETA = False
+
+
+def test_module_errors():
+    from caphn._lib import CaphnError
+    from models.decoderlstm import AttentionGru
+    m = AttentionGru(32, 16, 16, 16, 50)
+    with pytest.raises(CaphnError):
+        m(torch.zeros(2, 7, 32), torch.zeros(2, 5, dtype=torch.long))       # CPU tensors: no fallback
+    m = m.to(DEV)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 7, 32, device=DEV), torch.zeros(2, 5, dtype=torch.long, device=DEV), 1.0)
+    with pytest.raises(CaphnError):
+        m(torch.zeros(2, 7, 31, device=DEV), torch.zeros(2, 5, dtype=torch.long, device=DEV))
+    with pytest.raises(IndexError):
+        m(torch.zeros(2, 7, 32, device=DEV), torch.full((2, 5), 50, dtype=torch.long, device=DEV))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fused_engine_step(name):
+    from caphn.engine import FusedTrainer
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    net = build_net(dims, p, cc=tok is None)
+    max_norm = float(g["clip_max_norm"])
+    tr = FusedTrainer(net, lr=1e-3, max_norm=max_norm)
+    feats, caps = g["features"].to(DEV), g["captions"].to(DEV)
+    loss = tr.forward_backward(feats, caps, x_style=None if tok is not None else x.to(DEV), style_token=tok,
+                               validate=True)
+    assert abs(float(loss[0]) - float(g["loss"])) < 2e-6
+    assert maxdiff(tr.flat_g[:tr.theta_size].cpu(), g["dtheta"]) < 2e-6
+    mine = {}
+    for k, v in g.items():
+        if k.startswith(("gint/", "glit/")):
+            nm = k[5:]
+            if k.startswith("glit/") and tok is not None and nm == "captioner.embed.weight":
+                continue
+            if nm.endswith(".2.weight") and nm.startswith("hn_heads."):
+                got = tr.w2_grad_dense(int(nm.split(".")[1]))
+            else:
+                got = tr.grad(nm)
+            assert maxdiff(got.cpu(), v) < 2e-6, k
+            mine[nm] = got.cpu().clone()
+    # clip + Adam: the oracle's optimiser fed with the engine's own gradients must land on the same
+    # parameters (Adam's first step amplifies rounding noise on ~0 gradients, so identical inputs)
+    p2 = {k: v.clone() for k, v in p.items()}
+    _, tot, _, _ = O.train_step(dims, p2, {}, 1, x, g["features"], g["captions"], lr=1e-3, max_norm=max_norm,
+                                style_token=tok, grads_override=mine)
+    coef = tr.optimizer_step()
+    assert abs(float(coef[1]) - tot) < 1e-5 * max(tot, 1.0)
+    sd = dict(net.named_parameters())
+    for n in O.trainable_names(p):
+        assert maxdiff(sd[n].detach().cpu(), p2[n]) < 2e-7, n
+    # and close to the reference's own optimiser step (looser: see above)
+    for k, v in g.items():
+        if k.startswith("padam/"):
+            tol = 2.1e-3 if k.endswith("v_a.bias") else 1e-5
+            assert maxdiff(sd[k[6:]].detach().cpu(), v) < tol, k
+    # a second step runs and changes the loss
+    l2 = tr.step(feats, caps, x_style=None if tok is not None else x.to(DEV), style_token=tok)
+    assert float(l2[0]) != float(loss[0])
+
+
+def test_engine_tracks_swapped_submodule():
+    """captioner.embed = captioner.embed.from_pretrained(...) (hypernet_attention.py:108) must be honoured."""
+    from caphn.engine import FusedTrainer
+    name = "gru_tiny_cc"
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, _ = style_args(g)
+    net = build_net(dims, p, cc=True)
+    tr = FusedTrainer(net)
+    feats, caps = g["features"].to(DEV), g["captions"].to(DEV)
+    l0 = float(tr.forward_backward(feats, caps, x_style=x.to(DEV))[0])
+    new = torch.randn(dims.V, dims.E, generator=torch.Generator().manual_seed(0))
+    net.captioner.embed = net.captioner.embed.from_pretrained(new.to(DEV), freeze=False)
+    l1 = float(tr.forward_backward(feats, caps, x_style=x.to(DEV))[0])
+    p2 = dict(p); p2["captioner.embed.weight"] = new
+    ref, *_ = O.forward_backward(dims, p2, x, g["features"], g["captions"])
+    assert abs(l1 - float(ref)) < 2e-6 and abs(l0 - float(g["loss"])) < 2e-6
