@@ -58,23 +58,49 @@ def synth_batches(n, B, T, P, D, V, device, seed):
     return out
 
 
-def cpu_baseline(B, T, P, steps=4):
-    """Oracle (port of the reference's path) on the host cores: forward, backward, clip, Adam."""
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(B, T, P, budget_s=25.0, max_steps=5):
+    """Oracle (port of the reference's path) on the host cores: forward, backward, clip, Adam.
+    Bounded: stops after max_steps timed steps or budget_s seconds."""
     from oracle import caphn_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    cores = usable_cores()
+    torch.set_num_threads(cores)
     dims = O.Dims()
     p = O.init_params(dims, seed=1)
     batch = O.synth_batch(dims, B, T, P, seed=2)
     state = {}
+    t_start = time.perf_counter()
     O.train_step(dims, p, state, 1, None, batch["features"], batch["captions"], lr=1e-3, style_token=4)  # warm-up
     ts = []
-    for s in range(steps):
+    for s in range(max_steps):
         t0 = time.perf_counter()
         O.train_step(dims, p, state, s + 2, None, batch["features"], batch["captions"], lr=1e-3, style_token=4)
         ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s:
+            break
     med = float(np.median(ts))
-    return {"value": B / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} full steps (fwd+bwd+clip+Adam) at B={B}, T={T}, fp32, median {med * 1e3:.0f} ms/step"}
+    return {"value": B / med, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{len(ts)} full steps (fwd+bwd+clip+Adam) at B={B}, T={T}, fp32, after 1 warm-up; "
+                      f"median {med * 1e3:.0f} ms/step"}
 
 
 def main():
