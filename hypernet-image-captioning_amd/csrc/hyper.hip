@@ -173,36 +173,59 @@ __global__ __launch_bounds__(256) void gemv_t_partial_kernel(GemvTJobs jobs) {
     }
 }
 
+// Column reductions with 1024-thread blocks laid out as 64 columns x 16 row lanes: every thread
+// strides over rows, the 16 partial sums of a column meet in LDS.  (A thread-per-column loop over
+// hundreds of rows is a chain of dependent-latency loads: 100-300 us for a few hundred KB.)
+constexpr int RL = 16;
+__device__ __forceinline__ float col_reduce_finish(float acc, float (*red)[65]) {
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    red[rl][c] = acc;
+    __syncthreads();
+    float s = 0.f;
+    if (rl == 0) {
+#pragma unroll
+        for (int i = 0; i < RL; ++i) s += red[i][c];
+    }
+    return s;
+}
+
 // out[c] = (sum_blocks partial[blk][c]) * lrelu'(post[c]); written to up to two sinks
 struct ReduceJob { const float* partial; const float* post; float* out0; float* out1; int k, nblocks; };
 struct ReduceJobs { ReduceJob j[CAPHN_MAX_HEADS]; int n; };
-__global__ void gemv_t_reduce_kernel(ReduceJobs jobs) {
+__global__ __launch_bounds__(1024) void gemv_t_reduce_kernel(ReduceJobs jobs) {
+    __shared__ float red[RL][65];
     const ReduceJob& J = jobs.j[blockIdx.y];
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= J.k) return;
-    float s = 0.f;
-    for (int b = 0; b < J.nblocks; ++b) s += J.partial[(size_t)b * J.k + c];
-    if (J.post) s *= lrelu_grad(J.post[c]);
-    if (J.out0) J.out0[c] = s;
-    if (J.out1) J.out1[c] = s;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    if (blockIdx.x * 64 >= J.k) return;
+    float acc = 0.f;
+    if (c < J.k)
+        for (int b = rl; b < J.nblocks; b += RL) acc += J.partial[(size_t)b * J.k + c];
+    float s = col_reduce_finish(acc, red);
+    if (rl == 0 && c < J.k) {
+        if (J.post) s *= lrelu_grad(J.post[c]);
+        if (J.out0) J.out0[c] = s;
+        if (J.out1) J.out1[c] = s;
+    }
 }
 
-// small matrices: y[c] = (sum_jobs sum_r W_j[r][c] d_j[r]) * lrelu'(post[c]); one thread per column
+// small matrices: y[c] = (sum_jobs sum_r W_j[r][c] d_j[r]) * lrelu'(post[c])
 struct SmallTJob { const float* W; const float* d; int rows; };
 struct SmallTArgs { SmallTJob j[CAPHN_MAX_HEADS]; int n; int k; const float* post; float* out0; float* out1; };
-__global__ void gemv_t_small_kernel(SmallTArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.k) return;
-    float s = 0.f;
-    for (int i = 0; i < a.n; ++i) {
-        const SmallTJob& J = a.j[i];
-        float t = 0.f;
-        for (int r = 0; r < J.rows; ++r) t += J.W[(size_t)r * a.k + c] * J.d[r];
-        s += t;
+__global__ __launch_bounds__(1024) void gemv_t_small_kernel(SmallTArgs a) {
+    __shared__ float red[RL][65];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < a.k)
+        for (int i = 0; i < a.n; ++i) {
+            const SmallTJob& J = a.j[i];
+            for (int r = rl; r < J.rows; r += RL) acc += J.W[(size_t)r * a.k + c] * J.d[r];
+        }
+    float s = col_reduce_finish(acc, red);
+    if (rl == 0 && c < a.k) {
+        if (a.post) s *= lrelu_grad(a.post[c]);
+        if (a.out0) a.out0[c] = s;
+        if (a.out1) a.out1[c] = s;
     }
-    if (a.post) s *= lrelu_grad(a.post[c]);
-    if (a.out0) a.out0[c] = s;
-    if (a.out1) a.out1[c] = s;
 }
 
 // dense outer products out_j[r][c] = g_j[r] * a_j[c]
@@ -301,7 +324,7 @@ struct BwdWs { size_t partial[CAPHN_MAX_HEADS]; int nblocks[CAPHN_MAX_HEADS]; si
 inline BwdWs bwd_ws(const caphn_hyper_desc* d) {
     BwdWs w; size_t o = 0;
     for (int i = 0; i < d->n_heads; ++i) {
-        int nb = (int)std::min<long>(1024, ((long)d->w[i] + 15) / 16);
+        int nb = (int)std::min<long>(512, ((long)d->w[i] + 15) / 16);
         if (nb < 1) nb = 1;
         w.nblocks[i] = nb;
         w.partial[i] = o; o += caphn_align_up((size_t)nb * d->k[i], 4);
@@ -352,22 +375,22 @@ extern "C" int caphn_hyper_backward(const caphn_hyper_desc* d, const float* dthe
             R.partial = ws + W.partial[i]; R.post = acts + L.a[i]; R.out0 = ws + W.dz[i]; R.out1 = g->g_b1[i];
             R.k = d->k[i]; R.nblocks = W.nblocks[i];
         }
-        hipLaunchKernelGGL(gemv_t_reduce_kernel, dim3((kmax + 127) / 128, nh), dim3(128), 0, s, rj);
+        hipLaunchKernelGGL(gemv_t_reduce_kernel, dim3((kmax + 63) / 64, nh), dim3(1024), 0, s, rj);
     }
     {   // dbase = sum_i W1_i^T dz_i ; dzb2 = dbase * lrelu'(base)
         SmallTArgs a; a.n = nh; a.k = d->he; a.post = acts + L.base; a.out0 = ws + W.dzb2; a.out1 = g->g_base_b2;
         for (int i = 0; i < nh; ++i) { a.j[i].W = d->w1[i]; a.j[i].d = ws + W.dz[i]; a.j[i].rows = d->k[i]; }
-        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(1024), 0, s, a);
     }
     {   // da0 = Wb2^T dzb2 ; dzb0 = da0 * lrelu'(a0)
         SmallTArgs a; a.n = 1; a.k = d->he; a.post = acts + L.a0; a.out0 = ws + W.dzb0; a.out1 = g->g_base_b0;
         a.j[0].W = d->base_w2; a.j[0].d = ws + W.dzb2; a.j[0].rows = d->he;
-        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(1024), 0, s, a);
     }
     if (g->g_x) {   // dx = Wb0^T dzb0
         SmallTArgs a; a.n = 1; a.k = d->he; a.post = nullptr; a.out0 = g->g_x; a.out1 = nullptr;
         a.j[0].W = d->base_w0; a.j[0].d = ws + W.dzb0; a.j[0].rows = d->he;
-        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(1024), 0, s, a);
     }
     {   // dense weight grads (rank-1 outer products)
         OuterJobs oj; oj.n = 0; long b0 = 0;

@@ -76,32 +76,29 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(int rows, const float* _
 }
 
 // ------------------------------------------------------------------ column sums
-// stage 1: part[s][n] = sum over row slice s ; stage 2: out[n] = sum_s part[s][n]
-__global__ __launch_bounds__(256) void colsum_part_kernel(int M, int N, const float* __restrict__ A, int lda, float* __restrict__ part, int rows_per) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+// 256-thread blocks = 64 columns x 4 row lanes; grid.y slices the rows.  Stage 1 writes
+// part[slice][n], stage 2 is the same kernel over part (one slice).
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* __restrict__ A, int lda,
+                                                     float* __restrict__ out, int rows_per) {
+    __shared__ float red[4][65];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
     const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int m = m0;
-    for (; m + 3 < m1; m += 4) {
-        s0 += A[(size_t)m * lda + n]; s1 += A[(size_t)(m + 1) * lda + n];
-        s2 += A[(size_t)(m + 2) * lda + n]; s3 += A[(size_t)(m + 3) * lda + n];
+    float s0 = 0.f, s1 = 0.f;
+    if (n < N) {
+        int m = m0 + rl;
+        for (; m + 4 < m1; m += 8) { s0 += A[(size_t)m * lda + n]; s1 += A[(size_t)(m + 4) * lda + n]; }
+        if (m < m1) s0 += A[(size_t)m * lda + n];
     }
-    for (; m < m1; ++m) s0 += A[(size_t)m * lda + n];
-    part[(size_t)blockIdx.y * N + n] = (s0 + s1) + (s2 + s3);
-}
-__global__ __launch_bounds__(256) void colsum_final_kernel(int S, int N, const float* __restrict__ part, float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int i = 0; i < S; ++i) s += part[(size_t)i * N + n];
-    out[n] = s;
+    red[rl][c] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && n < N) out[(size_t)blockIdx.y * N + n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 inline int colsum_slices(int M, int N) {
-    const int colblocks = (N + 255) / 256;
-    int S = 1024 / colblocks;            // aim at ~1024 workgroups
-    if (S < 1) S = 1;
-    if (S > (M + 7) / 8) S = (M + 7) / 8;
+    const int colblocks = (N + 63) / 64;
+    int S = 2048 / colblocks;            // aim at ~2048 workgroups
+    if (S > (M + 31) / 32) S = (M + 31) / 32;
+    if (S > 256) S = 256;
     if (S < 1) S = 1;
     return S;
 }
@@ -139,6 +136,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(size_t n, const float* __res
 }
 
 // Gram matrices of R rank-1 factors: ws[r*R+s] = g_r . g_s ; ws[R*R + r*R+s] = a_r . a_s
+// grid (R*R, 2, chunks): every block reduces one chunk and adds it with one fp64 atomic (ws zeroed first)
+constexpr int GRAM_CHUNKS = 64;
 __global__ __launch_bounds__(256) void rank_gram_kernel(int R, int rows, int k, const float* __restrict__ gfac, size_t ldg,
                                                         const float* __restrict__ afac, size_t lda, double* __restrict__ ws) {
     __shared__ double red[4];
@@ -147,12 +146,15 @@ __global__ __launch_bounds__(256) void rank_gram_kernel(int R, int rows, int k, 
     const float* u = which ? afac + (size_t)r * lda : gfac + (size_t)r * ldg;
     const float* v = which ? afac + (size_t)s * lda : gfac + (size_t)s * ldg;
     const int n = which ? k : rows;
+    const int per = (n + GRAM_CHUNKS - 1) / GRAM_CHUNKS;
+    const int i0 = blockIdx.z * per, i1 = min(n, i0 + per);
+    if (i0 >= i1) return;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) acc += (double)u[i] * (double)v[i];
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) acc += (double)u[i] * (double)v[i];
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) ws[(size_t)which * R * R + pair] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) atomicAdd(&ws[(size_t)which * R * R + pair], red[0] + red[1] + red[2] + red[3]);
 }
 __global__ void rank_gram_finish_kernel(int R, const double* __restrict__ ws, double* acc) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -301,8 +303,13 @@ extern "C" int caphn_colsum_f32(int M, int N, const float* A, int lda, float* ou
     const int S = colsum_slices(M, N);
     const int rows_per = (M + S - 1) / S;
     float* part = static_cast<float*>(ws);
-    hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 255) / 256, S), dim3(256), 0, s, M, N, A, lda, part, rows_per);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, S, N, part, out);
+    const int cb = (N + 63) / 64;
+    if (S == 1) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(cb, 1), dim3(256), 0, s, M, N, A, lda, out, M);
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3(cb, S), dim3(256), 0, s, M, N, A, lda, part, rows_per);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cb, 1), dim3(256), 0, s, S, N, part, N, out, S);
+    }
     return caphn_launch_status();
 }
 
@@ -328,7 +335,8 @@ extern "C" int caphn_rank_sumsq_f32(int R, int rows, int k, const float* gfac, s
                                     double* acc, double* ws, caphn_stream_t stream) {
     if (R <= 0 || R > RMAX || rows <= 0 || k <= 0 || !gfac || !afac || !acc || !ws) return CAPHN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(rank_gram_kernel, dim3(R * R, 2), dim3(256), 0, s, R, rows, k, gfac, ldg, afac, lda, ws);
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * R * R, s) != hipSuccess) return CAPHN_ELAUNCH;
+    hipLaunchKernelGGL(rank_gram_kernel, dim3(R * R, 2, GRAM_CHUNKS), dim3(256), 0, s, R, rows, k, gfac, ldg, afac, lda, ws);
     hipLaunchKernelGGL(rank_gram_finish_kernel, dim3(1), dim3(64), 0, s, R, ws, acc);
     return caphn_launch_status();
 }

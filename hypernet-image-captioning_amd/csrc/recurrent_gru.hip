@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 1024;            // 16 waves per workgroup: one workgroup per CU (LDS-bound), 4 waves per SIMD
 
 __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n, int vec, int tid) {
     if (vec) {
@@ -54,57 +54,83 @@ __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const f
     }
 }
 
+// thread -> (column k, group g) map used to split sums over p across thread groups
+struct KG { int k, g, ng; };
+__device__ __forceinline__ KG kg_map(int tid, int H) {
+    KG m;
+    m.ng = H >= NT ? 1 : NT / H;
+    m.g = H >= NT ? 0 : tid / H;
+    m.k = H >= NT ? tid : tid - m.g * H;
+    if (m.g >= m.ng) { m.g = -1; }      // spare threads
+    return m;
+}
+
 __global__ __launch_bounds__(NT) void gru_attn_fwd_kernel(GruFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P, H = a.H, H3 = 3 * a.H, T = a.T;
-    float* Waf_s = lds;
-    float* G_s = Waf_s + P * H;
+    const int Ppad = (P + 63) & ~63;
+    float* G_s = lds;
     float* h_s = G_s + P * H3;
     float* uah_s = h_s + H;
     float* va_s = uah_s + H;
     float* gh_s = va_s + H;
     float* e_s = gh_s + H3;
+    float* part_s = e_s + Ppad;          // [ng][3H]
 
-    copy_to_lds(Waf_s, a.Waf + (size_t)b * P * H, P * H, a.vecS, tid);
     copy_to_lds(G_s, a.G + (size_t)b * P * H3, P * H3, a.vecS, tid);
     for (int k = tid; k < H; k += NT) { h_s[k] = a.h0[(size_t)b * H + k]; va_s[k] = a.v_a[k]; }
     const float bva = a.b_va[0];
+    const float* Waf_b = a.Waf + (size_t)b * P * H;
+    const KG m = kg_map(tid, H);
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
         const size_t bt = (size_t)b * T + t;
-        // A: U_a h + b_Ua -> uah_s ; W_hh h + b_hh -> gh_s
+        // A: U_a h + b_Ua -> uah_s ; W_hh h + b_hh -> gh_s   (W_hh, U_a streamed from L2)
         matvec_rows(a.U_a, a.b_Ua, h_s, uah_s, H, H, a.vecW, tid);
         matvec_rows(a.W_hh, a.b_hh, h_s, gh_s, H3, H, a.vecW, tid);
         __syncthreads();
-        // B: e_p = v_a . tanh(Waf_p + uah) + b_va
+        // B: e_p = v_a . tanh(Waf_p + uah) + b_va   (one wave per position, shuffle reduction)
         for (int p = wave; p < P; p += NT / 64) {
             float s = 0.f;
-            for (int k = lane; k < H; k += 64) s += va_s[k] * caphn_tanh(Waf_s[p * H + k] + uah_s[k]);
+            for (int k = lane; k < H; k += 64) s += va_s[k] * caphn_tanh(Waf_b[p * H + k] + uah_s[k]);
             s = wave_sum(s);
             if (lane == 0) e_s[p] = s + bva;
         }
         __syncthreads();
         // C: softmax over P (one wave)
         if (wave == 0) {
-            float m = -INFINITY;
-            for (int p = lane; p < P; p += 64) m = fmaxf(m, e_s[p]);
-            m = wave_max(m);
+            float mx = -INFINITY;
+            for (int p = lane; p < P; p += 64) mx = fmaxf(mx, e_s[p]);
+            mx = wave_max(mx);
             float sum = 0.f;
-            for (int p = lane; p < P; p += 64) { float ex = caphn_exp(e_s[p] - m); e_s[p] = ex; sum += ex; }
+            for (int p = lane; p < P; p += 64) { float ex = caphn_exp(e_s[p] - mx); e_s[p] = ex; sum += ex; }
             sum = wave_sum(sum);
             const float inv = 1.0f / sum;
             for (int p = lane; p < P; p += 64) { float al = e_s[p] * inv; e_s[p] = al; a.alphas[bt * P + p] = al; }
         }
         __syncthreads();
-        // D: gi = Xg + sum_p alpha_p G_p ; gates ; h'
+        // D1: partial gi_ctx = sum_{p = g mod ng} alpha_p G_p over thread groups
+        if (m.g >= 0) {
+            for (int k = m.k; k < H; k += (m.ng == 1 ? NT : H)) {
+                float gr = 0.f, gz = 0.f, gn = 0.f;
+                for (int p = m.g; p < P; p += m.ng) {
+                    const float al = e_s[p];
+                    const float* gp = G_s + p * H3 + k;
+                    gr += al * gp[0]; gz += al * gp[H]; gn += al * gp[2 * H];
+                }
+                float* ps = part_s + m.g * H3;
+                ps[k] = gr; ps[H + k] = gz; ps[2 * H + k] = gn;
+            }
+        }
+        __syncthreads();
+        // D2: gates and h'
         for (int k = tid; k < H; k += NT) {
             float gr = 0.f, gz = 0.f, gn = 0.f;
-            for (int p = 0; p < P; ++p) {
-                const float al = e_s[p];
-                const float* gp = G_s + p * H3 + k;
-                gr += al * gp[0]; gz += al * gp[H]; gn += al * gp[2 * H];
+            for (int g = 0; g < m.ng; ++g) {
+                const float* ps = part_s + g * H3;
+                gr += ps[k]; gz += ps[H + k]; gn += ps[2 * H + k];
             }
             const float* xg = a.Xg + bt * H3;
             const float hp = h_s[k];
@@ -118,17 +144,14 @@ __global__ __launch_bounds__(NT) void gru_attn_fwd_kernel(GruFwdArgs a) {
             a.gates[bt * H3 + k] = r; a.gates[bt * H3 + H + k] = z; a.gates[bt * H3 + 2 * H + k] = n;
             a.hn[bt * H + k] = hnv;
             a.uah[bt * H + k] = uah_s[k];
-            gh_s[k] = hnew;                    // stash: h_s is still being read by other threads' hp? no -- only [k]
+            h_s[k] = hnew;                  // only this thread reads h_s[k] in D2
         }
-        __syncthreads();
-        for (int k = tid; k < H; k += NT) h_s[k] = gh_s[k];
         __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// BPTT.  Walks t = T-1 .. 0 with dh carried in LDS.  G stays LDS-resident (d alpha_p = G_p . dgi);
-// Waf is re-read from L2 (39 KB/step) because the gradient vectors take the remaining LDS.
+// BPTT.  Walks t = T-1 .. 0 with dh carried in LDS.  G stays LDS-resident (d alpha_p = G_p . dgi).
 // Emits per-step dgi, dgh, d(U_a h), d e -- the weight gradients are batched MFMA GEMMs afterwards.
 template <int CH>   // CH = 4: dwordx4 column chunks, CH = 1: scalar columns (H % 4 != 0)
 __device__ __forceinline__ void matvec_t_accum(const float* __restrict__ W, const float* d_s, int rows, int H,
@@ -159,7 +182,7 @@ __global__ __launch_bounds__(NT) void gru_attn_bwd_kernel(GruBwdArgs a) {
     float* dgi_s = dgh_s + H3;
     float* dal_s = dgi_s + H3;
     float* al_s = dal_s + Ppad;
-    float* part_s = al_s + Ppad;     // [nslices][H]
+    float* part_s = al_s + Ppad;     // [max(nslices, ng)][H]
 
     copy_to_lds(G_s, a.G + (size_t)b * P * H3, P * H3, a.vecS, tid);
     for (int k = tid; k < H; k += NT) { dh_s[k] = 0.f; va_s[k] = a.v_a[k]; }
@@ -169,6 +192,7 @@ __global__ __launch_bounds__(NT) void gru_attn_bwd_kernel(GruBwdArgs a) {
     const int nch = (H + CH - 1) / CH;
     const int nch_eff = min(nch, NT);
     const int nslices = NT / nch_eff;
+    const KG m = kg_map(tid, H);
     __syncthreads();
 
     for (int t = T - 1; t >= 0; --t) {
@@ -212,14 +236,22 @@ __global__ __launch_bounds__(NT) void gru_attn_bwd_kernel(GruBwdArgs a) {
             }
         }
         __syncthreads();
-        // d(U_a h)[k] = v_k sum_p de_p (1 - tanh^2(Waf_pk + uah_k))
-        for (int k = tid; k < H; k += NT) {
-            const float u = uah_s[k];
-            float s = 0.f;
-            for (int p = 0; p < P; ++p) {
-                const float tv = caphn_tanh(Waf_b[p * H + k] + u);
-                s += dal_s[p] * (1.0f - tv * tv);
+        // d(U_a h)[k] = v_k sum_p de_p (1 - tanh^2(Waf_pk + uah_k)); p split over thread groups
+        if (m.g >= 0) {
+            for (int k = m.k; k < H; k += (m.ng == 1 ? NT : H)) {
+                const float u = uah_s[k];
+                float s = 0.f;
+                for (int p = m.g; p < P; p += m.ng) {
+                    const float tv = caphn_tanh(Waf_b[p * H + k] + u);
+                    s += dal_s[p] * (1.0f - tv * tv);
+                }
+                part_s[m.g * H + k] = s;
             }
+        }
+        __syncthreads();
+        for (int k = tid; k < H; k += NT) {
+            float s = 0.f;
+            for (int g = 0; g < m.ng; ++g) s += part_s[g * H + k];
             const float du = s * va_s[k];
             duah_s[k] = du;
             a.duah[bt * H + k] = du;
@@ -332,17 +364,22 @@ int ensure_lds_attr() {
 
 }  // namespace
 
+static int kg_groups(int H) { return H >= NT ? 1 : NT / H; }
 size_t caphn_gru_fwd_lds_bytes(int P, int H) {
     const size_t Ppad = (P + 63) & ~63;
-    return sizeof(float) * ((size_t)4 * P * H + 6 * (size_t)H + Ppad);
+    return sizeof(float) * ((size_t)3 * P * H + 6 * (size_t)H + Ppad + (size_t)kg_groups(H) * 3 * H);
 }
 size_t caphn_gru_bwd_lds_bytes(int P, int H) {
     const size_t Ppad = (P + 63) & ~63;
     const int CH = (H % 4 == 0) ? 4 : 1;
     const int nch = (H + CH - 1) / CH;
     const int nch_eff = nch < NT ? nch : NT;
-    const int nslices = NT / nch_eff;
-    return sizeof(float) * ((size_t)3 * P * H + 10 * (size_t)H + 2 * Ppad + (size_t)nslices * H);
+    int nsl = NT / nch_eff;
+    if (kg_groups(H) > nsl) nsl = kg_groups(H);
+    // the scalar-column map (CH = 1) may be chosen at run time for unaligned weights: it needs NT / min(H, NT) slices
+    const int nsl1 = NT / (H < NT ? H : NT);
+    if (nsl1 > nsl) nsl = nsl1;
+    return sizeof(float) * ((size_t)3 * P * H + 10 * (size_t)H + 2 * Ppad + (size_t)nsl * H);
 }
 
 int caphn_launch_gru_fwd(const GruFwdArgs& a, hipStream_t s) {
