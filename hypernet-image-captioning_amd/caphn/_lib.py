@@ -49,7 +49,7 @@ class DecoderGrads(C.Structure):
 
 class AdamHParams(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("step", C.c_int)]
+                ("step", C.c_int), ("dev_scalars", c_fp)]
 
 
 # name -> (restype, argtypes); must list every symbol include/caphn.h declares

@@ -56,6 +56,11 @@ class FusedTrainer:
         self._hyper_ws = None
         self._tok = torch.zeros(1, dtype=torch.int64, device=dev)
         self._nh = nh
+        # step-dependent Adam scalars live in device memory so a captured hipGraph replays for any step
+        self._adam_dev = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._adam_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        self._graphs: Dict[tuple, object] = {}
+        self._seen = set()
 
     # ------------------------------------------------------------------ parameter arenas
     def _build_arena(self):
@@ -236,11 +241,16 @@ class FusedTrainer:
         self._pending = None
         return allp[:, :self.theta_size], allp[:, self.theta_size:self.theta_size + L_acts]
 
-    def optimizer_step(self):
-        """clip_grad_norm_(max_norm) over ALL gradients + Adam, on device, no host sync."""
+    def _begin_step(self):
+        self.step_count += 1
+        a, b = ops.adam_scalars(self.lr, self.betas, self.step_count)
+        self._adam_host[0] = a
+        self._adam_host[1] = b
+        self._adam_dev.copy_(self._adam_host, non_blocking=True)
+
+    def _optimizer_impl(self):
         R = dp.world(self.group)
         gfac, acts_all = self._exchange()
-        self.step_count += 1
         part = ops.sumsq_partials(self.flat_g, self._part)
         self._acc.zero_()
         o = 0
@@ -252,16 +262,47 @@ class FusedTrainer:
             segs.append((gi, ai))
             o += w
         ops.clip_coef(part, self._acc, self.max_norm, 1.0 / R, out=self._coef)
-        ops.adam_dense(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self._coef, self.lr, self.step_count,
-                       self.betas, self.eps)
+        step = max(self.step_count, 1)
+        ops.adam_dense(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self._coef, self.lr, step,
+                       self.betas, self.eps, dev_scalars=self._adam_dev)
         for i, (gi, ai) in enumerate(segs):
-            ops.adam_rank(self.W2[i].data, self.W2_m[i], self.W2_v[i], gi, ai, self._coef, self.lr, self.step_count,
-                          self.betas, self.eps)
+            ops.adam_rank(self.W2[i].data, self.W2_m[i], self.W2_v[i], gi, ai, self._coef, self.lr, step,
+                          self.betas, self.eps, dev_scalars=self._adam_dev)
         return self._coef
+
+    def optimizer_step(self):
+        """clip_grad_norm_(max_norm) over ALL gradients + Adam, on device, no host sync."""
+        self._begin_step()
+        return self._optimizer_impl()
 
     def step(self, features, captions, x_style=None, style_token=None):
         loss = self.forward_backward(features, captions, x_style, style_token)
         self.optimizer_step()
+        return loss
+
+    def step_graphed(self, features, captions, x_style=None, style_token=None):
+        """Same step, replayed from a hipGraph (single GPU): ~90 kernel launches become one graph launch.
+        Graphs are cached per (input buffers, shapes, style): the caller must keep feeding the same
+        device buffers (copy new minibatches into them).  The first call with a key runs eagerly
+        (creates the lazily allocated buffers), the second captures, later ones replay."""
+        if dp.world(self.group) != 1:
+            return self.step(features, captions, x_style, style_token)
+        key = (features.data_ptr(), captions.data_ptr(), tuple(features.shape), tuple(captions.shape), style_token,
+               None if x_style is None else x_style.data_ptr())
+        if key not in self._seen:
+            self._seen.add(key)
+            return self.step(features, captions, x_style, style_token)
+        self._begin_step()
+        g = self._graphs.get(key)
+        if g is None:
+            self._sync_params()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = self.forward_backward(features, captions, x_style, style_token)
+                self._optimizer_impl()
+            self._graphs[key] = (g, loss)
+        g, loss = self._graphs[key]
+        g.replay()
         return loss
 
     # ------------------------------------------------------------------ introspection for tests

@@ -321,23 +321,29 @@ def clip_coef(partial: torch.Tensor, extra: Optional[torch.Tensor], max_norm: fl
     return out
 
 
-def _hp(lr, betas, eps, step):
-    return L.AdamHParams(float(lr), float(betas[0]), float(betas[1]), float(eps), int(step))
+def _hp(lr, betas, eps, step, dev_scalars=None):
+    return L.AdamHParams(float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
+                         dev_scalars.data_ptr() if dev_scalars is not None else None)
 
 
-def adam_dense(p, m, v, g, coef, lr, step, betas=(0.9, 0.999), eps=1e-8) -> None:
+def adam_scalars(lr, betas, step):
+    """Host values of the two step-dependent Adam scalars {lr / (1 - b1^t), sqrt(1 - b2^t)}."""
+    return float(lr / (1.0 - betas[0] ** step)), float((1.0 - betas[1] ** step) ** 0.5)
+
+
+def adam_dense(p, m, v, g, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_scalars=None) -> None:
     lib = L.load()
-    hp = _hp(lr, betas, eps, step)
+    hp = _hp(lr, betas, eps, step, dev_scalars)
     n = p.numel()
     assert m.numel() == n and v.numel() == n and g.numel() == n
     L.check(lib.caphn_adam_dense_f32(n, L.ptr(p), L.ptr(m), L.ptr(v), L.ptr(g), L.ptr(coef), C.byref(hp),
                                      L.stream_ptr()), "caphn_adam_dense_f32")
 
 
-def adam_rank(W, m, v, gfac, afac, coef, lr, step, betas=(0.9, 0.999), eps=1e-8) -> None:
+def adam_rank(W, m, v, gfac, afac, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_scalars=None) -> None:
     """Adam on W [rows,k] with gradient coef * sum_r gfac[r,:,None] * afac[r,None,:] (never materialised)."""
     lib = L.load()
-    hp = _hp(lr, betas, eps, step)
+    hp = _hp(lr, betas, eps, step, dev_scalars)
     rows, k = W.shape
     R = gfac.shape[0]
     assert gfac.shape[1] == rows and afac.shape[1] == k and afac.shape[0] == R

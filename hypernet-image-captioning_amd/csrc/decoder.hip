@@ -59,14 +59,15 @@ inline bool dims_ok(const caphn_decoder_dims* d) {
     return d && d->B > 0 && d->T > 0 && d->P > 0 && d->D > 0 && d->F > 0 && d->E > 0 && d->H > 0 && d->V > 0;
 }
 
-// split-K heuristic for the weight-gradient GEMMs (small MxN, long K)
+// split-K heuristic for the weight-gradient GEMMs (small MxN, long K): aim at >= 4 workgroups per CU
+// with at least 8 K-slabs each (the kernel picks 64x64 tiles below 1024 128x128 tiles)
 inline int pick_splitk(int M, int N, int K) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (t128 >= 256) return 1;
+    if (t128 >= 1024) return 1;
     const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
     const int nslab = (K + 31) / 32;
-    long s = (768 + t64 - 1) / t64;
-    if (s > nslab / 4) s = nslab / 4;
+    long s = (1024 + t64 - 1) / t64;
+    if (s > nslab / 8) s = nslab / 8;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
     return (int)s;

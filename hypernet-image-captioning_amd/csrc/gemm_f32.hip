@@ -24,12 +24,15 @@ struct GemmArgs {
     int vecA, vecB;
 };
 
-constexpr int BK = 32;
-constexpr int KPAD = BK + 4;      // K-contiguous LDS rows: 144 B pitch -> conflict-free ds_read_b128
-
-template <int BMN, bool KC>
+// BK = K-slab depth: 32, or 40 when K is a multiple of 40 but not of 32 (K = 200: 5 exact slabs
+// instead of 6.25).  K-contiguous LDS rows are padded to BK+4 floats (144 B / 176 B pitch: odd
+// multiples of 16 B, so the 16 lanes of a ds_read_b128 group hit 16 different 16-byte slots).
+template <int BMN, bool KC, int BK>
 struct Tile {
-    static constexpr int NV = BMN / 32;   // float4 per thread per slab
+    static constexpr int KPAD = BK + 4;
+    static constexpr int K4 = BK / 4;
+    static constexpr int TOTAL = BMN * K4;              // float4 per slab
+    static constexpr int NV = (TOTAL + 255) / 256;      // float4 per thread per slab
     static constexpr int LDM = BMN + 4;
     static constexpr int FLOATS = KC ? BMN * KPAD : BK * LDM;
 
@@ -39,9 +42,11 @@ struct Tile {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int idx = tid + 256 * i;
+            if (TOTAL % 256 != 0 && idx >= TOTAL) { r[i] = v; continue; }
             if (KC) {               // memory [rows, K]
-                int row = r0 + (tid >> 3) + 32 * i;
-                int k = k0 + (tid & 7) * 4;
+                int row = r0 + idx / K4;
+                int k = k0 + (idx % K4) * 4;
                 if (row < rows) {
                     const float* p = G + (size_t)row * ld + k;
                     if (vec && k + 3 < K) v = *reinterpret_cast<const f32x4*>(p);
@@ -51,7 +56,6 @@ struct Tile {
                     }
                 }
             } else {                // memory [K, rows]
-                int idx = tid + 256 * i;
                 int m = r0 + (idx % (BMN / 4)) * 4;
                 int k = k0 + idx / (BMN / 4);
                 if (k < K) {
@@ -69,13 +73,10 @@ struct Tile {
     __device__ static __forceinline__ void store(const f32x4 (&r)[NV], float* __restrict__ S, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            if (KC) {
-                int row = (tid >> 3) + 32 * i;
-                *reinterpret_cast<f32x4*>(S + row * KPAD + (tid & 7) * 4) = r[i];
-            } else {
-                int idx = tid + 256 * i;
-                *reinterpret_cast<f32x4*>(S + (idx / (BMN / 4)) * LDM + (idx % (BMN / 4)) * 4) = r[i];
-            }
+            const int idx = tid + 256 * i;
+            if (TOTAL % 256 != 0 && idx >= TOTAL) continue;
+            if (KC) *reinterpret_cast<f32x4*>(S + (idx / K4) * KPAD + (idx % K4) * 4) = r[i];
+            else *reinterpret_cast<f32x4*>(S + (idx / (BMN / 4)) * LDM + (idx % (BMN / 4)) * 4) = r[i];
         }
     }
     // fragment of 4 k-steps for the 32 rows starting at `row` (lane i = lane&31, kh = lane>>5)
@@ -88,10 +89,10 @@ struct Tile {
     }
 };
 
-template <int BM, int BN, bool TA, bool TB>
+template <int BM, int BN, bool TA, bool TB, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    using TileA = Tile<BM, !TA>;     // A [M,K] is K-contiguous unless transposed
-    using TileB = Tile<BN, TB>;      // B stored [N,K] (tb) is K-contiguous
+    using TileA = Tile<BM, !TA, BK>;     // A [M,K] is K-contiguous unless transposed
+    using TileB = Tile<BN, TB, BK>;      // B stored [N,K] (tb) is K-contiguous
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     __shared__ __attribute__((aligned(16))) float lds[TileA::FLOATS + TileB::FLOATS];
     float* As = lds;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, (slab + 1) * BK, g.vecB, tid);
         }
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
+        for (int kq = 0; kq < BK / 8; ++kq) {
             f32x4 fa[TM], fb[TN];
 #pragma unroll
             for (int a = 0; a < TM; ++a) fa[a] = TileA::frag(As, wm * WM + a * 32 + li, kq, kh);
@@ -179,14 +180,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 int launch_cfg(const GemmArgs& g, int ta, int tb, hipStream_t s) {
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk > 1 ? g.splitk : 1);
     dim3 block(256);
-    if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, s, g);
-    else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, s, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, s, g);
+    if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, BK>), grid, block, 0, s, g);
+    else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, BK>), grid, block, 0, s, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false, BK>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true, BK>), grid, block, 0, s, g);
     return caphn_launch_status();
 }
 
@@ -204,6 +205,7 @@ extern "C" int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.mask = mask; g.ldmask = ldmask; g.flags = flags;
+    const int BK = (K % 40 == 0 && K % 32 != 0) ? 40 : 32;
     const int nslab = (K + BK - 1) / BK;
     if (splitk > nslab) splitk = nslab;
     g.splitk = splitk > 1 ? splitk : 1;
@@ -211,8 +213,9 @@ extern "C" int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
     g.vecA = caphn_aligned16(A) && (lda % 4 == 0);
     g.vecB = caphn_aligned16(B) && (ldb % 4 == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // 128x128 tiles once they alone fill the 256 CUs; otherwise 64x64 for more workgroups
+    // fp32 MFMA is slow enough (64 cycles per 32x32x2) that LDS/L2 reuse is not the limit: what matters is
+    // balance over the 256 CUs.  128x128 tiles only when they alone give >= 4 workgroups per CU.
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * g.splitk;
-    if (tiles128 >= 256) return launch_cfg<128, 128>(g, ta, tb, s);
-    return launch_cfg<64, 64>(g, ta, tb, s);
+    if (tiles128 >= 1024) return BK == 40 ? launch_cfg<128, 128, 40>(g, ta, tb, s) : launch_cfg<128, 128, 32>(g, ta, tb, s);
+    return BK == 40 ? launch_cfg<64, 64, 40>(g, ta, tb, s) : launch_cfg<64, 64, 32>(g, ta, tb, s);
 }

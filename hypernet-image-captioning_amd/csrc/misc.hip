@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(int nparts, const double
 }
 
 // ------------------------------------------------------------------ Adam (torch.optim.Adam, single-tensor form)
-struct AdamK { float lr_bc1, b1, b2, eps, sqrt_bc2; };
+struct AdamK { float lr_bc1, b1, b2, eps, sqrt_bc2; const float* dev; };
 __device__ __forceinline__ float adam_elem(float p, float g, float& m, float& v, const AdamK& k) {
     m = m + (g - m) * (1.0f - k.b1);                       // exp_avg.lerp_(grad, 1 - beta1)
     v = v * k.b2 + (1.0f - k.b2) * g * g;                  // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
@@ -192,6 +192,7 @@ __device__ __forceinline__ float adam_elem(float p, float g, float& m, float& v,
 __global__ __launch_bounds__(256) void adam_dense_kernel(size_t n, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                          const float* __restrict__ g, const float* __restrict__ coef, AdamK k, int vec) {
     const float c = coef[0];
+    if (k.dev) { k.lr_bc1 = k.dev[0]; k.sqrt_bc2 = k.dev[1]; }
     const size_t stride = (size_t)gridDim.x * 256;
     if (vec) {
         f32x4* p4 = reinterpret_cast<f32x4*>(p); f32x4* m4 = reinterpret_cast<f32x4*>(m); f32x4* v4 = reinterpret_cast<f32x4*>(v);
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(256) void adam_rank_kernel(int R, int rows, int k, 
                                                         const float* gfac, size_t ldg, const float* afac, size_t lda,
                                                         const float* coef, AdamK K, int vec) {
     const float c = coef[0];
+    if (K.dev) { K.lr_bc1 = K.dev[0]; K.sqrt_bc2 = K.dev[1]; }
     if (vec && k <= 2048) {
         const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4, lane = threadIdx.x & 63;
         if (k <= 256) adam_rank_rows<1>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
@@ -272,6 +274,7 @@ inline AdamK make_adam(const caphn_adam_hparams* hp) {
     k.lr_bc1 = (float)((double)hp->lr / bc1);
     k.b1 = hp->beta1; k.b2 = hp->beta2; k.eps = hp->eps;
     k.sqrt_bc2 = (float)sqrt(bc2);
+    k.dev = hp->dev_scalars;
     return k;
 }
 

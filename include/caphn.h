@@ -192,6 +192,9 @@ int caphn_clip_coef(int nparts, const double* partial, const double* extra, doub
 typedef struct caphn_adam_hparams {
     float lr, beta1, beta2, eps;
     int step;                          /* 1-based, bias corrections computed from it */
+    const float* dev_scalars;          /* optional DEVICE pointer to {lr / (1 - beta1^step), sqrt(1 - beta2^step)}:
+                                          when non-NULL it overrides lr/step, so a captured hipGraph can be
+                                          replayed for every step (the caller refreshes the two floats) */
 } caphn_adam_hparams;
 /* p,m,v,g flat [n]; g is multiplied by coef[0] (device) first. */
 int caphn_adam_dense_f32(size_t n, float* p, float* m, float* v, const float* g, const float* coef,

@@ -44,6 +44,17 @@ def test_gemm_layouts(ops, ta, tb, M, N, K):
     assert maxdiff(out.cpu(), ref + bias.double()) < tol
 
 
+@pytest.mark.parametrize("K", [96, 200])
+def test_gemm_large_tile_config(ops, K):
+    """>= 1024 128x128 tiles selects the 128x128 kernel (BK = 32 for K = 96, BK = 40 for K = 200)."""
+    g = torch.Generator().manual_seed(K)
+    A, B = torch.randn(4096, K, generator=g), torch.randn(4000, K, generator=g)
+    bias = torch.randn(4000, generator=g)
+    out = ops.gemm(A.to(DEV), B.to(DEV), False, True, bias=bias.to(DEV))
+    ref = (A.to(DEV).double() @ B.to(DEV).double().t() + bias.to(DEV).double())
+    assert float((out.double() - ref).abs().max()) < 2e-6 * math.sqrt(K) * 4
+
+
 def test_gemm_strided_views(ops):
     """leading dimensions larger than the logical width (W_ih[:, E:] style views)."""
     g = torch.Generator().manual_seed(5)

@@ -168,3 +168,25 @@ def test_engine_tracks_swapped_submodule():
     p2 = dict(p); p2["captioner.embed.weight"] = new
     ref, *_ = O.forward_backward(dims, p2, x, g["features"], g["captions"])
     assert abs(l1 - float(ref)) < 2e-6 and abs(l0 - float(g["loss"])) < 2e-6
+
+
+def test_graph_replayed_step_matches_eager():
+    """step_graphed (hipGraph replay, device-side Adam scalars) follows the same trajectory as
+    eagerly launched steps."""
+    from caphn.engine import FusedTrainer
+    name = "gru_tiny_cc"
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, _ = style_args(g)
+    feats, caps, xs = g["features"].to(DEV), g["captions"].to(DEV), x.to(DEV)
+    ta = FusedTrainer(build_net(dims, p, cc=True), lr=1e-3)
+    tb = FusedTrainer(build_net(dims, p, cc=True), lr=1e-3)
+    la = [float(ta.step(feats, caps, x_style=xs)[0]) for _ in range(5)]
+    lb = []
+    for _ in range(5):
+        lb.append(float(tb.step_graphed(feats, caps, x_style=xs)[0]))
+    assert len(tb._graphs) == 1 and tb.step_count == 5
+    assert la[0] == lb[0]
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
+    assert la[-1] < la[0]
+    assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 1e-4
