@@ -32,11 +32,12 @@ class HyperGrads(C.Structure):
 
 
 class DecoderDims(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("B", "T", "P", "D", "F", "E", "H", "V")]
+    _fields_ = [(n, C.c_int) for n in ("B", "T", "P", "D", "F", "E", "H", "V", "cell", "raw_features")]
 
 
 _DEC_FIELDS = ("fc0_w", "fc0_b", "fc2_w", "fc2_b", "embed_w", "out_w", "out_b", "Wa_w", "Wa_b",
-               "Ua_w", "Ua_b", "va_w", "va_b", "inith_w", "inith_b", "w_ih", "w_hh", "b_ih", "b_hh")
+               "Ua_w", "Ua_b", "va_w", "va_b", "inith_w", "inith_b", "w_ih", "w_hh", "b_ih", "b_hh",
+               "initc_w", "initc_b")
 
 
 class DecoderParams(C.Structure):

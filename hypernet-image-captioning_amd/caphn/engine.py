@@ -22,9 +22,6 @@ import torch
 from . import dp, ops
 from ._lib import CaphnError
 
-_DEC_NAMES = [n for n in ops.DEC_FIELD_TO_NAME.values() if not n.startswith("gru.")]
-
-
 def _up4(n: int) -> int:
     return (n + 3) & ~3
 
@@ -43,8 +40,11 @@ class FusedTrainer:
         if dev.type != "cuda":
             raise CaphnError("FusedTrainer needs the model on a CUDA(HIP) device")
         self.dev = dev
-        if self.cap.layers or self.cap.drop.p > 0:
+        if getattr(self.cap, "layers", None) or self.cap.drop.p > 0:
             raise NotImplementedError("fused step supports num_layers=1, dropout p=0")
+        d0 = self.cap.dec_dims(1, 1, 1)
+        self._cell_names = d0.cell_names()
+        self._dec_names = [n for n in d0.names() if n not in self._cell_names]
         self._build_arena()
         self._bufs: Dict[Tuple[int, int, int], dict] = {}
         nh = len(self.shape.heads)
@@ -66,7 +66,7 @@ class FusedTrainer:
     def _build_arena(self):
         net, cap = self.net, self.cap
         hyper = net.hyper_named_tensors()
-        dec = {n: t for n, t in cap._named_tensors().items() if not n.startswith("gru.")}
+        dec = {n: t for n, t in cap._named_tensors().items() if n in self._dec_names}
         nh = len(self.shape.heads)
         order: List[Tuple[str, torch.nn.Parameter]] = []
         for i in range(nh):                                   # theta-ordered second-layer biases
@@ -87,7 +87,7 @@ class FusedTrainer:
             o += p.numel()
         self._hyper_small_end = _up4(o)
         o = self._hyper_small_end
-        for n in _DEC_NAMES:
+        for n in self._dec_names:
             p = dec[n]
             offs["captioner." + n] = (o, p.numel(), tuple(p.shape))
             o = _up4(o + p.numel())
@@ -101,7 +101,7 @@ class FusedTrainer:
         self._owned: Dict[str, torch.nn.Parameter] = {}
         for n, p in order:
             self._adopt(n, p)
-        for n in _DEC_NAMES:
+        for n in self._dec_names:
             self._adopt("captioner." + n, dec[n])
         # rank-1 group
         self.W2 = [hyper[f"hn_heads.{i}.2.weight"] for i in range(nh)]
@@ -125,7 +125,7 @@ class FusedTrainer:
         """Callers may swap sub-modules (captioner.embed = ...from_pretrained, hypernet_attention.py:108;
         sub-module transplant :424-428).  Re-adopt any parameter whose storage left the arena."""
         hyper = self.net.hyper_named_tensors()
-        dec = {"captioner." + n: t for n, t in self.cap._named_tensors().items() if not n.startswith("gru.")}
+        dec = {"captioner." + n: t for n, t in self.cap._named_tensors().items() if n in self._dec_names}
         for name in self.offs:
             cur = hyper.get(name, dec.get(name))
             o, n, shape = self.offs[name]
@@ -144,8 +144,7 @@ class FusedTrainer:
         key = (B, T, P)
         b = self._bufs.get(key)
         if b is None:
-            c = self.cap
-            dims = ops.DecDims(B, T, P, c.num_features, c.feature_out, c.embedding_dim, c.hidden_dim, c.vocab_size)
+            dims = self.cap.dec_dims(B, T, P)
             b = {"dims": dims, "ws": ops.decoder_workspace(dims, self.dev),
                  "logits": torch.empty(B, T, dims.V, dtype=torch.float32, device=self.dev),
                  "alphas": torch.empty(B, T, P, dtype=torch.float32, device=self.dev),
@@ -156,18 +155,16 @@ class FusedTrainer:
     def _dec_tensors(self, theta_flat, grads: bool):
         """decoder parameter (or gradient) dict; the GRU entries are slices of theta / dtheta."""
         flat = self.flat_g if grads else self.flat_p
-        d = {n: self._view(flat, "captioner." + n) for n in _DEC_NAMES}
-        c = self.cap
-        H3, EF, H = 3 * c.hidden_dim, c.embedding_dim + c.feature_out, c.hidden_dim
+        d = {n: self._view(flat, "captioner." + n) for n in self._dec_names}
+        shapes = self.cap.dec_dims(1, 1, 1).param_shapes()
         o = 0
-        for n, shape in (("gru.weight_ih", (H3, EF)), ("gru.weight_hh", (H3, H)), ("gru.bias_ih", (H3,)),
-                         ("gru.bias_hh", (H3,))):
+        for n in self._cell_names:
             k = 1
-            for s in shape:
+            for s in shapes[n]:
                 k *= s
-            d[n] = theta_flat[o:o + k].view(shape)
+            d[n] = theta_flat[o:o + k].view(shapes[n])
             o += k
-        assert o == self.theta_size, "hypernet heads do not match the GRUCell parameter sizes"
+        assert o == self.theta_size, "hypernet heads do not match the cell's parameter sizes"
         return d
 
     # ------------------------------------------------------------------ the step

@@ -9,15 +9,12 @@ import torch
 from . import ops
 from ._lib import CaphnError
 
-_DEC_ORDER: List[str] = list(ops.DEC_FIELD_TO_NAME.values())
-
-
 class _DecoderFn(torch.autograd.Function):
-    """AttentionGru.forward(features, captions, sample_prob=0.0)   models/decoderlstm.py:49-120"""
+    """AttentionGru.forward / AttentionLstm.forward with sample_prob=0.0   models/decoderlstm.py:49-120, :224-261"""
 
     @staticmethod
     def forward(ctx, dims, features, captions, *tensors):
-        params = {n: t.detach().contiguous() for n, t in zip(_DEC_ORDER, tensors)}
+        params = {n: t.detach().contiguous() for n, t in zip(dims.names(), tensors)}
         features = features.detach().contiguous()
         captions = captions.contiguous()
         ws = ops.decoder_workspace(dims, features.device)
@@ -35,7 +32,7 @@ class _DecoderFn(torch.autograd.Function):
         ops.decoder_backward(dims, ctx.params, ctx.features, ctx.captions, dlogits.contiguous(), grads, ctx.ws,
                              dalphas.contiguous() if dalphas is not None else None)
         ctx.ws = None
-        return (None, None, None) + tuple(grads[n] for n in _DEC_ORDER)
+        return (None, None, None) + tuple(grads[n] for n in dims.names())
 
 
 def attention_gru_forward(dims: ops.DecDims, features: torch.Tensor, captions: torch.Tensor,
@@ -43,7 +40,7 @@ def attention_gru_forward(dims: ops.DecDims, features: torch.Tensor, captions: t
     if not features.is_cuda:
         raise CaphnError("AttentionGru.forward runs on libcaphn's HIP kernels only: move the module and its "
                          "inputs to a CUDA(HIP) device (there is no CPU fallback)")
-    return _DecoderFn.apply(dims, features.float(), captions.long(), *[named[n] for n in _DEC_ORDER])
+    return _DecoderFn.apply(dims, features.float(), captions.long(), *[named[n] for n in dims.names()])
 
 
 class _HyperFn(torch.autograd.Function):

@@ -160,18 +160,6 @@ def hyper_backward(shape: HyperShape, p: Dict[str, torch.Tensor], dtheta: torch.
 
 
 # ------------------------------------------------------------------ decoder
-DEC_FIELD_TO_NAME = {
-    "fc0_w": "feature_fc.0.weight", "fc0_b": "feature_fc.0.bias",
-    "fc2_w": "feature_fc.2.weight", "fc2_b": "feature_fc.2.bias",
-    "embed_w": "embed.weight", "out_w": "fc.weight", "out_b": "fc.bias",
-    "Wa_w": "attention.W_a.weight", "Wa_b": "attention.W_a.bias",
-    "Ua_w": "attention.U_a.weight", "Ua_b": "attention.U_a.bias",
-    "va_w": "attention.v_a.weight", "va_b": "attention.v_a.bias",
-    "inith_w": "init_h.weight", "inith_b": "init_h.bias",
-    "w_ih": "gru.weight_ih", "w_hh": "gru.weight_hh", "b_ih": "gru.bias_ih", "b_hh": "gru.bias_hh",
-}
-
-
 @dataclass(frozen=True)
 class DecDims:
     B: int
@@ -182,25 +170,60 @@ class DecDims:
     E: int
     H: int
     V: int
+    cell: str = "gru"        # "gru" (AttentionGru) or "lstm" (AttentionLstm)
+    raw: bool = False        # True: no feature_fc, attention over the raw D-channel features (F == D)
+
+    @property
+    def NG(self) -> int:
+        return 4 if self.cell == "lstm" else 3
 
     def c(self) -> L.DecoderDims:
-        return L.DecoderDims(self.B, self.T, self.P, self.D, self.F, self.E, self.H, self.V)
+        return L.DecoderDims(self.B, self.T, self.P, self.D, self.F, self.E, self.H, self.V,
+                             1 if self.cell == "lstm" else 0, int(self.raw))
+
+    def fields(self):
+        """Ordered (C struct field, parameter name) pairs this configuration uses."""
+        f = []
+        if not self.raw:
+            f += [("fc0_w", "feature_fc.0.weight"), ("fc0_b", "feature_fc.0.bias"),
+                  ("fc2_w", "feature_fc.2.weight"), ("fc2_b", "feature_fc.2.bias")]
+        f += [("embed_w", "embed.weight"), ("out_w", "fc.weight"), ("out_b", "fc.bias"),
+              ("Wa_w", "attention.W_a.weight"), ("Wa_b", "attention.W_a.bias"),
+              ("Ua_w", "attention.U_a.weight"), ("Ua_b", "attention.U_a.bias"),
+              ("va_w", "attention.v_a.weight"), ("va_b", "attention.v_a.bias"),
+              ("inith_w", "init_h.weight"), ("inith_b", "init_h.bias")]
+        if self.cell == "lstm":
+            f += [("initc_w", "init_c.weight"), ("initc_b", "init_c.bias")]
+        c = self.cell
+        f += [("w_ih", f"{c}.weight_ih"), ("w_hh", f"{c}.weight_hh"), ("b_ih", f"{c}.bias_ih"), ("b_hh", f"{c}.bias_hh")]
+        return f
+
+    def names(self) -> List[str]:
+        return [n for _, n in self.fields()]
+
+    def cell_names(self) -> List[str]:
+        return [f"{self.cell}.{n}" for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
 
     def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
-        D, F, E, H, V = self.D, self.F, self.E, self.H, self.V
-        return {"feature_fc.0.weight": (F, D), "feature_fc.0.bias": (F,), "feature_fc.2.weight": (F, F),
+        D, F, E, H, V, G = self.D, self.F, self.E, self.H, self.V, self.NG * self.H
+        c = self.cell
+        full = {"feature_fc.0.weight": (F, D), "feature_fc.0.bias": (F,), "feature_fc.2.weight": (F, F),
                 "feature_fc.2.bias": (F,), "embed.weight": (V, E), "fc.weight": (V, H), "fc.bias": (V,),
                 "attention.W_a.weight": (H, F), "attention.W_a.bias": (H,), "attention.U_a.weight": (H, H),
                 "attention.U_a.bias": (H,), "attention.v_a.weight": (1, H), "attention.v_a.bias": (1,),
-                "init_h.weight": (H, F), "init_h.bias": (H,),
-                "gru.weight_ih": (3 * H, E + F), "gru.weight_hh": (3 * H, H), "gru.bias_ih": (3 * H,),
-                "gru.bias_hh": (3 * H,)}
+                "init_h.weight": (H, F), "init_h.bias": (H,), "init_c.weight": (H, F), "init_c.bias": (H,),
+                f"{c}.weight_ih": (G, E + F), f"{c}.weight_hh": (G, H), f"{c}.bias_ih": (G,), f"{c}.bias_hh": (G,)}
+        return {n: full[n] for n in self.names()}
+
+
+# GRU configuration's names (kept for callers that only deal with AttentionGru)
+DEC_FIELD_TO_NAME = dict(DecDims(1, 1, 1, 1, 1, 1, 1, 1).fields())
 
 
 def _dec_struct(cls, dims: DecDims, t: Dict[str, torch.Tensor]):
     s = cls()
     shapes = dims.param_shapes()
-    for field, name in DEC_FIELD_TO_NAME.items():
+    for field, name in dims.fields():
         ten = t[name]
         if tuple(ten.shape) != shapes[name]:
             raise L.CaphnError(f"{name}: expected shape {shapes[name]}, got {tuple(ten.shape)}")
@@ -220,7 +243,8 @@ def decoder_workspace(dims: DecDims, device) -> torch.Tensor:
 def decoder_forward(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,
                     ws: torch.Tensor, logits: Optional[torch.Tensor] = None, alphas: Optional[torch.Tensor] = None,
                     validate: bool = True):
-    """AttentionGru.forward(features, captions, sample_prob=0.0) (models/decoderlstm.py:49-120).
+    """AttentionGru.forward(features, captions, 0.0) (models/decoderlstm.py:49-120) or, with
+    dims.cell == "lstm", AttentionLstm.forward(captions, features, 0.0) (:224-261).
     validate=True range-checks the token ids (one host sync); the fused engine checks its batches once."""
     lib = L.load()
     if tuple(features.shape) != (dims.B, dims.P, dims.D) or tuple(captions.shape) != (dims.B, dims.T):

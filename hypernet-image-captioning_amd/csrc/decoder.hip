@@ -14,10 +14,10 @@
 namespace {
 
 struct Ws {   // float offsets into the workspace
-    size_t Y1, f, meanf, h0, Waf, G, Xe, Xg, Hs, Hprev, gates, hn, uah, alphas, idx;
-    size_t dHs, dgi, dgh, duah, de, dh0, ctx, dctx, dXe, dWaf, dmeanf, df, dY1, apart, vtmp, colws;
+    size_t Y1, f, meanf, h0, c0, Waf, G, Xe, Xg, Hs, Hprev, gates, hn, Cs, Cprev, uah, alphas, idx;
+    size_t dHs, dgi, dgh, duah, de, dh0, dc0, ctx, dctx, dXe, dWaf, dmeanf, df, dY1, apart, vtmp, colws;
     size_t total;
-    int npc, pchunk;
+    int npc, pchunk, NG;
 };
 
 inline size_t up4(size_t v) { return (v + 3) & ~(size_t)3; }
@@ -25,21 +25,27 @@ inline size_t up4(size_t v) { return (v + 3) & ~(size_t)3; }
 inline Ws layout(const caphn_decoder_dims* d) {
     Ws w;
     const size_t B = d->B, T = d->T, P = d->P, F = d->F, E = d->E, H = d->H, V = d->V, D = d->D;
+    const bool lstm = d->cell == CAPHN_CELL_LSTM, raw = d->raw_features != 0;
+    const size_t NG = lstm ? 4 : 3;
+    w.NG = (int)NG;
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += up4(n); return r; };
-    w.Y1 = take(B * P * F); w.f = take(B * P * F); w.meanf = take(B * F); w.h0 = take(B * H);
-    w.Waf = take(B * P * H); w.G = take(B * P * 3 * H); w.Xe = take(B * T * E); w.Xg = take(B * T * 3 * H);
-    w.Hs = take(B * T * H); w.Hprev = take(B * T * H); w.gates = take(B * T * 3 * H); w.hn = take(B * T * H);
+    w.Y1 = take(raw ? 0 : B * P * F); w.f = take(raw ? 0 : B * P * F); w.meanf = take(B * F); w.h0 = take(B * H);
+    w.c0 = take(lstm ? B * H : 0);
+    w.Waf = take(B * P * H); w.G = take(B * P * NG * H); w.Xe = take(B * T * E); w.Xg = take(B * T * NG * H);
+    w.Hs = take(B * T * H); w.Hprev = take(B * T * H); w.gates = take(B * T * NG * H); w.hn = take(lstm ? 0 : B * T * H);
+    w.Cs = take(lstm ? B * T * H : 0); w.Cprev = take(lstm ? B * T * H : 0);
     w.uah = take(B * T * H); w.alphas = take(B * T * P); w.idx = take(2 * B * T);   // int64
-    w.dHs = take(B * T * H); w.dgi = take(B * T * 3 * H); w.dgh = take(B * T * 3 * H); w.duah = take(B * T * H);
-    w.de = take(B * T * P); w.dh0 = take(B * H); w.ctx = take(B * T * F); w.dctx = take(B * T * F);
-    w.dXe = take(B * T * E); w.dWaf = take(B * P * H); w.dmeanf = take(B * F); w.df = take(B * P * F);
-    w.dY1 = take(B * P * F);
+    w.dHs = take(B * T * H); w.dgi = take(B * T * NG * H); w.dgh = take(lstm ? 0 : B * T * NG * H); w.duah = take(B * T * H);
+    w.de = take(B * T * P); w.dh0 = take(B * H); w.dc0 = take(lstm ? B * H : 0);
+    w.ctx = take(B * T * F); w.dctx = take(raw ? 0 : B * T * F);
+    w.dXe = take(B * T * E); w.dWaf = take(B * P * H); w.dmeanf = take(raw ? 0 : B * F); w.df = take(raw ? 0 : B * P * F);
+    w.dY1 = take(raw ? 0 : B * P * F);
     w.pchunk = 7; w.npc = (int)((P + w.pchunk - 1) / w.pchunk);
     w.apart = take(B * w.npc * (H + 1)); w.vtmp = take(H + 1);
     size_t cs = 0;
     auto need = [&](size_t M, size_t N) { cs = std::max(cs, caphn_colsum_workspace_bytes((int)M, (int)N) / sizeof(float)); };
-    need(B * T, V); need(B * T, 3 * H); need(B * T, H); need(B * P, H); need(B * P, F); need(B, H);
+    need(B * T, V); need(B * T, NG * H); need(B * T, H); need(B * P, H); need(B * P, F); need(B, H);
     need(B * w.npc, H + 1);
     w.colws = take(cs);
     w.total = o;
@@ -56,7 +62,10 @@ __global__ void build_idx_kernel(int B, int T, const int64_t* __restrict__ caps,
 }
 
 inline bool dims_ok(const caphn_decoder_dims* d) {
-    return d && d->B > 0 && d->T > 0 && d->P > 0 && d->D > 0 && d->F > 0 && d->E > 0 && d->H > 0 && d->V > 0;
+    if (!(d && d->B > 0 && d->T > 0 && d->P > 0 && d->D > 0 && d->F > 0 && d->E > 0 && d->H > 0 && d->V > 0)) return false;
+    if (d->cell != CAPHN_CELL_GRU && d->cell != CAPHN_CELL_LSTM) return false;
+    if (d->raw_features && d->F != d->D) return false;
+    return true;
 }
 
 // split-K heuristic for the weight-gradient GEMMs (small MxN, long K): aim at >= 4 workgroups per CU
@@ -105,34 +114,45 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     const Ws w = layout(d);
     float* ws = static_cast<float*>(ws_);
     const int B = d->B, T = d->T, P = d->P, D = d->D, F = d->F, E = d->E, H = d->H, V = d->V;
-    const int BP = B * P, BT = B * T, H3 = 3 * H, EF = E + F;
-    if (caphn_gru_fwd_lds_bytes(P, H) > 160 * 1024 || caphn_gru_bwd_lds_bytes(P, H) > 160 * 1024) return CAPHN_ELIMIT;
+    const bool lstm = d->cell == CAPHN_CELL_LSTM, raw = d->raw_features != 0;
+    const int BP = B * P, BT = B * T, GH = w.NG * H, EF = E + F;
+    const int RG = caphn_rec_resident_gates(P, H, w.NG);
+    if (RG < 0) return CAPHN_ELIMIT;
+    if (lstm && (!p->initc_w || !p->initc_b)) return CAPHN_EINVAL;
+    if (!raw && (!p->fc0_w || !p->fc0_b || !p->fc2_w || !p->fc2_b)) return CAPHN_EINVAL;
 
-    // feature_fc: Linear(D,F) + ReLU + Linear(F,F)      decoderlstm.py:22-26,61
-    RUN(caphn_gemm_f32(0, 1, BP, F, D, features, D, p->fc0_w, D, ws + w.Y1, F, p->fc0_b, nullptr, 0,
-                       CAPHN_GEMM_BIAS | CAPHN_GEMM_RELU, 1, s));
-    RUN(caphn_gemm_f32(0, 1, BP, F, F, ws + w.Y1, F, p->fc2_w, F, ws + w.f, F, p->fc2_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
-    // init_hidden: mean over positions -> Linear(F,H)      :122-135
-    RUN(caphn_launch_mean_p(B, P, F, ws + w.f, ws + w.meanf, s));
+    const float* f = features;
+    if (!raw) {
+        // feature_fc: Linear(D,F) + ReLU + Linear(F,F)      decoderlstm.py:22-26,61
+        RUN(caphn_gemm_f32(0, 1, BP, F, D, features, D, p->fc0_w, D, ws + w.Y1, F, p->fc0_b, nullptr, 0,
+                           CAPHN_GEMM_BIAS | CAPHN_GEMM_RELU, 1, s));
+        RUN(caphn_gemm_f32(0, 1, BP, F, F, ws + w.Y1, F, p->fc2_w, F, ws + w.f, F, p->fc2_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+        f = ws + w.f;
+    }
+    // init_hidden: mean over positions -> Linear(F,H) (and init_c for the LSTM)      :122-135 / :255-260
+    RUN(caphn_launch_mean_p(B, P, F, f, ws + w.meanf, s));
     RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->inith_w, F, ws + w.h0, H, p->inith_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    if (lstm)
+        RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->initc_w, F, ws + w.c0, H, p->initc_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
     // t-invariant attention projection W_a f + b      attention.py:34
-    RUN(caphn_gemm_f32(0, 1, BP, H, F, ws + w.f, F, p->Wa_w, F, ws + w.Waf, H, p->Wa_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    RUN(caphn_gemm_f32(0, 1, BP, H, F, f, F, p->Wa_w, F, ws + w.Waf, H, p->Wa_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
     // G = f W_ih[:, E:]^T  (context side of the gate pre-activations, hoisted)
-    RUN(caphn_gemm_f32(0, 1, BP, H3, F, ws + w.f, F, p->w_ih + E, EF, ws + w.G, H3, nullptr, nullptr, 0, 0, 1, s));
+    RUN(caphn_gemm_f32(0, 1, BP, GH, F, f, F, p->w_ih + E, EF, ws + w.G, GH, nullptr, nullptr, 0, 0, 1, s));
     // embedding lookup with the reference's zeroed first two inputs, then the x side of the gates
     int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
     hipLaunchKernelGGL(build_idx_kernel, dim3((BT + 255) / 256), dim3(256), 0, s, B, T, captions, idx);
     RUN(caphn_embedding_gather(BT, E, p->embed_w, idx, ws + w.Xe, s));
-    RUN(caphn_gemm_f32(0, 1, BT, H3, E, ws + w.Xe, E, p->w_ih, EF, ws + w.Xg, H3, p->b_ih, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    RUN(caphn_gemm_f32(0, 1, BT, GH, E, ws + w.Xe, E, p->w_ih, EF, ws + w.Xg, GH, p->b_ih, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
 
-    GruFwdArgs a;
-    a.B = B; a.T = T; a.P = P; a.H = H;
-    a.Waf = ws + w.Waf; a.G = ws + w.G; a.Xg = ws + w.Xg; a.h0 = ws + w.h0;
+    RecFwdArgs a;
+    a.B = B; a.T = T; a.P = P; a.H = H; a.RG = RG;
+    a.Waf = ws + w.Waf; a.G = ws + w.G; a.Xg = ws + w.Xg; a.h0 = ws + w.h0; a.c0 = ws + w.c0;
     a.W_hh = p->w_hh; a.b_hh = p->b_hh; a.U_a = p->Ua_w; a.b_Ua = p->Ua_b; a.v_a = p->va_w; a.b_va = p->va_b;
-    a.Hs = ws + w.Hs; a.Hprev = ws + w.Hprev; a.alphas = ws + w.alphas; a.gates = ws + w.gates; a.hn = ws + w.hn; a.uah = ws + w.uah;
+    a.Hs = ws + w.Hs; a.Hprev = ws + w.Hprev; a.alphas = ws + w.alphas; a.gates = ws + w.gates; a.hn = ws + w.hn;
+    a.Cs = ws + w.Cs; a.Cprev = ws + w.Cprev; a.uah = ws + w.uah;
     a.vecW = (H % 4 == 0) && caphn_aligned16(p->w_hh) && caphn_aligned16(p->Ua_w);
-    a.vecS = ((size_t)P * H % 4 == 0) && caphn_aligned16(ws);
-    RUN(caphn_launch_gru_fwd(a, s));
+    a.vecS = (H % 4 == 0) && caphn_aligned16(ws);
+    RUN(caphn_launch_rec_fwd(a, lstm, s));
 
     // vocab projection for all (b,t) at once      decoderlstm.py:105
     RUN(caphn_gemm_f32(0, 1, BT, V, H, ws + w.Hs, H, p->out_w, H, logits, V, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
@@ -151,41 +171,47 @@ extern "C" int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_d
     const Ws w = layout(d);
     float* ws = static_cast<float*>(ws_);
     const int B = d->B, T = d->T, P = d->P, D = d->D, F = d->F, E = d->E, H = d->H, V = d->V;
-    const int BP = B * P, BT = B * T, H3 = 3 * H, EF = E + F;
+    const bool lstm = d->cell == CAPHN_CELL_LSTM, raw = d->raw_features != 0;
+    const int BP = B * P, BT = B * T, GH = w.NG * H, EF = E + F;
+    const int RG = caphn_rec_resident_gates(P, H, w.NG);
+    if (RG < 0) return CAPHN_ELIMIT;
+    if (lstm && (!g->initc_w || !g->initc_b)) return CAPHN_EINVAL;
     void* cws = ws + w.colws;
     const int64_t* idx = reinterpret_cast<const int64_t*>(ws + w.idx);
+    const float* f = raw ? features : ws + w.f;
+    float* dgi = ws + w.dgi;
+    float* dgh = lstm ? dgi : ws + w.dgh;          // LSTM: d(gi) == d(gh)
 
     // vocab projection: dW = dlogits^T Hs, db = colsum, dHs = dlogits W
     RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, s));
     RUN(caphn_colsum_f32(BT, V, dlogits, V, g->out_b, cws, s));
     RUN(gemm_auto(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, s));
 
-    GruBwdArgs a;
-    a.B = B; a.T = T; a.P = P; a.H = H;
+    RecBwdArgs a;
+    a.B = B; a.T = T; a.P = P; a.H = H; a.RG = RG;
     a.Waf = ws + w.Waf; a.G = ws + w.G; a.W_hh = p->w_hh; a.U_a = p->Ua_w; a.v_a = p->va_w;
     a.Hprev = ws + w.Hprev; a.alphas = ws + w.alphas; a.gates = ws + w.gates; a.hn = ws + w.hn; a.uah = ws + w.uah;
+    a.Cs = ws + w.Cs; a.Cprev = ws + w.Cprev;
     a.dHs = ws + w.dHs; a.dalphas = dalphas;
-    a.dgi = ws + w.dgi; a.dgh = ws + w.dgh; a.duah = ws + w.duah; a.de = ws + w.de; a.dh0 = ws + w.dh0;
+    a.dgi = dgi; a.dgh = dgh; a.duah = ws + w.duah; a.de = ws + w.de; a.dh0 = ws + w.dh0; a.dc0 = ws + w.dc0;
     a.vecW = (H % 4 == 0) && caphn_aligned16(p->w_hh) && caphn_aligned16(p->Ua_w);
-    a.vecS = ((size_t)P * H % 4 == 0) && caphn_aligned16(ws);
-    RUN(caphn_launch_gru_bwd(a, s));
+    a.vecS = (H % 4 == 0) && caphn_aligned16(ws);
+    RUN(caphn_launch_rec_bwd(a, lstm, s));
 
     // recurrent weights: dW_hh = dgh^T Hprev, dU_a = duah^T Hprev, biases by column sums
-    RUN(gemm_auto(1, 0, H3, H, BT, ws + w.dgh, H3, ws + w.Hprev, H, g->w_hh, H, nullptr, 0, s));
-    RUN(caphn_colsum_f32(BT, H3, ws + w.dgh, H3, g->b_hh, cws, s));
+    RUN(gemm_auto(1, 0, GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, nullptr, 0, s));
+    RUN(caphn_colsum_f32(BT, GH, dgh, GH, g->b_hh, cws, s));
     RUN(gemm_auto(1, 0, H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, nullptr, 0, s));
     RUN(caphn_colsum_f32(BT, H, ws + w.duah, H, g->Ua_b, cws, s));
-    RUN(caphn_colsum_f32(BT, H3, ws + w.dgi, H3, g->b_ih, cws, s));
+    RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cws, s));
     // input weights: dW_ih[:, :E] = dgi^T Xe ; dW_ih[:, E:] = dgi^T ctx
-    RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, ws + w.f, ws + w.ctx, s));
-    RUN(gemm_auto(1, 0, H3, E, BT, ws + w.dgi, H3, ws + w.Xe, E, g->w_ih, EF, nullptr, 0, s));
-    RUN(gemm_auto(1, 0, H3, F, BT, ws + w.dgi, H3, ws + w.ctx, F, g->w_ih + E, EF, nullptr, 0, s));
+    RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, s));
+    RUN(gemm_auto(1, 0, GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, nullptr, 0, s));
+    RUN(gemm_auto(1, 0, GH, F, BT, dgi, GH, ws + w.ctx, F, g->w_ih + E, EF, nullptr, 0, s));
     // embedding: dXe = dgi W_ih[:, :E] scattered to the rows looked up in the forward
-    RUN(caphn_gemm_f32(0, 0, BT, E, H3, ws + w.dgi, H3, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, s));
+    RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, s));
     if (hipMemsetAsync(g->embed_w, 0, sizeof(float) * (size_t)V * E, s) != hipSuccess) return CAPHN_ELAUNCH;
     RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, s));
-    // context path into f
-    RUN(caphn_gemm_f32(0, 0, BT, F, H3, ws + w.dgi, H3, p->w_ih + E, EF, ws + w.dctx, F, nullptr, nullptr, 0, 0, 1, s));
     // attention parameters
     AttnGradArgs ag;
     ag.T = T; ag.P = P; ag.H = H; ag.pchunk = w.pchunk;
@@ -195,21 +221,32 @@ extern "C" int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_d
     RUN(caphn_colsum_f32(B * w.npc, H + 1, ws + w.apart, H + 1, ws + w.vtmp, cws, s));
     if (hipMemcpyAsync(g->va_w, ws + w.vtmp, sizeof(float) * H, hipMemcpyDeviceToDevice, s) != hipSuccess) return CAPHN_ELAUNCH;
     if (hipMemcpyAsync(g->va_b, ws + w.vtmp + H, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return CAPHN_ELAUNCH;
-    RUN(gemm_auto(1, 0, H, F, BP, ws + w.dWaf, H, ws + w.f, F, g->Wa_w, F, nullptr, 0, s));
+    RUN(gemm_auto(1, 0, H, F, BP, ws + w.dWaf, H, f, F, g->Wa_w, F, nullptr, 0, s));
     RUN(caphn_colsum_f32(BP, H, ws + w.dWaf, H, g->Wa_b, cws, s));
-    // init_h
+    // init_h (and init_c)
     RUN(gemm_auto(1, 0, H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, nullptr, 0, s));
     RUN(caphn_colsum_f32(B, H, ws + w.dh0, H, g->inith_b, cws, s));
-    RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dh0, H, p->inith_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, 0, 1, s));
-    // df = alpha^T dctx + dmean/P + dWaf W_a
-    RUN(caphn_launch_df(B, T, P, F, ws + w.alphas, ws + w.dctx, ws + w.dmeanf, ws + w.df, s));
-    RUN(caphn_gemm_f32(0, 0, BP, F, H, ws + w.dWaf, H, p->Wa_w, F, ws + w.df, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
-    // feature_fc backward
-    RUN(gemm_auto(1, 0, F, F, BP, ws + w.df, F, ws + w.Y1, F, g->fc2_w, F, nullptr, 0, s));
-    RUN(caphn_colsum_f32(BP, F, ws + w.df, F, g->fc2_b, cws, s));
-    RUN(caphn_gemm_f32(0, 0, BP, F, F, ws + w.df, F, p->fc2_w, F, ws + w.dY1, F, nullptr, ws + w.Y1, F, CAPHN_GEMM_MASK, 1, s));
-    RUN(gemm_auto(1, 0, F, D, BP, ws + w.dY1, F, features, D, g->fc0_w, D, nullptr, 0, s));
-    RUN(caphn_colsum_f32(BP, F, ws + w.dY1, F, g->fc0_b, cws, s));
+    if (lstm) {
+        RUN(gemm_auto(1, 0, H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, nullptr, 0, s));
+        RUN(caphn_colsum_f32(B, H, ws + w.dc0, H, g->initc_b, cws, s));
+    }
+    if (!raw) {
+        if (!g->fc0_w || !g->fc0_b || !g->fc2_w || !g->fc2_b) return CAPHN_EINVAL;
+        // context path into f, initial-state path into mean f
+        RUN(caphn_gemm_f32(0, 0, BT, F, GH, dgi, GH, p->w_ih + E, EF, ws + w.dctx, F, nullptr, nullptr, 0, 0, 1, s));
+        RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dh0, H, p->inith_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, 0, 1, s));
+        if (lstm)
+            RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dc0, H, p->initc_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
+        // df = alpha^T dctx + dmean/P + dWaf W_a
+        RUN(caphn_launch_df(B, T, P, F, ws + w.alphas, ws + w.dctx, ws + w.dmeanf, ws + w.df, s));
+        RUN(caphn_gemm_f32(0, 0, BP, F, H, ws + w.dWaf, H, p->Wa_w, F, ws + w.df, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
+        // feature_fc backward
+        RUN(gemm_auto(1, 0, F, F, BP, ws + w.df, F, ws + w.Y1, F, g->fc2_w, F, nullptr, 0, s));
+        RUN(caphn_colsum_f32(BP, F, ws + w.df, F, g->fc2_b, cws, s));
+        RUN(caphn_gemm_f32(0, 0, BP, F, F, ws + w.df, F, p->fc2_w, F, ws + w.dY1, F, nullptr, ws + w.Y1, F, CAPHN_GEMM_MASK, 1, s));
+        RUN(gemm_auto(1, 0, F, D, BP, ws + w.dY1, F, features, D, g->fc0_w, D, nullptr, 0, s));
+        RUN(caphn_colsum_f32(BP, F, ws + w.dY1, F, g->fc0_b, cws, s));
+    }
     (void)captions;
     return caphn_launch_status();
 }

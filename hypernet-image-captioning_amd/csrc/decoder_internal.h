@@ -2,33 +2,40 @@
 #pragma once
 #include "common.h"
 
-struct GruFwdArgs {
+// Recurrent forward: GRU (3 gates r,z,n) or LSTM (4 gates i,f,g,o) cell with additive attention.
+struct RecFwdArgs {
     int B, T, P, H;
-    const float* Waf;   // [B,P,H]   W_a f + b_Wa
-    const float* G;     // [B,P,3H]  f W_ih[:,E:]^T
-    const float* Xg;    // [B,T,3H]  x_t W_ih[:,:E]^T + b_ih
+    int RG;             // gate slabs of G kept LDS-resident (the rest stream from L2)
+    const float* Waf;   // [B,P,H]    W_a f + b_Wa
+    const float* G;     // [B,P,NG*H] f W_ih[:,E:]^T
+    const float* Xg;    // [B,T,NG*H] x_t W_ih[:,:E]^T + b_ih
     const float* h0;    // [B,H]
-    const float* W_hh; const float* b_hh;   // [3H,H],[3H]
+    const float* c0;    // [B,H]      (LSTM)
+    const float* W_hh; const float* b_hh;   // [NG*H,H],[NG*H]
     const float* U_a; const float* b_Ua;    // [H,H],[H]
     const float* v_a; const float* b_va;    // [H],[1]
     float* Hs; float* Hprev;                // [B,T,H] h_t, h_{t-1}
     float* alphas;                          // [B,T,P]
-    float* gates;                           // [B,T,3H] r,z,n
-    float* hn;                              // [B,T,H]  W_hn h + b_hn
+    float* gates;                           // [B,T,NG*H] post-activation gates
+    float* hn;                              // [B,T,H]  W_hn h + b_hn          (GRU)
+    float* Cs; float* Cprev;                // [B,T,H]  c_t, c_{t-1}           (LSTM)
     float* uah;                             // [B,T,H]  U_a h + b_Ua
     int vecW, vecS;
 };
-struct GruBwdArgs {
+struct RecBwdArgs {
     int B, T, P, H;
+    int RG;
     const float* Waf; const float* G;
     const float* W_hh; const float* U_a; const float* v_a;
     const float* Hprev; const float* alphas; const float* gates; const float* hn; const float* uah;
+    const float* Cs; const float* Cprev;
     const float* dHs;       // [B,T,H] gradient arriving from the vocab projection
     const float* dalphas;   // [B,T,P] or null
-    float* dgi; float* dgh; // [B,T,3H]
+    float* dgi; float* dgh; // [B,T,NG*H] (LSTM: dgh == dgi, one array)
     float* duah;            // [B,T,H]
     float* de;              // [B,T,P]
     float* dh0;             // [B,H]
+    float* dc0;             // [B,H] (LSTM)
     int vecW, vecS;
 };
 struct AttnGradArgs {
@@ -38,10 +45,11 @@ struct AttnGradArgs {
     float* part;            // [B*npc, H+1]
 };
 
-size_t caphn_gru_fwd_lds_bytes(int P, int H);
-size_t caphn_gru_bwd_lds_bytes(int P, int H);
-int caphn_launch_gru_fwd(const GruFwdArgs& a, hipStream_t s);
-int caphn_launch_gru_bwd(const GruBwdArgs& a, hipStream_t s);
+size_t caphn_rec_fwd_lds_bytes(int P, int H, int NG, int RG);
+size_t caphn_rec_bwd_lds_bytes(int P, int H, int NG, int RG);
+int caphn_rec_resident_gates(int P, int H, int NG);       // largest RG whose fwd and bwd kernels fit 160 KB; -1 if none
+int caphn_launch_rec_fwd(const RecFwdArgs& a, bool lstm, hipStream_t s);
+int caphn_launch_rec_bwd(const RecBwdArgs& a, bool lstm, hipStream_t s);
 int caphn_launch_attn_param_grads(const AttnGradArgs& a, int B, int npc, hipStream_t s);
 int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const float* f, float* ctx, hipStream_t s);
 int caphn_launch_df(int B, int T, int P, int F, const float* alphas, const float* dctx, const float* dmean, float* df, hipStream_t s);

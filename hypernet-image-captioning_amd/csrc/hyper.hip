@@ -22,10 +22,13 @@ struct GemvJob {
 struct GemvJobs { GemvJob j[CAPHN_MAX_HEADS]; int n; };
 
 // ---------------------------------------------------------------- forward: y = act(W x + b)
-// wave per row, RB rows per iteration, QMAX dwordx4 per lane per row (k <= 256*QMAX)
+// wave per row, RB = 8 rows per iteration, QMAX dwordx4 per lane per row (k <= 256*QMAX): 8*QMAX
+// independent 16-byte loads in flight per lane.  The 8 row sums are reduced together: three
+// halving exchange stages (xor 32,16,8) leave one row per 8-lane group, three more finish it --
+// 10 shuffles per 8 rows instead of 48.
 template <int QMAX>
 __device__ __forceinline__ void gemv_rows_wave(const GemvJob& J, int wave_g, int nwaves, int lane) {
-    constexpr int RB = 4;
+    constexpr int RB = 8;
     const int k4 = J.k >> 2;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(J.x);
     f32x4 xr[QMAX];
@@ -34,6 +37,7 @@ __device__ __forceinline__ void gemv_rows_wave(const GemvJob& J, int wave_g, int
         int c = lane + 64 * q;
         xr[q] = c < k4 ? x4[c] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    const int myrow = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
     for (int r0 = wave_g * RB; r0 < J.rows; r0 += nwaves * RB) {
         f32x4 w[RB][QMAX];
 #pragma unroll
@@ -42,22 +46,36 @@ __device__ __forceinline__ void gemv_rows_wave(const GemvJob& J, int wave_g, int
 #pragma unroll
             for (int q = 0; q < QMAX; ++q) {
                 int c = lane + 64 * q;
-                w[i][q] = (r0 + i < J.rows && c < k4) ? row[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+                w[i][q] = (r0 + i < J.rows && c < k4) ? __builtin_nontemporal_load(row + c) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        float mine = 0.f;
+        float v[RB];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             float s = 0.f;
 #pragma unroll
             for (int q = 0; q < QMAX; ++q)
                 s += w[i][q][0] * xr[q][0] + w[i][q][1] * xr[q][1] + w[i][q][2] * xr[q][2] + w[i][q][3] * xr[q][3];
-            s = wave_sum(s);
-            if (lane == i) mine = s;
+            v[i] = s;
         }
-        if (lane < RB && r0 + lane < J.rows) {
-            float v = mine + (J.b ? J.b[r0 + lane] : 0.f);
-            J.y[r0 + lane] = J.act ? lrelu(v) : v;
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            const int mask = 32 >> st, half = RB >> (st + 1);
+            const bool hi = (lane & mask) != 0;
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const float send = hi ? v[j] : v[j + half];
+                const float keep = hi ? v[j + half] : v[j];
+                v[j] = keep + __shfl_xor(send, mask, 64);
+            }
+        }
+        float s = v[0];
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if ((lane & 7) == 0 && r0 + myrow < J.rows) {
+            float o = s + (J.b ? J.b[r0 + myrow] : 0.f);
+            J.y[r0 + myrow] = J.act ? lrelu(o) : o;
         }
     }
 }
@@ -132,7 +150,7 @@ __device__ __forceinline__ void gemv_t_wave(const GemvTJob& J, int lb, int tid, 
 #pragma unroll
             for (int q = 0; q < QMAX; ++q) {
                 int c = lane + 64 * q;
-                w[i][q] = (ok && c < k4) ? row[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+                w[i][q] = (ok && c < k4) ? __builtin_nontemporal_load(row + c) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
 #pragma unroll
@@ -244,7 +262,7 @@ __global__ __launch_bounds__(256) void outer_kernel(OuterJobs jobs) {
 
 inline int gemv_blocks(int rows, int k, int vec) {
     // enough waves to cover the chip; big jobs grid-stride
-    long want = (vec && k >= 128) ? ((long)rows + 15) / 16 : ((long)rows + 31) / 32;
+    long want = (vec && k >= 128) ? ((long)rows + 31) / 32 : ((long)rows + 31) / 32;
     if (want < 1) want = 1;
     if (want > 2048) want = 2048;
     return (int)want;

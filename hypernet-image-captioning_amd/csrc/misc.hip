@@ -221,26 +221,56 @@ template <int QMAX>
 __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W, float* m, float* v,
                                                const float* gfac, size_t ldg, const float* afac, size_t lda,
                                                float c, const AdamK& K, int wave_g, int nwaves, int lane) {
+    constexpr int RB = 2;                 // rows per iteration: 6*QMAX independent dwordx4 loads in flight
     const int k4 = k >> 2;
-    for (int row = wave_g; row < rows; row += nwaves) {
-        float gr[RMAX];
+    // column factors of this lane's chunks stay in registers for every row (R == 1 fast path)
+    f32x4 a1[QMAX];
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) gr[r] = r < R ? gfac[(size_t)r * ldg + row] * c : 0.f;
-        f32x4* W4 = reinterpret_cast<f32x4*>(W + (size_t)row * k);
-        f32x4* m4 = reinterpret_cast<f32x4*>(m + (size_t)row * k);
-        f32x4* v4 = reinterpret_cast<f32x4*>(v + (size_t)row * k);
+    for (int q = 0; q < QMAX; ++q) {
+        const int cidx = lane + 64 * q;
+        a1[q] = (R == 1 && cidx < k4) ? reinterpret_cast<const f32x4*>(afac)[cidx] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row0 = wave_g * RB; row0 < rows; row0 += nwaves * RB) {
+        f32x4 pp[RB][QMAX], mm[RB][QMAX], vv[RB][QMAX];
 #pragma unroll
-        for (int q = 0; q < QMAX; ++q) {
-            const int cidx = lane + 64 * q;
-            if (cidx < k4) {
-                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < RB; ++i) {
+            const size_t base = (size_t)(row0 + i) * k;
 #pragma unroll
-                for (int r = 0; r < RMAX; ++r)
-                    if (r < R) g += reinterpret_cast<const f32x4*>(afac + (size_t)r * lda)[cidx] * gr[r];
-                f32x4 pp = W4[cidx], mm = m4[cidx], vv = v4[cidx];
+            for (int q = 0; q < QMAX; ++q) {
+                const int cidx = lane + 64 * q;
+                if (row0 + i < rows && cidx < k4) {
+                    pp[i][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(W + base) + cidx);
+                    mm[i][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + base) + cidx);
+                    vv[i][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + base) + cidx);
+                }
+            }
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { float me = mm[e], ve = vv[e]; pp[e] = adam_elem(pp[e], g[e], me, ve, K); mm[e] = me; vv[e] = ve; }
-                W4[cidx] = pp; m4[cidx] = mm; v4[cidx] = vv;
+        for (int i = 0; i < RB; ++i) {
+            if (row0 + i >= rows) continue;
+            const size_t base = (size_t)(row0 + i) * k;
+            float gr[RMAX];
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) gr[r] = r < R ? gfac[(size_t)r * ldg + row0 + i] * c : 0.f;
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) {
+                const int cidx = lane + 64 * q;
+                if (cidx < k4) {
+                    f32x4 g;
+                    if (R == 1) g = a1[q] * gr[0];
+                    else {
+                        g = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int r = 0; r < RMAX; ++r)
+                            if (r < R) g += reinterpret_cast<const f32x4*>(afac + (size_t)r * lda)[cidx] * gr[r];
+                    }
+                    f32x4 po = pp[i][q], mo = mm[i][q], vo = vv[i][q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float me = mo[e], ve = vo[e]; po[e] = adam_elem(po[e], g[e], me, ve, K); mo[e] = me; vo[e] = ve; }
+                    __builtin_nontemporal_store(po, reinterpret_cast<f32x4*>(W + base) + cidx);
+                    __builtin_nontemporal_store(mo, reinterpret_cast<f32x4*>(m + base) + cidx);
+                    __builtin_nontemporal_store(vo, reinterpret_cast<f32x4*>(v + base) + cidx);
+                }
             }
         }
     }
@@ -365,7 +395,7 @@ extern "C" int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, f
                                    const float* coef, const caphn_adam_hparams* hp, caphn_stream_t stream) {
     if (R <= 0 || R > RMAX || rows <= 0 || k <= 0 || !W || !m || !v || !gfac || !afac || !coef || !hp || hp->step < 1) return CAPHN_EINVAL;
     const int vec = (k % 4 == 0) && (lda % 4 == 0) && caphn_aligned16(W) && caphn_aligned16(m) && caphn_aligned16(v) && caphn_aligned16(afac);
-    long nb = ((long)rows + 3) / 4;
+    long nb = ((long)rows + 7) / 8;
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(adam_rank_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, make_adam(hp), vec);

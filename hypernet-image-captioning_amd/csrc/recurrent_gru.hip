@@ -65,21 +65,43 @@ __device__ __forceinline__ KG kg_map(int tid, int H) {
     return m;
 }
 
-__global__ __launch_bounds__(NT) void gru_attn_fwd_kernel(GruFwdArgs a) {
+// resident part of G: gate slabs [0, RG) of every position row
+__device__ __forceinline__ void load_G_resident(float* G_s, const float* __restrict__ Gb, int P, int GH, int RGH,
+                                                int vec, int tid) {
+    if (RGH == GH) { copy_to_lds(G_s, Gb, P * GH, vec, tid); return; }
+    if (vec) {
+        const int r4 = RGH >> 2;
+        for (int i = tid; i < P * r4; i += NT) {
+            const int p = i / r4, c = i - p * r4;
+            reinterpret_cast<f32x4*>(G_s + p * RGH)[c] = reinterpret_cast<const f32x4*>(Gb + (size_t)p * GH)[c];
+        }
+    } else {
+        for (int i = tid; i < P * RGH; i += NT) { const int p = i / RGH, c = i - p * RGH; G_s[i] = Gb[(size_t)p * GH + c]; }
+    }
+}
+
+template <bool LSTM>
+__global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
+    constexpr int NG = LSTM ? 4 : 3;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int P = a.P, H = a.H, H3 = 3 * a.H, T = a.T;
+    const int P = a.P, H = a.H, GH = NG * a.H, T = a.T, RG = a.RG, RGH = a.RG * a.H;
     const int Ppad = (P + 63) & ~63;
     float* G_s = lds;
-    float* h_s = G_s + P * H3;
+    float* h_s = G_s + P * RGH;
     float* uah_s = h_s + H;
     float* va_s = uah_s + H;
-    float* gh_s = va_s + H;
-    float* e_s = gh_s + H3;
-    float* part_s = e_s + Ppad;          // [ng][3H]
+    float* c_s = va_s + H;
+    float* gh_s = c_s + H;
+    float* e_s = gh_s + GH;
+    float* part_s = e_s + Ppad;          // [ng][GH]
 
-    copy_to_lds(G_s, a.G + (size_t)b * P * H3, P * H3, a.vecS, tid);
-    for (int k = tid; k < H; k += NT) { h_s[k] = a.h0[(size_t)b * H + k]; va_s[k] = a.v_a[k]; }
+    const float* Gb = a.G + (size_t)b * P * GH;
+    load_G_resident(G_s, Gb, P, GH, RGH, a.vecS, tid);
+    for (int k = tid; k < H; k += NT) {
+        h_s[k] = a.h0[(size_t)b * H + k]; va_s[k] = a.v_a[k];
+        c_s[k] = LSTM ? a.c0[(size_t)b * H + k] : 0.f;
+    }
     const float bva = a.b_va[0];
     const float* Waf_b = a.Waf + (size_t)b * P * H;
     const KG m = kg_map(tid, H);
@@ -89,7 +111,7 @@ __global__ __launch_bounds__(NT) void gru_attn_fwd_kernel(GruFwdArgs a) {
         const size_t bt = (size_t)b * T + t;
         // A: U_a h + b_Ua -> uah_s ; W_hh h + b_hh -> gh_s   (W_hh, U_a streamed from L2)
         matvec_rows(a.U_a, a.b_Ua, h_s, uah_s, H, H, a.vecW, tid);
-        matvec_rows(a.W_hh, a.b_hh, h_s, gh_s, H3, H, a.vecW, tid);
+        matvec_rows(a.W_hh, a.b_hh, h_s, gh_s, GH, H, a.vecW, tid);
         __syncthreads();
         // B: e_p = v_a . tanh(Waf_p + uah) + b_va   (one wave per position, shuffle reduction)
         for (int p = wave; p < P; p += NT / 64) {
@@ -114,35 +136,55 @@ __global__ __launch_bounds__(NT) void gru_attn_fwd_kernel(GruFwdArgs a) {
         // D1: partial gi_ctx = sum_{p = g mod ng} alpha_p G_p over thread groups
         if (m.g >= 0) {
             for (int k = m.k; k < H; k += (m.ng == 1 ? NT : H)) {
-                float gr = 0.f, gz = 0.f, gn = 0.f;
+                float acc[NG];
+#pragma unroll
+                for (int q = 0; q < NG; ++q) acc[q] = 0.f;
                 for (int p = m.g; p < P; p += m.ng) {
                     const float al = e_s[p];
-                    const float* gp = G_s + p * H3 + k;
-                    gr += al * gp[0]; gz += al * gp[H]; gn += al * gp[2 * H];
+#pragma unroll
+                    for (int q = 0; q < NG; ++q)
+                        acc[q] += al * (q < RG ? G_s[p * RGH + q * H + k] : Gb[(size_t)p * GH + q * H + k]);
                 }
-                float* ps = part_s + m.g * H3;
-                ps[k] = gr; ps[H + k] = gz; ps[2 * H + k] = gn;
+#pragma unroll
+                for (int q = 0; q < NG; ++q) part_s[m.g * GH + q * H + k] = acc[q];
             }
         }
         __syncthreads();
         // D2: gates and h'
         for (int k = tid; k < H; k += NT) {
-            float gr = 0.f, gz = 0.f, gn = 0.f;
-            for (int g = 0; g < m.ng; ++g) {
-                const float* ps = part_s + g * H3;
-                gr += ps[k]; gz += ps[H + k]; gn += ps[2 * H + k];
+            float pre[NG];
+            const float* xg = a.Xg + bt * GH;
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                float s = 0.f;
+                for (int g = 0; g < m.ng; ++g) s += part_s[g * GH + q * H + k];
+                pre[q] = xg[q * H + k] + s;
             }
-            const float* xg = a.Xg + bt * H3;
             const float hp = h_s[k];
-            const float r = caphn_sigmoid(xg[k] + gr + gh_s[k]);
-            const float z = caphn_sigmoid(xg[H + k] + gz + gh_s[H + k]);
-            const float hnv = gh_s[2 * H + k];
-            const float n = caphn_tanh(xg[2 * H + k] + gn + r * hnv);
-            const float hnew = (1.0f - z) * n + z * hp;
+            float hnew;
+            if (LSTM) {
+                const float gi = caphn_sigmoid(pre[0] + gh_s[k]);
+                const float gf = caphn_sigmoid(pre[1] + gh_s[H + k]);
+                const float gg = caphn_tanh(pre[2] + gh_s[2 * H + k]);
+                const float go = caphn_sigmoid(pre[3 % NG] + gh_s[(3 % NG) * H + k]);
+                const float cp = c_s[k];
+                const float cn = gf * cp + gi * gg;
+                hnew = go * caphn_tanh(cn);
+                a.gates[bt * GH + k] = gi; a.gates[bt * GH + H + k] = gf; a.gates[bt * GH + 2 * H + k] = gg;
+                a.gates[bt * GH + (3 % NG) * H + k] = go;
+                a.Cprev[bt * H + k] = cp; a.Cs[bt * H + k] = cn;
+                c_s[k] = cn;
+            } else {
+                const float r = caphn_sigmoid(pre[0] + gh_s[k]);
+                const float z = caphn_sigmoid(pre[1] + gh_s[H + k]);
+                const float hnv = gh_s[2 * H + k];
+                const float n = caphn_tanh(pre[2] + r * hnv);
+                hnew = (1.0f - z) * n + z * hp;
+                a.gates[bt * GH + k] = r; a.gates[bt * GH + H + k] = z; a.gates[bt * GH + 2 * H + k] = n;
+                a.hn[bt * H + k] = hnv;
+            }
             a.Hprev[bt * H + k] = hp;
             a.Hs[bt * H + k] = hnew;
-            a.gates[bt * H3 + k] = r; a.gates[bt * H3 + H + k] = z; a.gates[bt * H3 + 2 * H + k] = n;
-            a.hn[bt * H + k] = hnv;
             a.uah[bt * H + k] = uah_s[k];
             h_s[k] = hnew;                  // only this thread reads h_s[k] in D2
         }
@@ -151,8 +193,9 @@ __global__ __launch_bounds__(NT) void gru_attn_fwd_kernel(GruFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// BPTT.  Walks t = T-1 .. 0 with dh carried in LDS.  G stays LDS-resident (d alpha_p = G_p . dgi).
-// Emits per-step dgi, dgh, d(U_a h), d e -- the weight gradients are batched MFMA GEMMs afterwards.
+// BPTT.  Walks t = T-1 .. 0 with dh (and dc) carried in LDS.  Resident G slabs serve
+// d alpha_p = G_p . dgi.  Emits per-step dgi, dgh, d(U_a h), d e -- the weight gradients are
+// batched MFMA GEMMs afterwards.
 template <int CH>   // CH = 4: dwordx4 column chunks, CH = 1: scalar columns (H % 4 != 0)
 __device__ __forceinline__ void matvec_t_accum(const float* __restrict__ W, const float* d_s, int rows, int H,
                                                int chunk, int slice, int nslices, float (&acc)[CH]) {
@@ -168,24 +211,28 @@ __device__ __forceinline__ void matvec_t_accum(const float* __restrict__ W, cons
     }
 }
 
-__global__ __launch_bounds__(NT) void gru_attn_bwd_kernel(GruBwdArgs a) {
+template <bool LSTM>
+__global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
+    constexpr int NG = LSTM ? 4 : 3;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int P = a.P, H = a.H, H3 = 3 * a.H, T = a.T;
+    const int P = a.P, H = a.H, GH = NG * a.H, T = a.T, RG = a.RG, RGH = a.RG * a.H;
     const int Ppad = (P + 63) & ~63;
     float* G_s = lds;
-    float* dh_s = G_s + P * H3;
-    float* duah_s = dh_s + H;
+    float* dh_s = G_s + P * RGH;
+    float* dc_s = dh_s + H;
+    float* duah_s = dc_s + H;
     float* uah_s = duah_s + H;
     float* va_s = uah_s + H;
     float* dgh_s = va_s + H;
-    float* dgi_s = dgh_s + H3;
-    float* dal_s = dgi_s + H3;
+    float* dgi_s = dgh_s + GH;
+    float* dal_s = dgi_s + GH;
     float* al_s = dal_s + Ppad;
     float* part_s = al_s + Ppad;     // [max(nslices, ng)][H]
 
-    copy_to_lds(G_s, a.G + (size_t)b * P * H3, P * H3, a.vecS, tid);
-    for (int k = tid; k < H; k += NT) { dh_s[k] = 0.f; va_s[k] = a.v_a[k]; }
+    const float* Gb = a.G + (size_t)b * P * GH;
+    load_G_resident(G_s, Gb, P, GH, RGH, a.vecS, tid);
+    for (int k = tid; k < H; k += NT) { dh_s[k] = 0.f; dc_s[k] = 0.f; va_s[k] = a.v_a[k]; }
     const float* Waf_b = a.Waf + (size_t)b * P * H;
     // transposed mat-vec thread map: chunk of CH columns x row slice
     const int CH = a.vecW ? 4 : 1;
@@ -198,28 +245,48 @@ __global__ __launch_bounds__(NT) void gru_attn_bwd_kernel(GruBwdArgs a) {
     for (int t = T - 1; t >= 0; --t) {
         const size_t bt = (size_t)b * T + t;
         for (int p = tid; p < P; p += NT) al_s[p] = a.alphas[bt * P + p];
-        // GRU cell backward (pointwise), thread k
+        // cell backward (pointwise), thread k
         for (int k = tid; k < H; k += NT) {
-            const float r = a.gates[bt * H3 + k], z = a.gates[bt * H3 + H + k], n = a.gates[bt * H3 + 2 * H + k];
-            const float hnv = a.hn[bt * H + k], hp = a.Hprev[bt * H + k];
             const float dh = dh_s[k] + a.dHs[bt * H + k];
-            const float dn = dh * (1.0f - z);
-            const float dz = dh * (hp - n);
-            const float dnp = dn * (1.0f - n * n);
-            const float drp = dnp * hnv * r * (1.0f - r);
-            const float dzp = dz * z * (1.0f - z);
-            dh_s[k] = dh * z;                              // direct path h_{t-1} -> h_t
             uah_s[k] = a.uah[bt * H + k];
-            dgi_s[k] = drp; dgi_s[H + k] = dzp; dgi_s[2 * H + k] = dnp;
-            dgh_s[k] = drp; dgh_s[H + k] = dzp; dgh_s[2 * H + k] = dnp * r;
-            a.dgi[bt * H3 + k] = drp; a.dgi[bt * H3 + H + k] = dzp; a.dgi[bt * H3 + 2 * H + k] = dnp;
-            a.dgh[bt * H3 + k] = drp; a.dgh[bt * H3 + H + k] = dzp; a.dgh[bt * H3 + 2 * H + k] = dnp * r;
+            if (LSTM) {
+                const float gi = a.gates[bt * GH + k], gf = a.gates[bt * GH + H + k], gg = a.gates[bt * GH + 2 * H + k];
+                const float go = a.gates[bt * GH + (3 % NG) * H + k];
+                const float cp = a.Cprev[bt * H + k];
+                const float tc = caphn_tanh(a.Cs[bt * H + k]);
+                const float d_o = dh * tc;
+                const float dc = dc_s[k] + dh * go * (1.0f - tc * tc);
+                const float dip = dc * gg * gi * (1.0f - gi);
+                const float dfp = dc * cp * gf * (1.0f - gf);
+                const float dgp = dc * gi * (1.0f - gg * gg);
+                const float dop = d_o * go * (1.0f - go);
+                dc_s[k] = dc * gf;
+                dh_s[k] = 0.f;                              // no direct h_{t-1} -> h_t path in an LSTM
+                dgi_s[k] = dip; dgi_s[H + k] = dfp; dgi_s[2 * H + k] = dgp; dgi_s[(3 % NG) * H + k] = dop;
+                dgh_s[k] = dip; dgh_s[H + k] = dfp; dgh_s[2 * H + k] = dgp; dgh_s[(3 % NG) * H + k] = dop;
+                a.dgi[bt * GH + k] = dip; a.dgi[bt * GH + H + k] = dfp; a.dgi[bt * GH + 2 * H + k] = dgp;
+                a.dgi[bt * GH + (3 % NG) * H + k] = dop;
+            } else {
+                const float r = a.gates[bt * GH + k], z = a.gates[bt * GH + H + k], n = a.gates[bt * GH + 2 * H + k];
+                const float hnv = a.hn[bt * H + k], hp = a.Hprev[bt * H + k];
+                const float dn = dh * (1.0f - z);
+                const float dz = dh * (hp - n);
+                const float dnp = dn * (1.0f - n * n);
+                const float drp = dnp * hnv * r * (1.0f - r);
+                const float dzp = dz * z * (1.0f - z);
+                dh_s[k] = dh * z;                              // direct path h_{t-1} -> h_t
+                dgi_s[k] = drp; dgi_s[H + k] = dzp; dgi_s[2 * H + k] = dnp;
+                dgh_s[k] = drp; dgh_s[H + k] = dzp; dgh_s[2 * H + k] = dnp * r;
+                a.dgi[bt * GH + k] = drp; a.dgi[bt * GH + H + k] = dzp; a.dgi[bt * GH + 2 * H + k] = dnp;
+                a.dgh[bt * GH + k] = drp; a.dgh[bt * GH + H + k] = dzp; a.dgh[bt * GH + 2 * H + k] = dnp * r;
+            }
         }
         __syncthreads();
         // d alpha_p = G_p . dgi  (+ external gradient on the returned attention weights)
         for (int p = wave; p < P; p += NT / 64) {
             float s = 0.f;
-            for (int j = lane; j < H3; j += 64) s += G_s[p * H3 + j] * dgi_s[j];
+            for (int j = lane; j < RGH; j += 64) s += G_s[p * RGH + j] * dgi_s[j];
+            for (int j = RGH + lane; j < GH; j += 64) s += Gb[(size_t)p * GH + j] * dgi_s[j];
             s = wave_sum(s);
             if (lane == 0) dal_s[p] = s + (a.dalphas ? a.dalphas[bt * P + p] : 0.f);
         }
@@ -264,12 +331,12 @@ __global__ __launch_bounds__(NT) void gru_attn_bwd_kernel(GruBwdArgs a) {
                 for (int c = chunk; c < nch; c += nch_eff) {
                     if (CH == 4) {
                         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                        matvec_t_accum<4>(a.W_hh, dgh_s, H3, H, c, slice, nslices, acc);
+                        matvec_t_accum<4>(a.W_hh, dgh_s, GH, H, c, slice, nslices, acc);
                         matvec_t_accum<4>(a.U_a, duah_s, H, H, c, slice, nslices, acc);
                         *reinterpret_cast<f32x4*>(part_s + slice * H + c * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
                     } else {
                         float acc[1] = {0.f};
-                        matvec_t_accum<1>(a.W_hh, dgh_s, H3, H, c, slice, nslices, acc);
+                        matvec_t_accum<1>(a.W_hh, dgh_s, GH, H, c, slice, nslices, acc);
                         matvec_t_accum<1>(a.U_a, duah_s, H, H, c, slice, nslices, acc);
                         part_s[slice * H + c] = acc[0];
                     }
@@ -284,7 +351,10 @@ __global__ __launch_bounds__(NT) void gru_attn_bwd_kernel(GruBwdArgs a) {
         }
         __syncthreads();
     }
-    for (int k = tid; k < H; k += NT) a.dh0[(size_t)b * H + k] = dh_s[k];
+    for (int k = tid; k < H; k += NT) {
+        a.dh0[(size_t)b * H + k] = dh_s[k];
+        if (LSTM) a.dc0[(size_t)b * H + k] = dc_s[k];
+    }
 }
 
 // dWaf[b,p,k] = v_k sum_t de[b,t,p] (1 - tanh^2(Waf[b,p,k] + uah[b,t,k]))
@@ -354,10 +424,10 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 bool g_attr_set = false;
 int ensure_lds_attr() {
     if (g_attr_set) return CAPHN_OK;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_attn_fwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess) return CAPHN_ELAUNCH;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_attn_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess) return CAPHN_ELAUNCH;
+    const void* fns[4] = {reinterpret_cast<const void*>(rec_attn_fwd_kernel<false>), reinterpret_cast<const void*>(rec_attn_fwd_kernel<true>),
+                          reinterpret_cast<const void*>(rec_attn_bwd_kernel<false>), reinterpret_cast<const void*>(rec_attn_bwd_kernel<true>)};
+    for (const void* f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess) return CAPHN_ELAUNCH;
     g_attr_set = true;
     return CAPHN_OK;
 }
@@ -365,35 +435,42 @@ int ensure_lds_attr() {
 }  // namespace
 
 static int kg_groups(int H) { return H >= NT ? 1 : NT / H; }
-size_t caphn_gru_fwd_lds_bytes(int P, int H) {
+size_t caphn_rec_fwd_lds_bytes(int P, int H, int NG, int RG) {
     const size_t Ppad = (P + 63) & ~63;
-    return sizeof(float) * ((size_t)3 * P * H + 6 * (size_t)H + Ppad + (size_t)kg_groups(H) * 3 * H);
+    return sizeof(float) * ((size_t)RG * P * H + 4 * (size_t)H + (size_t)NG * H + Ppad + (size_t)kg_groups(H) * NG * H);
 }
-size_t caphn_gru_bwd_lds_bytes(int P, int H) {
+size_t caphn_rec_bwd_lds_bytes(int P, int H, int NG, int RG) {
     const size_t Ppad = (P + 63) & ~63;
     const int CH = (H % 4 == 0) ? 4 : 1;
     const int nch = (H + CH - 1) / CH;
     const int nch_eff = nch < NT ? nch : NT;
     int nsl = NT / nch_eff;
     if (kg_groups(H) > nsl) nsl = kg_groups(H);
-    // the scalar-column map (CH = 1) may be chosen at run time for unaligned weights: it needs NT / min(H, NT) slices
+    // the scalar-column map (CH = 1) may be chosen at run time for unaligned weights
     const int nsl1 = NT / (H < NT ? H : NT);
     if (nsl1 > nsl) nsl = nsl1;
-    return sizeof(float) * ((size_t)3 * P * H + 10 * (size_t)H + 2 * Ppad + (size_t)nsl * H);
+    return sizeof(float) * ((size_t)RG * P * H + 5 * (size_t)H + 2 * (size_t)NG * H + 2 * Ppad + (size_t)nsl * H);
+}
+int caphn_rec_resident_gates(int P, int H, int NG) {
+    for (int rg = NG; rg >= 0; --rg)
+        if (caphn_rec_fwd_lds_bytes(P, H, NG, rg) <= LDS_LIMIT && caphn_rec_bwd_lds_bytes(P, H, NG, rg) <= LDS_LIMIT) return rg;
+    return -1;
 }
 
-int caphn_launch_gru_fwd(const GruFwdArgs& a, hipStream_t s) {
-    const size_t lds = caphn_gru_fwd_lds_bytes(a.P, a.H);
+int caphn_launch_rec_fwd(const RecFwdArgs& a, bool lstm, hipStream_t s) {
+    const size_t lds = caphn_rec_fwd_lds_bytes(a.P, a.H, lstm ? 4 : 3, a.RG);
     if (lds > LDS_LIMIT) return CAPHN_ELIMIT;
     int rc = ensure_lds_attr(); if (rc) return rc;
-    hipLaunchKernelGGL(gru_attn_fwd_kernel, dim3(a.B), dim3(NT), lds, s, a);
+    if (lstm) hipLaunchKernelGGL(rec_attn_fwd_kernel<true>, dim3(a.B), dim3(NT), lds, s, a);
+    else hipLaunchKernelGGL(rec_attn_fwd_kernel<false>, dim3(a.B), dim3(NT), lds, s, a);
     return caphn_launch_status();
 }
-int caphn_launch_gru_bwd(const GruBwdArgs& a, hipStream_t s) {
-    const size_t lds = caphn_gru_bwd_lds_bytes(a.P, a.H);
+int caphn_launch_rec_bwd(const RecBwdArgs& a, bool lstm, hipStream_t s) {
+    const size_t lds = caphn_rec_bwd_lds_bytes(a.P, a.H, lstm ? 4 : 3, a.RG);
     if (lds > LDS_LIMIT) return CAPHN_ELIMIT;
     int rc = ensure_lds_attr(); if (rc) return rc;
-    hipLaunchKernelGGL(gru_attn_bwd_kernel, dim3(a.B), dim3(NT), lds, s, a);
+    if (lstm) hipLaunchKernelGGL(rec_attn_bwd_kernel<true>, dim3(a.B), dim3(NT), lds, s, a);
+    else hipLaunchKernelGGL(rec_attn_bwd_kernel<false>, dim3(a.B), dim3(NT), lds, s, a);
     return caphn_launch_status();
 }
 int caphn_launch_attn_param_grads(const AttnGradArgs& a, int B, int npc, hipStream_t s) {

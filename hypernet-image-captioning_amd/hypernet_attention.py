@@ -11,7 +11,7 @@ from torch.nn import functional as F
 
 from caphn import functional as CF
 from caphn import ops
-from models.decoderlstm import AttentionGru
+from models.decoderlstm import AttentionGru, AttentionLstm
 from models.encoder import EncoderCNN
 from utils import flip_parameters_to_tensors, set_all_parameters
 
@@ -47,7 +47,10 @@ def build_hypernet_layers(cell: nn.Module, hyper_emb: int):
 
 class HyperNet(_Base):
     def __init__(self, feature_size, embed_size, hidden_size, vocab_size, vocab, num_layers=1, lr=1e-6,
-                 mixup=False, alpha=0.3, cc=False, hyper_emb=10):
+                 mixup=False, alpha=0.3, cc=False, hyper_emb=10, cell='gru'):
+        """Reference signature (hypernet_attention.py:33) plus `cell`: 'gru' builds the reference's
+        AttentionGru captioner; 'lstm' (extension) builds an AttentionLstm behind the
+        same feature_fc and generates the LSTMCell's weights instead."""
         super().__init__()
         hp = self.hparams if pl is not None else {}
         hp['feature_size'] = feature_size; hp['vocab_size'] = vocab_size; hp['embed_size'] = embed_size
@@ -60,12 +63,22 @@ class HyperNet(_Base):
         self.mixup = mixup
         self.alpha = alpha
         self.image_encoder = EncoderCNN()
-        self.captioner = AttentionGru(2048, feature_size, embed_size, hidden_size, vocab_size, p=0.0)
+        self.cell = cell
+        if cell == 'gru':
+            self.captioner = AttentionGru(2048, feature_size, embed_size, hidden_size, vocab_size, p=0.0)
+        elif cell == 'lstm':
+            self.captioner = AttentionLstm(2048, embed_size, hidden_size, vocab_size, p=0.0, feature_out=feature_size)
+        else:
+            raise ValueError("cell must be 'gru' or 'lstm'")
         if not cc:
             hyper_emb = embed_size
         self.hyper_emb = hyper_emb
-        self.hn_base, self.hn_heads = build_hypernet_layers(self.captioner.gru, hyper_emb)
+        self.hn_base, self.hn_heads = build_hypernet_layers(self.cell_module, hyper_emb)
         self._shape = ops.HyperShape(hyper_emb, [(h[0].out_features, h[2].out_features) for h in self.hn_heads])
+
+    @property
+    def cell_module(self):
+        return self.captioner.gru if self.cell == 'gru' else self.captioner.lstm
 
     def hyper_named_tensors(self):
         t = {"hn_base.0.weight": self.hn_base[0].weight, "hn_base.0.bias": self.hn_base[0].bias,
@@ -78,8 +91,8 @@ class HyperNet(_Base):
     def forward(self, x):
         """hypernet_attention.py:111-121.  x: [1,he] (Flickr) or [he] (CC one-hot row)."""
         heads_out = CF.hyper_forward(self._shape, x, self.hyper_named_tensors())
-        flip_parameters_to_tensors(self.captioner.gru)
-        set_all_parameters(self.captioner.gru, heads_out.reshape(1, -1))
+        flip_parameters_to_tensors(self.cell_module)
+        set_all_parameters(self.cell_module, heads_out.reshape(1, -1))
         return self.captioner
 
     def configure_optimizers(self):
@@ -103,6 +116,9 @@ class HyperNet(_Base):
         style_embed = self.captioner.embed(style)
         self.forward(style_embed)
         img_feats = self.image_encoder(imgs.float())
-        caps_pred, _ = self.captioner(img_feats, caps.long(), self.teacher_forcing_proba)
+        if self.cell == 'gru':
+            caps_pred, _ = self.captioner(img_feats, caps.long(), self.teacher_forcing_proba)
+        else:
+            caps_pred, _ = self.captioner(caps.long(), img_feats, self.teacher_forcing_proba)
         return F.cross_entropy(caps_pred.view(-1, self.hparams['vocab_size']), caps.view(-1).long(),
                                ignore_index=self.vocab.w2i['<pad>'])

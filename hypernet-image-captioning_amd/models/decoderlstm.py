@@ -61,9 +61,11 @@ class AttentionGru(nn.Module):
         B, P, D = features.shape
         if D != self.num_features:
             raise CaphnError(f"features have {D} channels, module expects {self.num_features}")
-        dims = ops.DecDims(B, captions.shape[1], P, D, self.feature_out, self.embedding_dim, self.hidden_dim,
+        return CF.attention_gru_forward(self.dec_dims(B, captions.shape[1], P), features, captions, self._named_tensors())
+
+    def dec_dims(self, B, T, P):
+        return ops.DecDims(B, T, P, self.num_features, self.feature_out, self.embedding_dim, self.hidden_dim,
                            self.vocab_size)
-        return CF.attention_gru_forward(dims, features, captions, self._named_tensors())
 
     def init_hidden(self, features):
         """models/decoderlstm.py:122-135 (features are post-feature_fc here, as in the reference)."""
@@ -76,6 +78,80 @@ class GruNet(AttentionGru):
 
     def forward(self, features, captions, sample_prob=0.0):
         return super().forward(features, captions, sample_prob)[0]
+
+
+class AttentionLstm(nn.Module):
+    """Reference AttentionLstm (models/decoderlstm.py:188-261): constructor
+    (num_features, embedding_dim, hidden_dim, vocab_size, p=0.5), sub-modules `embeddings`, `lstm`,
+    `fc`, `attention`, `drop`, `init_h`, `init_c`, forward(captions, features, sample_prob=1.0).
+    Attention runs directly over the num_features-channel features (no feature_fc).
+
+    feature_out (extension): when given, a feature_fc
+    Linear(num_features, feature_out)+ReLU+Linear(feature_out, feature_out) precedes the attention, as
+    in AttentionGru -- the configuration the hypernet-LSTM path uses (its G slab then fits the LDS)."""
+
+    def __init__(self, num_features, embedding_dim, hidden_dim, vocab_size, p=0.5, feature_out=None):
+        super().__init__()
+        self.num_features = num_features
+        self.embedding_dim = embedding_dim
+        self.hidden_dim = hidden_dim
+        self.vocab_size = vocab_size
+        self.sample_temp = 0.5
+        self.feature_out = feature_out
+        att_in = num_features
+        if feature_out is not None:
+            self.feature_fc = nn.Sequential(nn.Linear(num_features, feature_out), nn.ReLU(),
+                                            nn.Linear(feature_out, feature_out))
+            att_in = feature_out
+        self.embeddings = nn.Embedding(vocab_size, embedding_dim)
+        self.lstm = nn.LSTMCell(embedding_dim + att_in, hidden_dim)
+        self.fc = nn.Linear(hidden_dim, vocab_size)
+        self.attention = BahdanauAttention(att_in, hidden_dim)
+        self.drop = nn.Dropout(p=p)
+        self.init_h = nn.Linear(att_in, hidden_dim)
+        self.init_c = nn.Linear(att_in, hidden_dim)
+
+    @property
+    def embed(self):            # uniform access for the fused engine
+        return self.embeddings
+
+    def _named_tensors(self):
+        t = {"embed.weight": self.embeddings.weight, "fc.weight": self.fc.weight, "fc.bias": self.fc.bias,
+             "attention.W_a.weight": self.attention.W_a.weight, "attention.W_a.bias": self.attention.W_a.bias,
+             "attention.U_a.weight": self.attention.U_a.weight, "attention.U_a.bias": self.attention.U_a.bias,
+             "attention.v_a.weight": self.attention.v_a.weight, "attention.v_a.bias": self.attention.v_a.bias,
+             "init_h.weight": self.init_h.weight, "init_h.bias": self.init_h.bias,
+             "init_c.weight": self.init_c.weight, "init_c.bias": self.init_c.bias}
+        if self.feature_out is not None:
+            t.update({"feature_fc.0.weight": self.feature_fc[0].weight, "feature_fc.0.bias": self.feature_fc[0].bias,
+                      "feature_fc.2.weight": self.feature_fc[2].weight, "feature_fc.2.bias": self.feature_fc[2].bias})
+        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            t["lstm." + n] = getattr(self.lstm, n)
+        return t
+
+    def dec_dims(self, B, T, P):
+        F = self.feature_out if self.feature_out is not None else self.num_features
+        return ops.DecDims(B, T, P, self.num_features, F, self.embedding_dim, self.hidden_dim, self.vocab_size,
+                           cell="lstm", raw=self.feature_out is None)
+
+    def forward(self, captions, features, sample_prob=1.0):
+        """captions [B,T], features [B,P,num_features] -> (outputs [B,T,V], atten_weights [B,T,P]).
+        NOTE the reference's argument order and its default sample_prob=1.0 (decoderlstm.py:224)."""
+        if sample_prob != 0.0:
+            raise NotImplementedError("scheduled sampling / free running (sample_prob > 0, "
+                                      "models/decoderlstm.py:236-251) is not built yet (SURVEY.md 8f N1); "
+                                      "pass sample_prob=0.0 for teacher forcing")
+        if self.training and self.drop.p > 0:
+            raise NotImplementedError("dropout p > 0 in training mode is not supported by the fused HIP path; "
+                                      "construct with p=0.0 or call .eval()")
+        B, P, D = features.shape
+        if D != self.num_features:
+            raise CaphnError(f"features have {D} channels, module expects {self.num_features}")
+        return CF.attention_gru_forward(self.dec_dims(B, captions.shape[1], P), features, captions, self._named_tensors())
+
+    def init_hidden(self, features):
+        mean_annotations = torch.mean(features, dim=1)
+        return self.init_h(mean_annotations), self.init_c(mean_annotations)
 
 
 # names hypernet.py:11 imports from models.decoderlstm (they only exist in the import-less later.py)

@@ -109,12 +109,18 @@ int caphn_hyper_backward(const caphn_hyper_desc* d, const float* dtheta, const f
 
 /* ---------------------------------------------------------------------------------------
  * Decoder: AttentionGru.forward with teacher forcing            [models/decoderlstm.py:49-120]
+ *          AttentionLstm.forward (same loop, LSTMCell, init_c)  [models/decoderlstm.py:224-261]
  * + BahdanauAttention.forward                                   [models/attention.py:21-46]
- * + nn.GRUCell arithmetic                                       [decoderlstm.py:32,100]
+ * + nn.GRUCell / nn.LSTMCell arithmetic                         [decoderlstm.py:32,100 / :209,243]
  */
+#define CAPHN_CELL_GRU 0     /* nn.GRUCell,  gates r,z,n   (AttentionGru,  models/decoderlstm.py:32)  */
+#define CAPHN_CELL_LSTM 1    /* nn.LSTMCell, gates i,f,g,o (AttentionLstm, models/decoderlstm.py:209) */
 typedef struct caphn_decoder_dims {
     int B, T, P;        /* batch, caption length, attention positions (49) */
     int D, F, E, H, V;  /* encoder channels, feature_out, embedding_dim, hidden_dim, vocab */
+    int cell;           /* CAPHN_CELL_* ; NG = 3 (GRU) or 4 (LSTM) gate blocks of H rows */
+    int raw_features;   /* 1: no feature_fc, attention runs directly over the D-channel features
+                           (reference AttentionLstm, decoderlstm.py:242); then F must equal D */
 } caphn_decoder_dims;
 
 typedef struct caphn_decoder_params {   /* reference state_dict names in comments */
@@ -126,17 +132,19 @@ typedef struct caphn_decoder_params {   /* reference state_dict names in comment
     const float* Ua_w; const float* Ua_b;     /* captioner.attention.U_a [H,H],[H] */
     const float* va_w; const float* va_b;     /* captioner.attention.v_a [1,H],[1] */
     const float* inith_w; const float* inith_b; /* captioner.init_h      [H,F],[H] */
-    const float* w_ih; const float* w_hh;     /* gru.weight_ih [3H,E+F], gru.weight_hh [3H,H] (slices of theta) */
-    const float* b_ih; const float* b_hh;     /* gru.bias_ih [3H], gru.bias_hh [3H] */
+    const float* w_ih; const float* w_hh;     /* cell weight_ih [NG*H,E+F], weight_hh [NG*H,H] (slices of theta) */
+    const float* b_ih; const float* b_hh;     /* cell bias_ih [NG*H], bias_hh [NG*H] */
+    const float* initc_w; const float* initc_b; /* captioner.init_c    [H,F],[H]  (LSTM only, else NULL) */
 } caphn_decoder_params;
 
-typedef struct caphn_decoder_grads {    /* same shapes as the parameters; all required */
+typedef struct caphn_decoder_grads {    /* same shapes as the parameters; all required (feature_fc ones unless raw_features, init_c ones if LSTM) */
     float* fc0_w; float* fc0_b; float* fc2_w; float* fc2_b;
     float* embed_w;                     /* fully overwritten (zero + scatter-add) */
     float* out_w; float* out_b;
     float* Wa_w; float* Wa_b; float* Ua_w; float* Ua_b; float* va_w; float* va_b;
     float* inith_w; float* inith_b;
     float* w_ih; float* w_hh; float* b_ih; float* b_hh;   /* = dtheta, in theta order when contiguous */
+    float* initc_w; float* initc_b;     /* LSTM only */
 } caphn_decoder_grads;
 
 /* Saved-activation workspace shared by forward and backward (one training step). */

@@ -42,7 +42,7 @@ def dec_params_from_oracle(p, theta, dims, device):
     off = 0
     for name, shape in dims.cell_param_shapes():
         n = int(np.prod(shape))
-        out["gru." + name] = th[off:off + n].view(shape)
+        out[dims.cell + "." + name] = th[off:off + n].view(shape)
         off += n
     return out
 
@@ -56,9 +56,9 @@ def hyper_shape(dims):
     return ops.HyperShape(dims.he, [(k, w) for _, k, w in O.head_layout(dims)])
 
 
-def dec_dims(dims, B, T, P):
+def dec_dims(dims, B, T, P, raw=False):
     from caphn import ops
-    return ops.DecDims(B, T, P, dims.D, dims.F, dims.E, dims.H, dims.V)
+    return ops.DecDims(B, T, P, dims.D, dims.F, dims.E, dims.H, dims.V, cell=dims.cell, raw=raw)
 
 
 def rel_err(a, b):

@@ -149,6 +149,60 @@ def test_decoder_forward_backward_tiny(ops, name):
     assert maxdiff(l3.cpu(), g["logits_q1"]) < 2e-6
 
 
+def test_decoder_lstm_raw_features_tiny(ops):
+    """LSTM cell, attention over the raw features (no feature_fc): the reference's AttentionLstm
+    (models/decoderlstm.py:188-261) with hypernet-injected weights, golden case lstm_tiny."""
+    dims = TINY_DIMS["lstm_tiny"]
+    g, p = load_case("lstm_tiny")
+    B, T = g["captions"].shape
+    P = g["features"].shape[1]
+    dd = dec_dims(dims, B, T, P, raw=True)
+    params = dec_params_from_oracle(p, g["theta"], dims, DEV)
+    params = {n: params[n] for n in dd.names()}
+    ws = ops.decoder_workspace(dd, DEV)
+    feats, caps = g["features"].to(DEV), g["captions"].to(DEV)
+    logits, alphas = ops.decoder_forward(dd, params, feats, caps, ws)
+    assert maxdiff(logits.cpu(), g["logits"]) < 2e-6
+    assert maxdiff(alphas.cpu(), g["alphas"]) < 1e-6
+    lo, dlogits = ops.cross_entropy_fwd_bwd(logits, caps, 0)
+    assert abs(float(lo[0]) - float(g["loss"])) < 2e-6
+    grads = {n: torch.full(s, float("nan"), device=DEV) for n, s in dd.param_shapes().items()}
+    ops.decoder_backward(dd, params, feats, caps, dlogits, grads, ws)
+    for n, gt in grads.items():
+        if n.startswith("lstm."):
+            continue
+        assert maxdiff(gt.cpu(), g["glit/captioner." + n]) < 2e-6, n
+    dth = torch.cat([grads["lstm." + n].flatten() for n, _ in dims.cell_param_shapes()])
+    assert maxdiff(dth.cpu(), g["dtheta"]) < 2e-6
+
+
+@pytest.mark.parametrize("H,P", [(12, 6), (200, 49)])
+def test_decoder_lstm_with_feature_fc_vs_oracle(ops, H, P):
+    """LSTM cell behind a feature_fc (the hypernet-LSTM configuration).  At H=200, P=49 the four-gate G
+    slab exceeds the LDS, so three gate slabs stay resident and the fourth streams from L2."""
+    dims = O.Dims(D=24, F=H, E=H - 2 if H < 100 else H, H=H, V=50, he=6, cell="lstm")
+    p = O.init_params(dims, seed=5)
+    batch = O.synth_batch(dims, B=4, T=7, P=P, seed=6)
+    x = torch.zeros(dims.he); x[2] = 1.0
+    loss, logits_ref, alphas_ref, theta, gref = O.forward_backward(dims, p, x, batch["features"], batch["captions"])
+    dd = dec_dims(dims, 4, 7, P)
+    params = dec_params_from_oracle(p, theta, dims, DEV)
+    ws = ops.decoder_workspace(dd, DEV)
+    feats, caps = batch["features"].to(DEV), batch["captions"].to(DEV)
+    logits, alphas = ops.decoder_forward(dd, params, feats, caps, ws)
+    assert maxdiff(logits.cpu(), logits_ref) < 3e-6
+    assert maxdiff(alphas.cpu(), alphas_ref) < 1e-6
+    lo, dlogits = ops.cross_entropy_fwd_bwd(logits, caps, 0)
+    grads = {n: torch.full(s, float("nan"), device=DEV) for n, s in dd.param_shapes().items()}
+    ops.decoder_backward(dd, params, feats, caps, dlogits, grads, ws)
+    for n, gt in grads.items():
+        if n.startswith("lstm."):
+            continue
+        assert maxdiff(gt.cpu(), gref["captioner." + n]) < 3e-6, n
+    dth = torch.cat([grads["lstm." + n].flatten() for n, _ in dims.cell_param_shapes()])
+    assert maxdiff(dth.cpu(), gref["dtheta"]) < 3e-6
+
+
 def test_cross_entropy_matches_torch(ops):
     torch.manual_seed(1)
     rows, V = 77, 9684

@@ -190,3 +190,46 @@ def test_graph_replayed_step_matches_eager():
     assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
     assert la[-1] < la[0]
     assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 1e-4
+
+
+def test_hypernet_lstm_module_and_engine():
+    """HyperNet(cell='lstm'): hypernet generates the LSTMCell weights of an AttentionLstm behind a
+    feature_fc.  Module API gradients and one fused engine step against the oracle."""
+    from hypernet_attention import HyperNet
+    from models.decoderlstm import AttentionLstm
+    from caphn.engine import FusedTrainer
+    dims = O.Dims(D=24, F=12, E=10, H=12, V=50, he=6, cell="lstm")
+    p = O.init_params(dims, seed=15)
+    batch = O.synth_batch(dims, B=4, T=7, P=6, seed=16)
+    x = torch.zeros(dims.he); x[1] = 1.0
+    loss_ref, logits_ref, _, _, gref = O.forward_backward(dims, p, x, batch["features"], batch["captions"])
+
+    def build():
+        net = HyperNet(dims.F, dims.E, dims.H, dims.V, _Vocab(), cc=True, hyper_emb=dims.he, cell="lstm")
+        net.captioner = AttentionLstm(dims.D, dims.E, dims.H, dims.V, p=0.0, feature_out=dims.F)
+        sd = {k.replace("captioner.embed.", "captioner.embeddings."): v for k, v in p.items()}
+        res = net.load_state_dict(sd, strict=False)
+        assert all(k.startswith("captioner.lstm.") for k in res.missing_keys) and not res.unexpected_keys, res
+        return net.to(DEV)
+    net = build()
+    feats, caps = batch["features"].to(DEV), batch["captions"].to(DEV)
+    cap = net.forward(x.to(DEV))
+    logits, _ = cap(caps, feats, 0.0)                       # reference argument order (captions, features)
+    assert maxdiff(logits.detach().cpu(), logits_ref) < 3e-6
+    F.cross_entropy(logits.view(-1, dims.V), caps.view(-1), ignore_index=0).backward()
+    sd = dict(net.named_parameters())
+    for k, v in gref.items():
+        if k == "dtheta" or v is None:
+            continue
+        assert maxdiff(sd[k.replace("captioner.embed.", "captioner.embeddings.")].grad.cpu(), v) < 3e-6, k
+    with pytest.raises(NotImplementedError):
+        cap(caps, feats)                                     # the reference default sample_prob=1.0
+    tr = FusedTrainer(build(), lr=1e-3)
+    l = tr.forward_backward(feats, caps, x_style=x.to(DEV), validate=True)
+    assert abs(float(l[0]) - float(loss_ref)) < 3e-6
+    assert maxdiff(tr.flat_g[:tr.theta_size].cpu(), gref["dtheta"]) < 3e-6
+    assert maxdiff(tr.grad("captioner.init_c.weight").cpu(), gref["captioner.init_c.weight"]) < 3e-6
+    l0 = float(l[0])
+    for _ in range(5):
+        l = tr.step(feats, caps, x_style=x.to(DEV))
+    assert float(l[0]) < l0
