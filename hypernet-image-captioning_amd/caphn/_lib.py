@@ -83,6 +83,7 @@ SIGNATURES = {
     "caphn_adam_rank_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_size_t,
                                       c_fp, C.c_size_t, c_fp, C.POINTER(AdamHParams), c_fp]),
     "caphn_outer_f32": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_tune": (C.c_int, [C.c_int, C.c_int]),
 }
 
 _ERR = {-1: "CAPHN_EINVAL (bad argument)", -2: "CAPHN_ELAUNCH (HIP launch error)",

@@ -22,13 +22,12 @@ struct GemvJob {
 struct GemvJobs { GemvJob j[CAPHN_MAX_HEADS]; int n; };
 
 // ---------------------------------------------------------------- forward: y = act(W x + b)
-// wave per row, RB = 8 rows per iteration, QMAX dwordx4 per lane per row (k <= 256*QMAX): 8*QMAX
-// independent 16-byte loads in flight per lane.  The 8 row sums are reduced together: three
-// halving exchange stages (xor 32,16,8) leave one row per 8-lane group, three more finish it --
-// 10 shuffles per 8 rows instead of 48.
-template <int QMAX>
+// wave per row, RB rows per iteration, QMAX dwordx4 per lane per row (k <= 256*QMAX): RB*QMAX
+// independent 16-byte loads in flight per lane.  RB == 8 reduces the 8 row sums together (three
+// halving exchange stages then three plain ones: 10 shuffles per 8 rows); RB == 4 reduces row by row.
+// NTL: non-temporal loads.  Variants are selected by caphn_tune (measured A/B).
+template <int QMAX, int RB, bool NTL>
 __device__ __forceinline__ void gemv_rows_wave(const GemvJob& J, int wave_g, int nwaves, int lane) {
-    constexpr int RB = 8;
     const int k4 = J.k >> 2;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(J.x);
     f32x4 xr[QMAX];
@@ -37,7 +36,7 @@ __device__ __forceinline__ void gemv_rows_wave(const GemvJob& J, int wave_g, int
         int c = lane + 64 * q;
         xr[q] = c < k4 ? x4[c] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int myrow = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+    const int myrow = RB == 8 ? ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1) : lane;
     for (int r0 = wave_g * RB; r0 < J.rows; r0 += nwaves * RB) {
         f32x4 w[RB][QMAX];
 #pragma unroll
@@ -46,7 +45,8 @@ __device__ __forceinline__ void gemv_rows_wave(const GemvJob& J, int wave_g, int
 #pragma unroll
             for (int q = 0; q < QMAX; ++q) {
                 int c = lane + 64 * q;
-                w[i][q] = (r0 + i < J.rows && c < k4) ? __builtin_nontemporal_load(row + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r0 + i < J.rows && c < k4) w[i][q] = NTL ? __builtin_nontemporal_load(row + c) : row[c];
+                else w[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         float v[RB];
@@ -58,26 +58,45 @@ __device__ __forceinline__ void gemv_rows_wave(const GemvJob& J, int wave_g, int
                 s += w[i][q][0] * xr[q][0] + w[i][q][1] * xr[q][1] + w[i][q][2] * xr[q][2] + w[i][q][3] * xr[q][3];
             v[i] = s;
         }
+        float mine = 0.f;
+        if (RB == 8) {
 #pragma unroll
-        for (int st = 0; st < 3; ++st) {
-            const int mask = 32 >> st, half = RB >> (st + 1);
-            const bool hi = (lane & mask) != 0;
+            for (int st = 0; st < 3; ++st) {
+                const int mask = 32 >> st, half = RB >> (st + 1);
+                const bool hi = (lane & mask) != 0;
 #pragma unroll
-            for (int j = 0; j < half; ++j) {
-                const float send = hi ? v[j] : v[j + half];
-                const float keep = hi ? v[j + half] : v[j];
-                v[j] = keep + __shfl_xor(send, mask, 64);
+                for (int j = 0; j < half; ++j) {
+                    const float send = hi ? v[j] : v[j + half];
+                    const float keep = hi ? v[j + half] : v[j];
+                    v[j] = keep + __shfl_xor(send, mask, 64);
+                }
+            }
+            float s = v[0];
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 1, 64);
+            mine = s;
+        } else {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const float s = wave_sum(v[i]);
+                if (lane == i) mine = s;
             }
         }
-        float s = v[0];
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 1, 64);
-        if ((lane & 7) == 0 && r0 + myrow < J.rows) {
-            float o = s + (J.b ? J.b[r0 + myrow] : 0.f);
+        const bool writer = RB == 8 ? (lane & 7) == 0 : lane < RB;
+        if (writer && r0 + myrow < J.rows) {
+            float o = mine + (J.b ? J.b[r0 + myrow] : 0.f);
             J.y[r0 + myrow] = J.act ? lrelu(o) : o;
         }
     }
+}
+
+template <int RB, bool NTL>
+__device__ __forceinline__ void gemv_rows_wave_k(const GemvJob& J, int wave_g, int nwaves, int lane) {
+    if (J.k <= 256) gemv_rows_wave<1, RB, NTL>(J, wave_g, nwaves, lane);
+    else if (J.k <= 512) gemv_rows_wave<2, RB, NTL>(J, wave_g, nwaves, lane);
+    else if (J.k <= 1024) gemv_rows_wave<4, RB, NTL>(J, wave_g, nwaves, lane);
+    else gemv_rows_wave<8, RB, NTL>(J, wave_g, nwaves, lane);
 }
 
 // 8 lanes per row: any k, vector or scalar loads
@@ -106,6 +125,7 @@ __device__ __forceinline__ void gemv_rows_oct(const GemvJob& J, int lb, int tid)
     }
 }
 
+template <int RB, bool NTL>
 __global__ __launch_bounds__(256) void gemv_fwd_kernel(GemvJobs jobs) {
     int ji = 0;
     for (int i = 1; i < jobs.n; ++i) if ((int)blockIdx.x >= jobs.j[i].block0) ji = i;
@@ -113,14 +133,22 @@ __global__ __launch_bounds__(256) void gemv_fwd_kernel(GemvJobs jobs) {
     const int lb = blockIdx.x - J.block0, tid = threadIdx.x;
     if (J.vec && J.k >= 128 && J.k <= 2048) {
         const int wave_g = lb * 4 + (tid >> 6), nwaves = J.nblocks * 4, lane = tid & 63;
-        if (J.k <= 256) gemv_rows_wave<1>(J, wave_g, nwaves, lane);
-        else if (J.k <= 512) gemv_rows_wave<2>(J, wave_g, nwaves, lane);
-        else if (J.k <= 1024) gemv_rows_wave<4>(J, wave_g, nwaves, lane);
-        else gemv_rows_wave<8>(J, wave_g, nwaves, lane);
+        gemv_rows_wave_k<RB, NTL>(J, wave_g, nwaves, lane);
     } else {
         gemv_rows_oct(J, lb, tid);
     }
 }
+}  // namespace
+int g_tune_gemv = 1;      // 0: RB=4 plain loads  1: RB=4 non-temporal loads (default: 115 vs 126 us)  2/3: RB=8 (3x slower)
+static void launch_gemv_fwd(const GemvJobs& jobs, int nblocks, hipStream_t s) {
+    switch (g_tune_gemv) {
+        case 0: hipLaunchKernelGGL((gemv_fwd_kernel<4, false>), dim3(nblocks), dim3(256), 0, s, jobs); break;
+        case 2: hipLaunchKernelGGL((gemv_fwd_kernel<8, false>), dim3(nblocks), dim3(256), 0, s, jobs); break;
+        case 3: hipLaunchKernelGGL((gemv_fwd_kernel<8, true>), dim3(nblocks), dim3(256), 0, s, jobs); break;
+        default: hipLaunchKernelGGL((gemv_fwd_kernel<4, true>), dim3(nblocks), dim3(256), 0, s, jobs); break;
+    }
+}
+namespace {
 
 // ---------------------------------------------------------------- backward: y = W^T d (W [rows,k])
 // large matrices: lanes own column chunks, waves own rows; per-block partial sums -> ws, then reduce
@@ -262,7 +290,7 @@ __global__ __launch_bounds__(256) void outer_kernel(OuterJobs jobs) {
 
 inline int gemv_blocks(int rows, int k, int vec) {
     // enough waves to cover the chip; big jobs grid-stride
-    long want = (vec && k >= 128) ? ((long)rows + 31) / 32 : ((long)rows + 31) / 32;
+    long want = (vec && k >= 128) ? ((long)rows + 15) / 16 : ((long)rows + 31) / 32;
     if (want < 1) want = 1;
     if (want > 2048) want = 2048;
     return (int)want;
@@ -309,7 +337,7 @@ extern "C" int caphn_hyper_forward(const caphn_hyper_desc* d, const float* x, fl
         GemvJob& J = jobs.j[0];
         J.W = W; J.b = b; J.x = in; J.y = out; J.rows = rows; J.k = k; J.act = act;
         J.vec = vec_ok(W, in, k); J.block0 = 0; J.nblocks = gemv_blocks(rows, k, J.vec);
-        hipLaunchKernelGGL(gemv_fwd_kernel, dim3(J.nblocks), dim3(256), 0, s, jobs);
+        launch_gemv_fwd(jobs, J.nblocks, s);
     };
     one(d->base_w0, d->base_b0, acts + L.x, acts + L.a0, d->he, d->he, 1);
     one(d->base_w2, d->base_b2, acts + L.a0, acts + L.base, d->he, d->he, 1);
@@ -321,7 +349,7 @@ extern "C" int caphn_hyper_forward(const caphn_hyper_desc* d, const float* x, fl
             J.rows = d->k[i]; J.k = d->he; J.act = 1; J.vec = vec_ok(J.W, J.x, J.k);
             J.block0 = b0; J.nblocks = gemv_blocks(J.rows, J.k, J.vec); b0 += J.nblocks;
         }
-        hipLaunchKernelGGL(gemv_fwd_kernel, dim3(b0), dim3(256), 0, s, jobs);
+        launch_gemv_fwd(jobs, b0, s);
     }
     {   // second layers: theta = cat_i (W2_i a_i + b2_i)
         GemvJobs jobs; jobs.n = d->n_heads; int b0 = 0; size_t off = 0;
@@ -331,7 +359,7 @@ extern "C" int caphn_hyper_forward(const caphn_hyper_desc* d, const float* x, fl
             J.rows = d->w[i]; J.k = d->k[i]; J.act = 0; J.vec = vec_ok(J.W, J.x, J.k);
             J.block0 = b0; J.nblocks = gemv_blocks(J.rows, J.k, J.vec); b0 += J.nblocks;
         }
-        hipLaunchKernelGGL(gemv_fwd_kernel, dim3(b0), dim3(256), 0, s, jobs);
+        launch_gemv_fwd(jobs, b0, s);
     }
     return caphn_launch_status();
 }
@@ -443,4 +471,13 @@ extern "C" int caphn_outer_f32(int rows, int k, const float* gv, const float* av
     long nb = ((long)rows * k + 1023) / 1024;
     hipLaunchKernelGGL(outer_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), o2);
     return caphn_launch_status();
+}
+
+// Tuning knob for the microbenchmark (tools/microbench_stream.py); not part of the stable ABI surface
+// beyond its declaration.  key 0: forward GEMV variant, key 1: rank-Adam variant (misc.hip).
+extern int g_tune_adam;
+extern "C" int caphn_tune(int key, int value) {
+    if (key == 0) { g_tune_gemv = value; return CAPHN_OK; }
+    if (key == 1) { g_tune_adam = value; return CAPHN_OK; }
+    return CAPHN_EINVAL;
 }

@@ -217,14 +217,14 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(size_t n, float* __rest
 // W,m,v [rows,k]; grad[row][col] = coef * sum_r gfac[r][row] * afac[r][col].  One wave per row
 // (row-contiguous dwordx4 streams of W, m and v: read 12 B, write 12 B per element).
 constexpr int RMAX = 8;
-template <int QMAX>
+// RB rows per wave iteration (3*RB*QMAX independent dwordx4 loads in flight), NTL / NTS: non-temporal
+// loads / stores.  Variant chosen by caphn_tune(1, v) -- measured A/B.
+template <int QMAX, int RB, bool NTL, bool NTS>
 __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W, float* m, float* v,
                                                const float* gfac, size_t ldg, const float* afac, size_t lda,
                                                float c, const AdamK& K, int wave_g, int nwaves, int lane) {
-    constexpr int RB = 2;                 // rows per iteration: 6*QMAX independent dwordx4 loads in flight
     const int k4 = k >> 2;
-    // column factors of this lane's chunks stay in registers for every row (R == 1 fast path)
-    f32x4 a1[QMAX];
+    f32x4 a1[QMAX];            // column factors stay in registers for every row (R == 1 fast path)
 #pragma unroll
     for (int q = 0; q < QMAX; ++q) {
         const int cidx = lane + 64 * q;
@@ -239,9 +239,12 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
             for (int q = 0; q < QMAX; ++q) {
                 const int cidx = lane + 64 * q;
                 if (row0 + i < rows && cidx < k4) {
-                    pp[i][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(W + base) + cidx);
-                    mm[i][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + base) + cidx);
-                    vv[i][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + base) + cidx);
+                    const f32x4* pw = reinterpret_cast<const f32x4*>(W + base) + cidx;
+                    const f32x4* pm = reinterpret_cast<const f32x4*>(m + base) + cidx;
+                    const f32x4* pv = reinterpret_cast<const f32x4*>(v + base) + cidx;
+                    pp[i][q] = NTL ? __builtin_nontemporal_load(pw) : *pw;
+                    mm[i][q] = NTL ? __builtin_nontemporal_load(pm) : *pm;
+                    vv[i][q] = NTL ? __builtin_nontemporal_load(pv) : *pv;
                 }
             }
         }
@@ -267,14 +270,17 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
                     f32x4 po = pp[i][q], mo = mm[i][q], vo = vv[i][q];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { float me = mo[e], ve = vo[e]; po[e] = adam_elem(po[e], g[e], me, ve, K); mo[e] = me; vo[e] = ve; }
-                    __builtin_nontemporal_store(po, reinterpret_cast<f32x4*>(W + base) + cidx);
-                    __builtin_nontemporal_store(mo, reinterpret_cast<f32x4*>(m + base) + cidx);
-                    __builtin_nontemporal_store(vo, reinterpret_cast<f32x4*>(v + base) + cidx);
+                    f32x4* qw = reinterpret_cast<f32x4*>(W + base) + cidx;
+                    f32x4* qm = reinterpret_cast<f32x4*>(m + base) + cidx;
+                    f32x4* qv = reinterpret_cast<f32x4*>(v + base) + cidx;
+                    if (NTS) { __builtin_nontemporal_store(po, qw); __builtin_nontemporal_store(mo, qm); __builtin_nontemporal_store(vo, qv); }
+                    else { *qw = po; *qm = mo; *qv = vo; }
                 }
             }
         }
     }
 }
+template <int RB, bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void adam_rank_kernel(int R, int rows, int k, float* W, float* m, float* v,
                                                         const float* gfac, size_t ldg, const float* afac, size_t lda,
                                                         const float* coef, AdamK K, int vec) {
@@ -282,10 +288,10 @@ __global__ __launch_bounds__(256) void adam_rank_kernel(int R, int rows, int k, 
     if (K.dev) { K.lr_bc1 = K.dev[0]; K.sqrt_bc2 = K.dev[1]; }
     if (vec && k <= 2048) {
         const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4, lane = threadIdx.x & 63;
-        if (k <= 256) adam_rank_rows<1>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
-        else if (k <= 512) adam_rank_rows<2>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
-        else if (k <= 1024) adam_rank_rows<4>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
-        else adam_rank_rows<8>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
+        if (k <= 256) adam_rank_rows<1, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
+        else if (k <= 512) adam_rank_rows<2, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
+        else if (k <= 1024) adam_rank_rows<4, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
+        else adam_rank_rows<8, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
     } else {
         const size_t n = (size_t)rows * k, stride = (size_t)gridDim.x * 256;
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -297,6 +303,9 @@ __global__ __launch_bounds__(256) void adam_rank_kernel(int R, int rows, int k, 
     }
 }
 
+}  // namespace
+int g_tune_adam = 3;   // measured: 3 (non-temporal loads + stores) 503 us vs 0 (plain) 524 us on 240000x480
+namespace {
 inline AdamK make_adam(const caphn_adam_hparams* hp) {
     AdamK k;
     const double bc1 = 1.0 - pow((double)hp->beta1, (double)hp->step);
@@ -395,10 +404,23 @@ extern "C" int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, f
                                    const float* coef, const caphn_adam_hparams* hp, caphn_stream_t stream) {
     if (R <= 0 || R > RMAX || rows <= 0 || k <= 0 || !W || !m || !v || !gfac || !afac || !coef || !hp || hp->step < 1) return CAPHN_EINVAL;
     const int vec = (k % 4 == 0) && (lda % 4 == 0) && caphn_aligned16(W) && caphn_aligned16(m) && caphn_aligned16(v) && caphn_aligned16(afac);
-    long nb = ((long)rows + 7) / 8;
+    long nb = ((long)rows + 3) / 4;
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(adam_rank_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, make_adam(hp), vec);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const AdamK K = make_adam(hp);
+#define ADAM_RANK_LAUNCH(RB, NTL, NTS) hipLaunchKernelGGL((adam_rank_kernel<RB, NTL, NTS>), dim3((unsigned)nb), dim3(256), 0, s, \
+        R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, vec)
+    switch (g_tune_adam) {      // default 3: one row per wave iteration, non-temporal loads and stores
+        case 0: ADAM_RANK_LAUNCH(1, false, false); break;
+        case 1: ADAM_RANK_LAUNCH(1, true, false); break;
+        case 2: ADAM_RANK_LAUNCH(1, false, true); break;
+        case 4: ADAM_RANK_LAUNCH(2, false, false); break;
+        case 5: ADAM_RANK_LAUNCH(2, true, false); break;
+        case 6: ADAM_RANK_LAUNCH(2, true, true); break;
+        default: ADAM_RANK_LAUNCH(1, true, true); break;
+    }
+#undef ADAM_RANK_LAUNCH
     return caphn_launch_status();
 }
 

@@ -214,6 +214,10 @@ int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, float* v,
 /* dense outer product out[rows,k] = g[rows] (x) a[k]  (module API: torch optimisers want dW2 dense) */
 int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out, caphn_stream_t stream);
 
+/* Tuning knob used by tools/microbench_stream.py to A/B kernel variants in one process
+ * (key 0: forward-GEMV variant, key 1: rank-Adam variant).  Defaults are the measured-fastest. */
+int caphn_tune(int key, int value);
+
 #ifdef __cplusplus
 }
 #endif
