@@ -111,7 +111,12 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
-    ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying a hipGraph")
+    ap.add_argument("--tune", action="append", default=[], help="kernel-variant knob key=value (caphn_tune), for A/B runs")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a hipGraph (single GPU).  Default is host-launched kernels: the step is "
+                         "GPU-bound either way (measured 2.958 vs 2.977 ms) and host launches let the HIP events around "
+                         "the dominant kernel sit inside the timed region")
+    ap.add_argument("--eager", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +133,10 @@ def main():
 
     from hypernet_attention import HyperNet
     from caphn.engine import FusedTrainer
+    from caphn import _lib
+    for kv in args.tune:
+        k, v = kv.split("=")
+        assert _lib.load().caphn_tune(int(k), int(v)) == 0
 
     B, T, P, D, F, E, H, V = args.batch, 20, 49, 2048, 200, 200, 200, 9684
     torch.manual_seed(1234)                       # identical replicas on every rank
@@ -141,7 +150,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = (world == 1) and not args.eager
+    use_graph = (world == 1) and args.graph
     do_step = tr.step_graphed if use_graph else tr.step
     if use_graph:                                  # two passes over the batch buffers: eager, then capture
         for _ in range(2):
@@ -186,7 +195,16 @@ def main():
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[:cnt["i"]]])) if cnt["i"] else float("nan")
         k0, w0 = tr.shape.heads[0]
         kbytes = 24.0 * k0 * w0
-        achieved = kbytes / (kern_ms * 1e-3) / 1e9
+        achieved = kbytes / (kern_ms * 1e-3) / 1e9 if cnt["i"] else None
+        # HBM bytes of one launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # gfx950 corrections applied) -- collected separately, summary committed under profiles/
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_adam_rank.json")))
+            if int(pmc["algorithmic_bytes"]) == int(kbytes):
+                traffic = pmc["traffic_bytes"]
+        except Exception:  # noqa: BLE001
+            pass
         ms_step = dt / args.steps * 1e3
         line = {
             "metric": METRIC, "value": B * world * args.steps / dt, "unit": "images/s",
@@ -201,7 +219,7 @@ def main():
                        "final_loss": float(loss[0])},
             "roofline": {"bound": "hbm", "kernel": "adam_rank_kernel(hn_heads.0.2.weight)",
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
+                         "frac": (achieved / (HBM_PEAK / 1e9)) if achieved else None, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes": kbytes,
                          "step_frac": STEP_ALGO_BYTES / (ms_step * 1e-3) / HBM_PEAK if B == 128 else None},
         }
