@@ -11,11 +11,13 @@
 #include "decoder_internal.h"
 #include <algorithm>
 
+int g_tune_rec_rotate = 1;
+
 namespace {
 
 struct Ws {   // float offsets into the workspace
     size_t Y1, f, meanf, h0, c0, Waf, G, Xe, Xg, Hs, Hprev, gates, hn, Cs, Cprev, uah, alphas, idx;
-    size_t dHs, dgi, dgh, duah, de, dh0, dc0, ctx, dctx, dXe, dWaf, dmeanf, df, dY1, apart, vtmp, colws;
+    size_t dHs, dgi, dgh, duah, de, dh0, dc0, ctx, dctx, dXe, dWaf, dmeanf, df, dY1, apart, vtmp, colws, prof;
     size_t total;
     int npc, pchunk, NG;
 };
@@ -48,6 +50,7 @@ inline Ws layout(const caphn_decoder_dims* d) {
     need(B * T, V); need(B * T, NG * H); need(B * T, H); need(B * P, H); need(B * P, F); need(B, H);
     need(B * w.npc, H + 1);
     w.colws = take(cs);
+    w.prof = take(64);        // 2 x 8 uint64 phase counters (forward, backward) of the recurrent kernels
     w.total = o;
     (void)D;
     return w;
@@ -152,6 +155,8 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     a.Cs = ws + w.Cs; a.Cprev = ws + w.Cprev; a.uah = ws + w.uah;
     a.vecW = (H % 4 == 0) && caphn_aligned16(p->w_hh) && caphn_aligned16(p->Ua_w);
     a.vecS = (H % 4 == 0) && caphn_aligned16(ws);
+    a.prof = reinterpret_cast<unsigned long long*>(ws + w.prof);
+    a.rotate = g_tune_rec_rotate;
     RUN(caphn_launch_rec_fwd(a, lstm, s));
 
     // vocab projection for all (b,t) at once      decoderlstm.py:105
@@ -196,6 +201,8 @@ extern "C" int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_d
     a.dgi = dgi; a.dgh = dgh; a.duah = ws + w.duah; a.de = ws + w.de; a.dh0 = ws + w.dh0; a.dc0 = ws + w.dc0;
     a.vecW = (H % 4 == 0) && caphn_aligned16(p->w_hh) && caphn_aligned16(p->Ua_w);
     a.vecS = (H % 4 == 0) && caphn_aligned16(ws);
+    a.prof = reinterpret_cast<unsigned long long*>(ws + w.prof) + 8;
+    a.rotate = g_tune_rec_rotate;
     RUN(caphn_launch_rec_bwd(a, lstm, s));
 
     // recurrent weights: dW_hh = dgh^T Hprev, dU_a = duah^T Hprev, biases by column sums

@@ -20,7 +20,8 @@ struct RecFwdArgs {
     float* hn;                              // [B,T,H]  W_hn h + b_hn          (GRU)
     float* Cs; float* Cprev;                // [B,T,H]  c_t, c_{t-1}           (LSTM)
     float* uah;                             // [B,T,H]  U_a h + b_Ua
-    int vecW, vecS;
+    unsigned long long* prof;               // 8 counters: per-phase shader-clock sums of workgroup 0 (tuning aid)
+    int vecW, vecS, rotate;
 };
 struct RecBwdArgs {
     int B, T, P, H;
@@ -36,7 +37,8 @@ struct RecBwdArgs {
     float* de;              // [B,T,P]
     float* dh0;             // [B,H]
     float* dc0;             // [B,H] (LSTM)
-    int vecW, vecS;
+    unsigned long long* prof;
+    int vecW, vecS, rotate;
 };
 struct AttnGradArgs {
     int T, P, H, pchunk;

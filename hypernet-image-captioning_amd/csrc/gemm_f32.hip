@@ -9,20 +9,11 @@
 // identically for A and B, which a sum does not care about).  Global loads of slab t+1 are
 // issued before the MFMAs of slab t and written to LDS after them.
 #include "common.h"
+#include "gemm_internal.h"
+
+int g_tune_gemm = 1;      // 1: split-bf16 MFMA back end (default: equal-or-better accuracy, 5-18 % faster); 0: fp32 MFMA
 
 namespace {
-
-struct GemmArgs {
-    int M, N, K;
-    const float* A; int lda;
-    const float* B; int ldb;
-    float* C; int ldc;
-    const float* bias;
-    const float* mask; int ldmask;
-    int flags;
-    int splitk, slabs_per_split;
-    int vecA, vecB;
-};
 
 // BK = K-slab depth: 32, or 40 when K is a multiple of 40 but not of 32 (K = 200: 5 exact slabs
 // instead of 6.25).  K-contiguous LDS rows are padded to BK+4 floats (144 B / 176 B pitch: odd
@@ -201,10 +192,19 @@ extern "C" int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return CAPHN_EINVAL;
     if ((flags & CAPHN_GEMM_BIAS) && !bias) return CAPHN_EINVAL;
     if ((flags & CAPHN_GEMM_MASK) && !mask) return CAPHN_EINVAL;
-    if (splitk > 1 && (flags & ~CAPHN_GEMM_BIAS)) return CAPHN_EINVAL;
+    if (splitk > 1 && (flags & 0xFFFF & ~CAPHN_GEMM_BIAS)) return CAPHN_EINVAL;
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.mask = mask; g.ldmask = ldmask; g.flags = flags;
+    if (g_tune_gemm == 1) {          // split-bf16 back end: three bf16 planes per operand, 6 MFMAs per K=16
+        const int nslab = (K + 31) / 32;
+        if (splitk > nslab) splitk = nslab;
+        g.splitk = splitk > 1 ? splitk : 1;
+        g.slabs_per_split = (nslab + g.splitk - 1) / g.splitk;
+        g.vecA = caphn_aligned16(A) && (lda % 4 == 0);
+        g.vecB = caphn_aligned16(B) && (ldb % 4 == 0);
+        return caphn_gemm_bf16x3_launch(g, ta, tb, static_cast<hipStream_t>(stream));
+    }
     const int BK = (K % 40 == 0 && K % 32 != 0) ? 40 : 32;
     const int nslab = (K + BK - 1) / BK;
     if (splitk > nslab) splitk = nslab;

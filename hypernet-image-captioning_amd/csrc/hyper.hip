@@ -474,10 +474,15 @@ extern "C" int caphn_outer_f32(int rows, int k, const float* gv, const float* av
 }
 
 // Tuning knob for the microbenchmark (tools/microbench_stream.py); not part of the stable ABI surface
-// beyond its declaration.  key 0: forward GEMV variant, key 1: rank-Adam variant (misc.hip).
+// beyond its declaration.  key 0: forward GEMV variant, key 1: rank-Adam variant (misc.hip),
+// key 2: GEMM back end (0 fp32 MFMA, 1 split-bf16 MFMA).
 extern int g_tune_adam;
+extern int g_tune_gemm;
+extern int g_tune_rec_rotate;
 extern "C" int caphn_tune(int key, int value) {
     if (key == 0) { g_tune_gemv = value; return CAPHN_OK; }
     if (key == 1) { g_tune_adam = value; return CAPHN_OK; }
+    if (key == 2) { g_tune_gemm = value; return CAPHN_OK; }
+    if (key == 3) { g_tune_rec_rotate = value; return CAPHN_OK; }
     return CAPHN_EINVAL;
 }

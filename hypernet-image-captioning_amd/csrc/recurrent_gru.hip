@@ -18,7 +18,9 @@
 
 namespace {
 
-constexpr int NT = 1024;            // 16 waves per workgroup: one workgroup per CU (LDS-bound), 4 waves per SIMD
+constexpr int NT = 1024;
+// phase stamp (workgroup 0, thread 0): adds the shader clocks since the previous stamp to counter i
+#define PSTAMP(i) do { if (prof_on) { unsigned long long _n = clock64(); pc[i] += _n - plast; plast = _n; } } while (0)            // 16 waves per workgroup: one workgroup per CU (LDS-bound), 4 waves per SIMD
 
 __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n, int vec, int tid) {
     if (vec) {
@@ -31,10 +33,14 @@ __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict_
 }
 
 // y[row] = dot(W[row,:], x_s) + bias[row] for `rows` rows; 8 lanes per row, result to out_s
+// `rot` rotates the row order per workgroup: all workgroups stream the same L2-resident weights, and in
+// lockstep they would hammer the same L2 channels at the same instant.
 __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const float* __restrict__ bias,
-                                            const float* x_s, float* out_s, int rows, int K, int vec, int tid) {
+                                            const float* x_s, float* out_s, int rows, int K, int vec, int tid, int rot) {
     const int grp = tid >> 3, s = tid & 7;
-    for (int r = grp; r < rows; r += NT / 8) {
+    for (int r0 = grp; r0 < rows; r0 += NT / 8) {
+        int r = r0 + rot;
+        if (r >= rows) r -= rows;
         const float* row = W + (size_t)r * K;
         float sum = 0.f;
         if (vec) {
@@ -105,14 +111,19 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
     const float bva = a.b_va[0];
     const float* Waf_b = a.Waf + (size_t)b * P * H;
     const KG m = kg_map(tid, H);
+    const int rotU = a.rotate ? (int)(((unsigned)b * 13u) % (unsigned)H) : 0;
+    const int rotW = a.rotate ? (int)(((unsigned)b * 37u) % (unsigned)GH) : 0;
     __syncthreads();
+    const bool prof_on = (b == 0 && tid == 0 && a.prof != nullptr);
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = prof_on ? clock64() : 0;
 
     for (int t = 0; t < T; ++t) {
         const size_t bt = (size_t)b * T + t;
         // A: U_a h + b_Ua -> uah_s ; W_hh h + b_hh -> gh_s   (W_hh, U_a streamed from L2)
-        matvec_rows(a.U_a, a.b_Ua, h_s, uah_s, H, H, a.vecW, tid);
-        matvec_rows(a.W_hh, a.b_hh, h_s, gh_s, GH, H, a.vecW, tid);
+        matvec_rows(a.U_a, a.b_Ua, h_s, uah_s, H, H, a.vecW, tid, rotU);
+        matvec_rows(a.W_hh, a.b_hh, h_s, gh_s, GH, H, a.vecW, tid, rotW);
         __syncthreads();
+        PSTAMP(0);
         // B: e_p = v_a . tanh(Waf_p + uah) + b_va   (one wave per position, shuffle reduction)
         for (int p = wave; p < P; p += NT / 64) {
             float s = 0.f;
@@ -121,6 +132,7 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
             if (lane == 0) e_s[p] = s + bva;
         }
         __syncthreads();
+        PSTAMP(1);
         // C: softmax over P (one wave)
         if (wave == 0) {
             float mx = -INFINITY;
@@ -133,6 +145,7 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
             for (int p = lane; p < P; p += 64) { float al = e_s[p] * inv; e_s[p] = al; a.alphas[bt * P + p] = al; }
         }
         __syncthreads();
+        PSTAMP(2);
         // D1: partial gi_ctx = sum_{p = g mod ng} alpha_p G_p over thread groups
         if (m.g >= 0) {
             for (int k = m.k; k < H; k += (m.ng == 1 ? NT : H)) {
@@ -150,6 +163,7 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
             }
         }
         __syncthreads();
+        PSTAMP(3);
         // D2: gates and h'
         for (int k = tid; k < H; k += NT) {
             float pre[NG];
@@ -189,7 +203,9 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
             h_s[k] = hnew;                  // only this thread reads h_s[k] in D2
         }
         __syncthreads();
+        PSTAMP(4);
     }
+    if (prof_on) for (int i = 0; i < 8; ++i) a.prof[i] = pc[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -198,8 +214,10 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
 // batched MFMA GEMMs afterwards.
 template <int CH>   // CH = 4: dwordx4 column chunks, CH = 1: scalar columns (H % 4 != 0)
 __device__ __forceinline__ void matvec_t_accum(const float* __restrict__ W, const float* d_s, int rows, int H,
-                                               int chunk, int slice, int nslices, float (&acc)[CH]) {
-    for (int j = slice; j < rows; j += nslices) {
+                                               int chunk, int slice, int nslices, float (&acc)[CH], int rot) {
+    for (int j0 = slice; j0 < rows; j0 += nslices) {
+        int j = j0 + rot;
+        if (j >= rows) j -= rows;
         const float dj = d_s[j];
         const float* row = W + (size_t)j * H + chunk * CH;
         if (CH == 4) {
@@ -240,7 +258,11 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
     const int nch_eff = min(nch, NT);
     const int nslices = NT / nch_eff;
     const KG m = kg_map(tid, H);
+    const int rotU = a.rotate ? (int)(((unsigned)b * 13u) % (unsigned)H) : 0;
+    const int rotW = a.rotate ? (int)(((unsigned)b * 37u) % (unsigned)GH) : 0;
     __syncthreads();
+    const bool prof_on = (b == 0 && tid == 0 && a.prof != nullptr);
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = prof_on ? clock64() : 0;
 
     for (int t = T - 1; t >= 0; --t) {
         const size_t bt = (size_t)b * T + t;
@@ -282,6 +304,7 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
             }
         }
         __syncthreads();
+        PSTAMP(0);
         // d alpha_p = G_p . dgi  (+ external gradient on the returned attention weights)
         for (int p = wave; p < P; p += NT / 64) {
             float s = 0.f;
@@ -291,6 +314,7 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
             if (lane == 0) dal_s[p] = s + (a.dalphas ? a.dalphas[bt * P + p] : 0.f);
         }
         __syncthreads();
+        PSTAMP(1);
         // softmax backward: de_p = alpha_p (dalpha_p - sum_q alpha_q dalpha_q)
         if (wave == 0) {
             float dot = 0.f;
@@ -303,6 +327,7 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
             }
         }
         __syncthreads();
+        PSTAMP(2);
         // d(U_a h)[k] = v_k sum_p de_p (1 - tanh^2(Waf_pk + uah_k)); p split over thread groups
         if (m.g >= 0) {
             for (int k = m.k; k < H; k += (m.ng == 1 ? NT : H)) {
@@ -316,6 +341,7 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
             }
         }
         __syncthreads();
+        PSTAMP(3);
         for (int k = tid; k < H; k += NT) {
             float s = 0.f;
             for (int g = 0; g < m.ng; ++g) s += part_s[g * H + k];
@@ -324,6 +350,7 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
             a.duah[bt * H + k] = du;
         }
         __syncthreads();
+        PSTAMP(4);
         // dh_{t-1} += W_hh^T dgh + U_a^T duah
         {
             const int chunk = tid % nch_eff, slice = tid / nch_eff;
@@ -331,26 +358,29 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
                 for (int c = chunk; c < nch; c += nch_eff) {
                     if (CH == 4) {
                         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                        matvec_t_accum<4>(a.W_hh, dgh_s, GH, H, c, slice, nslices, acc);
-                        matvec_t_accum<4>(a.U_a, duah_s, H, H, c, slice, nslices, acc);
+                        matvec_t_accum<4>(a.W_hh, dgh_s, GH, H, c, slice, nslices, acc, rotW);
+                        matvec_t_accum<4>(a.U_a, duah_s, H, H, c, slice, nslices, acc, rotU);
                         *reinterpret_cast<f32x4*>(part_s + slice * H + c * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
                     } else {
                         float acc[1] = {0.f};
-                        matvec_t_accum<1>(a.W_hh, dgh_s, GH, H, c, slice, nslices, acc);
-                        matvec_t_accum<1>(a.U_a, duah_s, H, H, c, slice, nslices, acc);
+                        matvec_t_accum<1>(a.W_hh, dgh_s, GH, H, c, slice, nslices, acc, rotW);
+                        matvec_t_accum<1>(a.U_a, duah_s, H, H, c, slice, nslices, acc, rotU);
                         part_s[slice * H + c] = acc[0];
                     }
                 }
             }
         }
         __syncthreads();
+        PSTAMP(5);
         for (int k = tid; k < H; k += NT) {
             float s = dh_s[k];
             for (int sl = 0; sl < nslices; ++sl) s += part_s[sl * H + k];
             dh_s[k] = s;
         }
         __syncthreads();
+        PSTAMP(6);
     }
+    if (prof_on) for (int i = 0; i < 8; ++i) a.prof[i] = pc[i];
     for (int k = tid; k < H; k += NT) {
         a.dh0[(size_t)b * H + k] = dh_s[k];
         if (LSTM) a.dc0[(size_t)b * H + k] = dc_s[k];

@@ -215,7 +215,8 @@ int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, float* v,
 int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out, caphn_stream_t stream);
 
 /* Tuning knob used by tools/microbench_stream.py to A/B kernel variants in one process
- * (key 0: forward-GEMV variant, key 1: rank-Adam variant).  Defaults are the measured-fastest. */
+ * (key 0: forward-GEMV variant, key 1: rank-Adam variant, key 2: GEMM back end -- 0 fp32 MFMA,
+ * 1 split-bf16 MFMA).  Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
 #ifdef __cplusplus

@@ -21,9 +21,19 @@ def ops():
     return _ops
 
 
+@pytest.fixture(params=[1, 0], ids=["split_bf16", "fp32_mfma"])
+def gemm_backend(request):
+    """Both GEMM back ends must meet the same fp32 tolerances (1 = default split-bf16, 0 = fp32 MFMA)."""
+    from caphn import _lib
+    lib = _lib.load()
+    assert lib.caphn_tune(2, request.param) == 0
+    yield request.param
+    lib.caphn_tune(2, 1)
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(64, 64, 32), (37, 83, 19), (130, 200, 200), (2560, 200, 333), (300, 1000, 64)])
-def test_gemm_layouts(ops, ta, tb, M, N, K):
+def test_gemm_layouts(ops, gemm_backend, ta, tb, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
     A = torch.randn((K, M) if ta else (M, K), generator=g)
     B = torch.randn((N, K) if tb else (K, N), generator=g)
@@ -45,7 +55,7 @@ def test_gemm_layouts(ops, ta, tb, M, N, K):
 
 
 @pytest.mark.parametrize("K", [96, 200])
-def test_gemm_large_tile_config(ops, K):
+def test_gemm_large_tile_config(ops, gemm_backend, K):
     """>= 1024 128x128 tiles selects the 128x128 kernel (BK = 32 for K = 96, BK = 40 for K = 200)."""
     g = torch.Generator().manual_seed(K)
     A, B = torch.randn(4096, K, generator=g), torch.randn(4000, K, generator=g)
@@ -53,6 +63,27 @@ def test_gemm_large_tile_config(ops, K):
     out = ops.gemm(A.to(DEV), B.to(DEV), False, True, bias=bias.to(DEV))
     ref = (A.to(DEV).double() @ B.to(DEV).double().t() + bias.to(DEV).double())
     assert float((out.double() - ref).abs().max()) < 2e-6 * math.sqrt(K) * 4
+
+
+def test_gemm_split_bf16_is_fp32_accurate(ops):
+    """The split-bf16 back end keeps fp32-class accuracy on data with a wide dynamic range
+    (per-element magnitudes from 1e-9 to 1e3), where a plain bf16 GEMM would be off by 1e-2 relative."""
+    from caphn import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(300, 777, generator=g) * torch.pow(10.0, torch.randint(-9, 4, (300, 777), generator=g).float())
+    B = torch.randn(260, 777, generator=g) * torch.pow(10.0, torch.randint(-6, 2, (260, 777), generator=g).float())
+    ref = A.double() @ B.double().t()
+    scale = (A.double().abs() @ B.double().abs().t())          # sum_k |a||b|: the natural error scale
+    errs = {}
+    for mode in (0, 1):
+        lib.caphn_tune(2, mode)
+        out = ops.gemm(A.to(DEV), B.to(DEV), False, True)
+        errs[mode] = float(((out.cpu().double() - ref).abs() / scale).max())
+    lib.caphn_tune(2, 1)
+    # fp32 accumulation over K = 777 widely scaled terms: ~1e-6 of sum |a||b| for BOTH back ends (a plain
+    # bf16 GEMM would sit at ~4e-3); the split must not be worse than the fp32 MFMA
+    assert errs[0] < 3e-6 and errs[1] < 1.25 * errs[0] + 1e-7, errs
 
 
 def test_gemm_strided_views(ops):

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Accuracy (vs fp64) and time of the two GEMM back ends on the step's real shapes."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "hypernet-image-captioning_amd"))
+from caphn import _lib, ops  # noqa: E402
+
+SHAPES = [  # name, ta, tb, M, N, K, splitk
+    ("fc0 fwd", 0, 1, 6272, 200, 2048, 1), ("logits fwd", 0, 1, 2560, 9684, 200, 1),
+    ("dW_fc", 1, 0, 9684, 200, 2560, 2), ("dHs", 0, 0, 2560, 200, 9684, 7), ("dW_fc0", 1, 0, 200, 2048, 6272, 8),
+    ("G", 0, 1, 6272, 600, 200, 1), ("Xg", 0, 1, 2560, 600, 200, 1), ("dW_hh", 1, 0, 600, 200, 2560, 10),
+    ("dY1", 0, 0, 6272, 200, 200, 1),
+]
+
+
+def main():
+    lib = _lib.load()
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    for name, ta, tb, M, N, K, sk in SHAPES:
+        A = torch.randn((K, M) if ta else (M, K), generator=g, device=dev)
+        B = torch.randn((N, K) if tb else (K, N), generator=g, device=dev) * 0.07
+        ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+        out = torch.zeros(M, N, device=dev)
+        line = f"{name:11s} M={M:5d} N={N:5d} K={K:5d}"
+        for mode in (0, 1):
+            lib.caphn_tune(2, mode)
+            ts = []
+            for _ in range(6):
+                if sk > 1:
+                    out.zero_()
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); ops.gemm(A, B, bool(ta), bool(tb), out=out, splitk=sk); e.record()
+                torch.cuda.synchronize()
+                ts.append(s.elapsed_time(e))
+            err = float((out.double() - ref).abs().max())
+            rel = err / float(ref.abs().max())
+            t = float(np.median(ts[1:])) * 1e3
+            line += f" | {'f32' if mode == 0 else 'bf16x3'}: {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF err {err:.2e} (rel {rel:.1e})"
+        print(line)
+    lib.caphn_tune(2, 0)
+
+
+if __name__ == "__main__":
+    main()
