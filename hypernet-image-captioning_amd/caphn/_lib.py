@@ -68,6 +68,8 @@ SIGNATURES = {
     "caphn_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDims)]),
     "caphn_decoder_forward": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
                                         c_fp, c_fp, c_fp, c_fp]),
+    "caphn_decoder_forward_sampled": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
+                                                C.c_char_p, c_fp, c_fp, c_fp, c_fp]),
     "caphn_decoder_backward": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
                                          c_fp, c_fp, C.POINTER(DecoderGrads), c_fp, c_fp]),
     "caphn_ce_workspace_bytes": (C.c_size_t, [C.c_int]),

@@ -264,6 +264,29 @@ def decoder_forward(dims: DecDims, params: Dict[str, torch.Tensor], features: to
     return logits, alphas
 
 
+def decoder_forward_sampled(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor,
+                            captions: torch.Tensor, use_sampling: Sequence[bool], ws: torch.Tensor):
+    """Free-running / scheduled-sampling forward (models/decoderlstm.py:78-96, :236-251); forward only.
+    use_sampling[t] is the per-step draw ``np.random.random() < sample_prob`` (entry 0 ignored)."""
+    lib = L.load()
+    if tuple(features.shape) != (dims.B, dims.P, dims.D) or tuple(captions.shape) != (dims.B, dims.T):
+        raise L.CaphnError(f"features {tuple(features.shape)} / captions {tuple(captions.shape)} do not match {dims}")
+    if len(use_sampling) != dims.T:
+        raise L.CaphnError("use_sampling needs one flag per timestep")
+    if bool((captions < 0).any()) or bool((captions >= dims.V).any()):
+        raise IndexError("caption token id out of range")
+    cd = dims.c()
+    ps = _dec_struct(L.DecoderParams, dims, params)
+    dev = features.device
+    logits = _f32(dims.B, dims.T, dims.V, device=dev)
+    alphas = _f32(dims.B, dims.T, dims.P, device=dev)
+    flags = bytes(1 if bool(x) else 0 for x in use_sampling)
+    L.check(lib.caphn_decoder_forward_sampled(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64),
+                                              flags, L.ptr(logits), L.ptr(alphas), C.c_void_p(ws.data_ptr()),
+                                              L.stream_ptr()), "caphn_decoder_forward_sampled")
+    return logits, alphas
+
+
 def decoder_backward(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,
                      dlogits: torch.Tensor, grads: Dict[str, torch.Tensor], ws: torch.Tensor,
                      dalphas: Optional[torch.Tensor] = None) -> None:

@@ -12,6 +12,7 @@
 #include <algorithm>
 
 int g_tune_rec_rotate = 1;
+#define RUN(x) do { int _rc = (x); if (_rc != CAPHN_OK) return _rc; } while (0)
 
 namespace {
 
@@ -85,7 +86,6 @@ inline int pick_splitk(int M, int N, int K) {
     return (int)s;
 }
 
-#define RUN(x) do { int _rc = (x); if (_rc != CAPHN_OK) return _rc; } while (0)
 
 // C = A^T-or-not . B with optional split-K (zero-fills C first when splitting)
 inline int gemm_auto(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -100,6 +100,59 @@ inline int gemm_auto(int ta, int tb, int M, int N, int K, const float* A, int ld
         return caphn_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, 0, flags, sk, s);
     }
     return caphn_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, 0, flags, 1, s);
+}
+
+// feature_fc, init_hidden (+ init_c), W_a f, G = f W_ih[:,E:]^T  -- everything that does not depend on the captions
+static int decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_params* p, const Ws& w, float* ws,
+                              const float* features, const float** f_out, hipStream_t s) {
+    const int B = d->B, P = d->P, D = d->D, F = d->F, E = d->E, H = d->H;
+    const bool lstm = d->cell == CAPHN_CELL_LSTM, raw = d->raw_features != 0;
+    const int BP = B * P, GH = w.NG * H, EF = E + F;
+    const float* f = features;
+    if (!raw) {
+        // feature_fc: Linear(D,F) + ReLU + Linear(F,F)      decoderlstm.py:22-26,61
+        RUN(caphn_gemm_f32(0, 1, BP, F, D, features, D, p->fc0_w, D, ws + w.Y1, F, p->fc0_b, nullptr, 0,
+                           CAPHN_GEMM_BIAS | CAPHN_GEMM_RELU, 1, s));
+        RUN(caphn_gemm_f32(0, 1, BP, F, F, ws + w.Y1, F, p->fc2_w, F, ws + w.f, F, p->fc2_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+        f = ws + w.f;
+    }
+    // init_hidden: mean over positions -> Linear(F,H) (and init_c for the LSTM)      :122-135 / :255-260
+    RUN(caphn_launch_mean_p(B, P, F, f, ws + w.meanf, s));
+    RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->inith_w, F, ws + w.h0, H, p->inith_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    if (lstm)
+        RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->initc_w, F, ws + w.c0, H, p->initc_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    // t-invariant attention projection W_a f + b      attention.py:34
+    RUN(caphn_gemm_f32(0, 1, BP, H, F, f, F, p->Wa_w, F, ws + w.Waf, H, p->Wa_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    // G = f W_ih[:, E:]^T  (context side of the gate pre-activations, hoisted)
+    RUN(caphn_gemm_f32(0, 1, BP, GH, F, f, F, p->w_ih + E, EF, ws + w.G, GH, nullptr, nullptr, 0, 0, 1, s));
+    *f_out = f;
+    return CAPHN_OK;
+}
+
+// next-step input token of the free-running decode: mode 0 -> -1 (zero vector), 1 -> captions[b, col],
+// 2 -> argmax_v logits[b, col, v] (lowest index on ties)
+__global__ __launch_bounds__(256) void next_token_kernel(int B, int T, int V, int mode, int col,
+                                                         const int64_t* __restrict__ caps, const float* __restrict__ logits,
+                                                         int64_t* __restrict__ idx) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (mode == 0) { if (tid == 0) idx[b] = -1; return; }
+    if (mode == 1) { if (tid == 0) idx[b] = caps[(size_t)b * T + col]; return; }
+    const float* row = logits + ((size_t)b * T + col) * V;
+    float best = -INFINITY; int besti = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) { const float x = row[v]; if (x > best) { best = x; besti = v; } }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ob = __shfl_xor(best, m, 64); const int oi = __shfl_xor(besti, m, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 4; ++i) if (bv[i] > best || (bv[i] == best && bi[i] < besti)) { best = bv[i]; besti = bi[i]; }
+        idx[b] = besti;
+    }
 }
 
 }  // namespace
@@ -124,23 +177,8 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     if (lstm && (!p->initc_w || !p->initc_b)) return CAPHN_EINVAL;
     if (!raw && (!p->fc0_w || !p->fc0_b || !p->fc2_w || !p->fc2_b)) return CAPHN_EINVAL;
 
-    const float* f = features;
-    if (!raw) {
-        // feature_fc: Linear(D,F) + ReLU + Linear(F,F)      decoderlstm.py:22-26,61
-        RUN(caphn_gemm_f32(0, 1, BP, F, D, features, D, p->fc0_w, D, ws + w.Y1, F, p->fc0_b, nullptr, 0,
-                           CAPHN_GEMM_BIAS | CAPHN_GEMM_RELU, 1, s));
-        RUN(caphn_gemm_f32(0, 1, BP, F, F, ws + w.Y1, F, p->fc2_w, F, ws + w.f, F, p->fc2_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
-        f = ws + w.f;
-    }
-    // init_hidden: mean over positions -> Linear(F,H) (and init_c for the LSTM)      :122-135 / :255-260
-    RUN(caphn_launch_mean_p(B, P, F, f, ws + w.meanf, s));
-    RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->inith_w, F, ws + w.h0, H, p->inith_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
-    if (lstm)
-        RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->initc_w, F, ws + w.c0, H, p->initc_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
-    // t-invariant attention projection W_a f + b      attention.py:34
-    RUN(caphn_gemm_f32(0, 1, BP, H, F, f, F, p->Wa_w, F, ws + w.Waf, H, p->Wa_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
-    // G = f W_ih[:, E:]^T  (context side of the gate pre-activations, hoisted)
-    RUN(caphn_gemm_f32(0, 1, BP, GH, F, f, F, p->w_ih + E, EF, ws + w.G, GH, nullptr, nullptr, 0, 0, 1, s));
+    const float* f = nullptr;
+    RUN(decoder_precompute(d, p, w, ws, features, &f, s));
     // embedding lookup with the reference's zeroed first two inputs, then the x side of the gates
     int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
     hipLaunchKernelGGL(build_idx_kernel, dim3((BT + 255) / 256), dim3(256), 0, s, B, T, captions, idx);
@@ -255,5 +293,64 @@ extern "C" int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_d
         RUN(caphn_colsum_f32(BP, F, ws + w.dY1, F, g->fc0_b, cws, s));
     }
     (void)captions;
+    return caphn_launch_status();
+}
+
+// Free-running / scheduled-sampling forward (no backward state kept: validation and inference).
+//   GRU  (AttentionGru.forward, decoderlstm.py:78-96):  x_t = 0 for t = 0 (and t = 1 when not sampling: the zeroed
+//        view), teacher embed[caps[:,t-1]] when step t does not sample, embed[argmax logits_{t-1}] when it does.
+//   LSTM (AttentionLstm.forward, :236-251): the sampled embedding is produced AFTER fc at a sampling step and only
+//        consumed by a later sampling step, so a sampling step t reuses whatever word_embed the previous
+//        iteration left behind.
+// use_sampling: HOST array of T flags (the per-step draws np.random.random() < sample_prob; entry 0 is ignored).
+extern "C" int caphn_decoder_forward_sampled(const caphn_decoder_dims* d, const caphn_decoder_params* p,
+                                             const float* features, const int64_t* captions,
+                                             const unsigned char* use_sampling,
+                                             float* logits, float* alphas, void* ws_, caphn_stream_t stream) {
+    if (!dims_ok(d) || !p || !features || !captions || !use_sampling || !logits || !ws_) return CAPHN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = layout(d);
+    float* ws = static_cast<float*>(ws_);
+    const int B = d->B, T = d->T, P = d->P, E = d->E, F = d->F, H = d->H, V = d->V;
+    const bool lstm = d->cell == CAPHN_CELL_LSTM;
+    const int GH = w.NG * H, EF = E + F;
+    const int RG = caphn_rec_resident_gates(P, H, w.NG);
+    if (RG < 0) return CAPHN_ELIMIT;
+    if (lstm && (!p->initc_w || !p->initc_b)) return CAPHN_EINVAL;
+    const float* f = nullptr;
+    RUN(decoder_precompute(d, p, w, ws, features, &f, s));
+    int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
+    // source of word_embed: 0 zero, 1 teacher column `col`, 2 sampled from logits column `col`
+    int src_mode = 0, src_col = 0;
+    for (int t = 0; t < T; ++t) {
+        const bool samp = t > 0 && use_sampling[t] != 0;
+        if (!samp) {
+            // t == 0: zeroed view of embed[:,0,:]; t == 1 reads that same zeroed view (decoderlstm.py:82-88)
+            if (t < 2) { src_mode = 0; } else { src_mode = 1; src_col = t - 1; }
+        } else if (!lstm) {
+            src_mode = 2; src_col = t - 1;              // GRU: argmax of the previous output, taken now
+        }                                               // LSTM: keep what the previous iteration left
+        hipLaunchKernelGGL(next_token_kernel, dim3(B), dim3(256), 0, s, B, T, V, src_mode, src_col, captions, logits, idx);
+        RUN(caphn_embedding_gather(B, E, p->embed_w, idx, ws + w.Xe, s));
+        RUN(caphn_gemm_f32(0, 1, B, GH, E, ws + w.Xe, E, p->w_ih, EF, ws + w.Xg, GH, p->b_ih, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+        RecFwdArgs a;
+        a.B = B; a.T = 1; a.P = P; a.H = H; a.RG = RG;
+        a.Waf = ws + w.Waf; a.G = ws + w.G; a.Xg = ws + w.Xg;
+        a.h0 = t == 0 ? ws + w.h0 : ws + w.Hs + (size_t)(t - 1) * B * H;
+        a.c0 = lstm ? (t == 0 ? ws + w.c0 : ws + w.Cs + (size_t)(t - 1) * B * H) : nullptr;
+        a.W_hh = p->w_hh; a.b_hh = p->b_hh; a.U_a = p->Ua_w; a.b_Ua = p->Ua_b; a.v_a = p->va_w; a.b_va = p->va_b;
+        a.Hs = ws + w.Hs + (size_t)t * B * H; a.Hprev = ws + w.Hprev; a.alphas = ws + w.alphas;
+        a.gates = ws + w.gates; a.hn = ws + w.hn; a.Cs = ws + w.Cs + (size_t)t * B * H; a.Cprev = ws + w.Cprev; a.uah = ws + w.uah;
+        a.prof = nullptr; a.rotate = 0;
+        a.vecW = (H % 4 == 0) && caphn_aligned16(p->w_hh) && caphn_aligned16(p->Ua_w);
+        a.vecS = (H % 4 == 0) && caphn_aligned16(ws);
+        RUN(caphn_launch_rec_fwd(a, lstm, s));
+        // logits[:, t, :] = h_t W_fc^T + b   (leading dimension T*V)
+        RUN(caphn_gemm_f32(0, 1, B, V, H, a.Hs, H, p->out_w, H, logits + (size_t)t * V, T * V, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+        if (alphas)
+            if (hipMemcpy2DAsync(alphas + (size_t)t * P, sizeof(float) * (size_t)T * P, ws + w.alphas, sizeof(float) * P,
+                                 sizeof(float) * P, B, hipMemcpyDeviceToDevice, s) != hipSuccess) return CAPHN_ELAUNCH;
+        if (samp && lstm) { src_mode = 2; src_col = t; }    // :247-251: sampled embedding of THIS output, used later
+    }
     return caphn_launch_status();
 }

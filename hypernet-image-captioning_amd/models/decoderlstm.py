@@ -3,6 +3,7 @@ and return types (models/decoderlstm.py:11-185).  Sub-modules stay ordinary nn.M
 ordinary nn.Parameters in the reference's layout, so callers can call, swap and checkpoint them
 (hypernet_attention.py:251-272, :419-428); the teacher-forced forward reads their storage and
 runs entirely in libcaphn's HIP kernels."""
+import numpy as np
 import torch
 from torch import nn
 
@@ -10,6 +11,23 @@ from caphn import functional as CF
 from caphn import ops
 from caphn._lib import CaphnError
 from .attention import BahdanauAttention
+
+
+def _sampled_forward(module, dims, features, captions, sample_prob):
+    """Scheduled sampling / free running (models/decoderlstm.py:78-96, :236-251).  The per-timestep
+    draws consume numpy's global RNG exactly like the reference: one np.random.random() per step, compared
+    with 0.0 at t = 0 and with sample_prob afterwards.  Forward only (validation / inference)."""
+    flags = [bool(np.random.random() < (0.0 if t == 0 else sample_prob)) for t in range(dims.T)]
+    if not features.is_cuda:
+        raise CaphnError("libcaphn's HIP kernels need CUDA(HIP) tensors (there is no CPU fallback)")
+    named = module._named_tensors()
+    if torch.is_grad_enabled() and any(t.requires_grad for t in named.values()):
+        raise NotImplementedError("the free-running / scheduled-sampling path is forward only: call it under "
+                                  "torch.no_grad() (validation_step does, cc_train_hypernet.py:187-188)")
+    params = {n: named[n].detach().contiguous().float() for n in dims.names()}
+    ws = ops.decoder_workspace(dims, features.device)
+    return ops.decoder_forward_sampled(dims, params, features.detach().float().contiguous(),
+                                       captions.long().contiguous(), flags, ws)
 
 
 class AttentionGru(nn.Module):
@@ -50,9 +68,6 @@ class AttentionGru(nn.Module):
 
     def forward(self, features, captions, sample_prob=0.0):
         """features [B,P,num_features], captions [B,T] -> (outputs [B,T,V], atten_weights [B,T,P])."""
-        if sample_prob != 0.0:
-            raise NotImplementedError("scheduled sampling / free running (sample_prob > 0, "
-                                      "models/decoderlstm.py:89-96) is not built yet (SURVEY.md 8f N1)")
         if self.layers:
             raise NotImplementedError("num_layers > 1 is not supported by the fused HIP path")
         if self.training and self.drop.p > 0:
@@ -61,7 +76,10 @@ class AttentionGru(nn.Module):
         B, P, D = features.shape
         if D != self.num_features:
             raise CaphnError(f"features have {D} channels, module expects {self.num_features}")
-        return CF.attention_gru_forward(self.dec_dims(B, captions.shape[1], P), features, captions, self._named_tensors())
+        dims = self.dec_dims(B, captions.shape[1], P)
+        if sample_prob != 0.0:
+            return _sampled_forward(self, dims, features, captions, sample_prob)
+        return CF.attention_gru_forward(dims, features, captions, self._named_tensors())
 
     def dec_dims(self, B, T, P):
         return ops.DecDims(B, T, P, self.num_features, self.feature_out, self.embedding_dim, self.hidden_dim,
@@ -137,17 +155,16 @@ class AttentionLstm(nn.Module):
     def forward(self, captions, features, sample_prob=1.0):
         """captions [B,T], features [B,P,num_features] -> (outputs [B,T,V], atten_weights [B,T,P]).
         NOTE the reference's argument order and its default sample_prob=1.0 (decoderlstm.py:224)."""
-        if sample_prob != 0.0:
-            raise NotImplementedError("scheduled sampling / free running (sample_prob > 0, "
-                                      "models/decoderlstm.py:236-251) is not built yet (SURVEY.md 8f N1); "
-                                      "pass sample_prob=0.0 for teacher forcing")
         if self.training and self.drop.p > 0:
             raise NotImplementedError("dropout p > 0 in training mode is not supported by the fused HIP path; "
                                       "construct with p=0.0 or call .eval()")
         B, P, D = features.shape
         if D != self.num_features:
             raise CaphnError(f"features have {D} channels, module expects {self.num_features}")
-        return CF.attention_gru_forward(self.dec_dims(B, captions.shape[1], P), features, captions, self._named_tensors())
+        dims = self.dec_dims(B, captions.shape[1], P)
+        if sample_prob != 0.0:
+            return _sampled_forward(self, dims, features, captions, sample_prob)
+        return CF.attention_gru_forward(dims, features, captions, self._named_tensors())
 
     def init_hidden(self, features):
         mean_annotations = torch.mean(features, dim=1)

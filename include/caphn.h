@@ -155,6 +155,14 @@ size_t caphn_decoder_workspace_bytes(const caphn_decoder_dims* d);
 int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_decoder_params* p,
                           const float* features, const int64_t* captions,
                           float* logits, float* alphas, void* ws, caphn_stream_t stream);
+/* Free-running / scheduled-sampling forward (validation, inference; keeps no backward state).
+ * use_sampling is a HOST array of T flags: the reference's per-step draw np.random.random() < sample_prob
+ * (decoderlstm.py:79-80); entry 0 is ignored (step 0 never samples).  A sampling step feeds back
+ * embed[argmax logits] following the GRU rule (:89-96) or the LSTM's lagging rule (:236-251). */
+int caphn_decoder_forward_sampled(const caphn_decoder_dims* d, const caphn_decoder_params* p,
+                                  const float* features, const int64_t* captions,
+                                  const unsigned char* use_sampling,
+                                  float* logits, float* alphas, void* ws, caphn_stream_t stream);
 /* dlogits [B,T,V] (may be overwritten) -> parameter gradients.  ws must be the workspace the
  * matching forward filled.  dalphas (gradient w.r.t. the returned attention weights) may be NULL. */
 int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_decoder_params* p,

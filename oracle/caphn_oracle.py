@@ -263,13 +263,16 @@ def decoder_forward(dims: Dims, p: Dict[str, Tensor], cellw: Dict[str, Tensor],
     outs, alphas = [], []
     output = None
     zero_x = torch.zeros(B, dims.E, dtype=f.dtype)
+    x = zero_x
     for t in range(T):
         samp = bool(use_sampling[t]) if (use_sampling is not None and t > 0) else False
         if not samp:
             x = zero_x if t < 2 else emb[:, t - 1, :]                    # :82-88 + view quirk
-        else:
+        elif dims.cell == "gru":
             top = torch.argmax(F_.log_softmax(output / sample_temp, dim=1), dim=1)  # :91-95
             x = F_.embedding(top, p["captioner.embed.weight"])
+        # lstm + sampling: AttentionLstm does not touch word_embed before the cell (:236-242); it keeps
+        # whatever the previous iteration left (teacher embedding, or the embedding sampled after fc below)
         ctx, alpha = attention(p, f, h, Waf)                             # :97
         xin = torch.cat([x, ctx], 1)                                     # :99
         if dims.cell == "gru":
@@ -277,6 +280,9 @@ def decoder_forward(dims: Dims, p: Dict[str, Tensor], cellw: Dict[str, Tensor],
         else:
             h, c = lstm_cell(xin, h, c, cellw)
         output = F_.linear(h, p["captioner.fc.weight"], p["captioner.fc.bias"])  # :105
+        if samp and dims.cell == "lstm":                                 # :247-251
+            top = torch.argmax(F_.log_softmax(output / sample_temp, dim=1), dim=1)
+            x = F_.embedding(top, p["captioner.embed.weight"])
         outs.append(output)
         alphas.append(alpha)
     return torch.stack(outs, 1), torch.stack(alphas, 1)

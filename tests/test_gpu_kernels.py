@@ -180,6 +180,31 @@ def test_decoder_forward_backward_tiny(ops, name):
     assert maxdiff(l3.cpu(), g["logits_q1"]) < 2e-6
 
 
+@pytest.mark.parametrize("name", ["gru_tiny_flickr", "gru_tiny_cc", "gru_odd_cc", "lstm_tiny"])
+def test_decoder_free_running_and_scheduled_sampling(ops, name):
+    """sample_prob = 1.0 (every step t >= 1 feeds back its own argmax) and a mixed 0.5 pattern, against the
+    reference's outputs; token argmax bit-exact."""
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    B, T = g["captions"].shape
+    P = g["features"].shape[1]
+    raw = dims.cell == "lstm"
+    dd = dec_dims(dims, B, T, P, raw=raw)
+    params = dec_params_from_oracle(p, g["theta"], dims, DEV)
+    params = {n: params[n] for n in dd.names()}
+    ws = ops.decoder_workspace(dd, DEV)
+    feats, caps = g["features"].to(DEV), g["captions"].to(DEV)
+    lf, af = ops.decoder_forward_sampled(dd, params, feats, caps, [True] * T, ws)
+    assert maxdiff(lf.cpu(), g["logits_free"]) < 2e-6 and maxdiff(af.cpu(), g["alphas_free"]) < 1e-6
+    assert torch.equal(lf.argmax(-1).cpu(), g["tokens_free"])
+    pattern = [bool(v) for v in g["mixed_pattern"]]
+    lm, am = ops.decoder_forward_sampled(dd, params, feats, caps, pattern, ws)
+    assert maxdiff(lm.cpu(), g["logits_mixed"]) < 2e-6 and maxdiff(am.cpu(), g["alphas_mixed"]) < 1e-6
+    # all-False flags == teacher forcing
+    l0, _ = ops.decoder_forward_sampled(dd, params, feats, caps, [False] * T, ws)
+    assert maxdiff(l0.cpu(), g["logits"]) < 2e-6
+
+
 def test_decoder_lstm_raw_features_tiny(ops):
     """LSTM cell, attention over the raw features (no feature_fc): the reference's AttentionLstm
     (models/decoderlstm.py:188-261) with hypernet-injected weights, golden case lstm_tiny."""

@@ -96,7 +96,7 @@ def test_module_errors():
     with pytest.raises(CaphnError):
         m(torch.zeros(2, 7, 32), torch.zeros(2, 5, dtype=torch.long))       # CPU tensors: no fallback
     m = m.to(DEV)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):      # sampling path is forward-only: needs no_grad
         m(torch.zeros(2, 7, 32, device=DEV), torch.zeros(2, 5, dtype=torch.long, device=DEV), 1.0)
     with pytest.raises(CaphnError):
         m(torch.zeros(2, 7, 31, device=DEV), torch.zeros(2, 5, dtype=torch.long, device=DEV))
@@ -233,3 +233,26 @@ def test_hypernet_lstm_module_and_engine():
     for _ in range(5):
         l = tr.step(feats, caps, x_style=x.to(DEV))
     assert float(l[0]) < l0
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_module_validation_path_free_running(name):
+    """validation_step runs the captioner twice: teacher forced and sample_prob = 1.0
+    (cc_train_hypernet.py:187-188); scheduled sampling consumes numpy's global RNG like the reference."""
+    import numpy as np
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    net = build_net(dims, p, cc=tok is None)
+    feats, caps = g["features"].to(DEV), g["captions"].to(DEV)
+    with torch.no_grad():
+        xs = net.captioner.embed(torch.tensor([tok], device=DEV)) if tok is not None else x.to(DEV)
+        cap = net.forward(xs)
+        l_tf, _ = cap(feats, caps.long(), 0.0)
+        l_free, a_free = cap(feats, caps.long(), 1.0)
+        np.random.seed(4321)
+        l_mixed, _ = cap(feats, caps.long(), 0.5)
+    assert maxdiff(l_tf.cpu(), g["logits"]) < 2e-6
+    assert maxdiff(l_free.cpu(), g["logits_free"]) < 2e-6 and maxdiff(a_free.cpu(), g["alphas_free"]) < 1e-6
+    assert torch.equal(l_free.argmax(-1).cpu(), g["tokens_free"])
+    assert maxdiff(l_mixed.cpu(), g["logits_mixed"]) < 2e-6

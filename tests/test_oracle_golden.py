@@ -95,6 +95,35 @@ def test_free_running(name):
 
 
 @pytest.mark.parametrize("name", GRU_CASES)
+def test_scheduled_sampling_mixed_pattern(name):
+    """sample_prob = 0.5 with the reference's per-step numpy draws (models/decoderlstm.py:79-80)."""
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    xs = p["captioner.embed.weight"][tok][None] if tok is not None else x
+    cellw = O.split_theta(dims, O.hyper_forward(p, xs))
+    pattern = [bool(v) for v in g["mixed_pattern"]]
+    assert any(pattern[1:]) and not all(pattern[1:])
+    logits, alphas = O.decoder_forward(dims, p, cellw, g["features"], g["captions"], use_sampling=pattern)
+    assert maxdiff(logits, g["logits_mixed"]) < ATOL and maxdiff(alphas, g["alphas_mixed"]) < ATOL
+
+
+def test_lstm_free_running_and_mixed():
+    """AttentionLstm's sampling rule differs from the GRU's: the sampled embedding is produced after fc and
+    only consumed by a later sampling step (models/decoderlstm.py:236-251)."""
+    dims = TINY_DIMS["lstm_tiny"]
+    g, p = load_case("lstm_tiny")
+    cellw = O.split_theta(dims, g["theta"])
+    T = g["captions"].shape[1]
+    lf, af = O.decoder_forward(dims, p, cellw, g["features"], g["captions"], use_sampling=[True] * T, use_feature_fc=False)
+    assert maxdiff(lf, g["logits_free"]) < ATOL and maxdiff(af, g["alphas_free"]) < ATOL
+    assert torch.equal(lf.argmax(-1), g["tokens_free"])
+    pattern = [bool(v) for v in g["mixed_pattern"]]
+    lm, am = O.decoder_forward(dims, p, cellw, g["features"], g["captions"], use_sampling=pattern, use_feature_fc=False)
+    assert maxdiff(lm, g["logits_mixed"]) < ATOL and maxdiff(am, g["alphas_mixed"]) < ATOL
+
+
+@pytest.mark.parametrize("name", GRU_CASES)
 def test_clip_and_adam(name):
     """clip_coef + adam_step against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam."""
     dims = TINY_DIMS[name]

@@ -172,6 +172,13 @@ def tiny_case(name, dims, B, T, P, seed, flickr, max_norm):
     of, _ = ref_gru_step(dims, p, feats, caps, x_style, style_token, sample_prob=1.0, want_grads=False)
     arrs["logits_free"] = of["logits"]; arrs["alphas_free"] = of["alphas"]
     arrs["tokens_free"] = of["logits"].argmax(-1)
+    # scheduled sampling with p = 0.5: the draws come from numpy's global RNG, one per timestep (:80)
+    np.random.seed(4321)
+    draws = np.random.random(T)
+    arrs["mixed_pattern"] = np.array([bool(t > 0 and draws[t] < 0.5) for t in range(T)])
+    np.random.seed(4321)
+    om, _ = ref_gru_step(dims, p, feats, caps, x_style, style_token, sample_prob=0.5, want_grads=False)
+    arrs["logits_mixed"] = om["logits"]; arrs["alphas_mixed"] = om["alphas"]
     # one clip + Adam step with torch's own implementations on the intended grads
     names = O.trainable_names(p)
     g_all = dict(lit); g_all.update(intended)
@@ -229,6 +236,19 @@ def lstm_case(name, seed):
         if n.startswith("lstm."):
             continue
         arrs["glit/" + name_map.get(n, "captioner." + n)] = q.grad
+    # free running: the reference's default sample_prob = 1.0 (:224), every step t >= 1 samples
+    with torch.no_grad():
+        lf, af = m(caps, feats, 1.0)
+    arrs["logits_free"] = lf; arrs["alphas_free"] = af; arrs["tokens_free"] = lf.argmax(-1)
+    # a mixed pattern: force the per-step draws through numpy's global RNG exactly as the reference consumes it
+    import numpy as _np
+    _np.random.seed(1234)
+    draws = _np.random.random(T)
+    pattern = [bool(t > 0 and draws[t] < 0.5) for t in range(T)]
+    _np.random.seed(1234)
+    with torch.no_grad():
+        lm, am = m(caps, feats, 0.5)
+    arrs["mixed_pattern"] = _np.array(pattern); arrs["logits_mixed"] = lm; arrs["alphas_mixed"] = am
     save_npz(os.path.join(OUT, name + ".npz"), **arrs)
     return {"registered": reg, "heads": O.head_layout(dims)}
 
