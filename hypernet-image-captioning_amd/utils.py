@@ -63,3 +63,39 @@ def set_all_parameters(module, theta, detach=None):
             continue
         count += set_all_parameters(module._modules[name], theta, detach)
     return count
+
+
+# ---- domain-embedding helpers used by HyperNetCC's front-ends (reference utils.py:354-393) -----------
+def get_domain_list(cap_dir1, cap_dir2):
+    """utils.py:354-368: unique domains (3rd field, separated by five spaces) in file order."""
+    domains = []
+    for path in (cap_dir1, cap_dir2):
+        if path is None or len(path) == 0:
+            continue
+        with open(path, 'r') as f:
+            for line in f.readlines():
+                domains.append(line.split("     ")[2])
+    return list(dict.fromkeys(domains))
+
+
+def get_hist_embedding(cap_dir1, vocab, list_domain, do_log=True):
+    """utils.py:371-393: per-domain word histogram over the vocabulary (+1 bucket for unknown words),
+    optionally log10(count + 1e-4)."""
+    from math import log
+    eps = 0.0001
+    with open(cap_dir1, 'r') as f:
+        lines = [ln.split("     ") for ln in f.readlines()]
+    out = {}
+    for cur_domain in list_domain:
+        counter_word = [0] * (len(vocab) + 1)
+        for x in lines:
+            if cur_domain == x[2]:
+                for word in x[1].split(" "):
+                    try:
+                        counter_word[vocab.w2i[word]] += 1
+                    except KeyError:
+                        counter_word[len(vocab)] += 1
+        if do_log:
+            counter_word = [log(c + eps, 10) for c in counter_word]
+        out[cur_domain.replace("\n", '')] = counter_word
+    return out

@@ -256,3 +256,64 @@ def test_module_validation_path_free_running(name):
     assert maxdiff(l_free.cpu(), g["logits_free"]) < 2e-6 and maxdiff(a_free.cpu(), g["alphas_free"]) < 1e-6
     assert torch.equal(l_free.argmax(-1).cpu(), g["tokens_free"])
     assert maxdiff(l_mixed.cpu(), g["logits_mixed"]) < 2e-6
+
+
+@pytest.mark.parametrize("mode", ["one hot", "embedding", "histograme", "JSD"])
+def test_hypernet_cc_front_ends(mode):
+    """HyperNetCC's domain-embedding front-ends (cc_train_hypernet.py:63-106, :136-149): the gradient
+    reaches the front-end parameters through the hypernet's input row."""
+    import copy
+    from cc_train_hypernet import HyperNetCC
+    from models.decoderlstm import AttentionGru
+    torch.manual_seed(0)
+    domains = ["news\n", "sport\n", "travel\n"]
+    dims0 = O.Dims(D=24, F=12, E=12, H=12, V=40, he=3 if mode == "one hot" else 10)
+
+    class _V(_Vocab):
+        def __len__(self):
+            return len(self.w2i)
+    vocab = _V()
+    feats_dom = None
+    if mode == "histograme":
+        feats_dom = {d: torch.rand(len(vocab) + 1).tolist() for d in domains}
+    if mode == "JSD":
+        feats_dom = {d: torch.randn(2).tolist() for d in domains}
+    net = HyperNetCC(dims0.F, dims0.E, dims0.H, dims0.V, vocab, domains, lr=1e-3, hyper_emb=10, embedding=mode,
+                     domain_features=feats_dom)
+    assert net.hyper_emb == dims0.he
+    net.hypernet.captioner = AttentionGru(dims0.D, dims0.F, dims0.E, dims0.H, dims0.V, p=0.0)
+    net = net.to(DEV)
+    batch = O.synth_batch(dims0, B=3, T=6, P=5, seed=9)
+    tb = (batch["features"].to(DEV), batch["captions"].to(DEV).float(), None, ("sport", "sport", "sport"))
+    loss = net.training_step(tb, 0)
+    loss.backward()
+    # oracle: same parameters, torch autograd through the attached theta
+    p = {k[len("hypernet."):]: v.detach().cpu() for k, v in net.state_dict().items() if k.startswith("hypernet.")}
+    p = {k: v for k, v in p.items() if not k.startswith("captioner.gru.")}
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    fe = fe_mod = None
+    if mode == "one hot":
+        x = torch.nn.functional.one_hot(torch.tensor(1), 3).float()
+    elif mode == "embedding":
+        fe = net.embed.weight.detach().cpu().clone().requires_grad_(True)
+        x = fe[1]
+    else:
+        fe_mod = copy.deepcopy(net.embed).cpu()
+        for prm in fe_mod.parameters():
+            prm.grad = None
+        x = fe_mod(torch.tensor(feats_dom["sport\n"], dtype=torch.float32))
+    theta = O.hyper_forward(q, x)
+    logits, _ = O.decoder_forward(dims0, q, O.split_theta(dims0, theta), batch["features"], batch["captions"])
+    ref = O.caption_loss(logits, batch["captions"])
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 3e-6
+    assert maxdiff(net.hypernet.hn_base[0].weight.grad.cpu(), q["hn_base.0.weight"].grad) < 3e-6
+    if mode == "embedding":
+        assert maxdiff(net.embed.weight.grad.cpu(), fe.grad) < 3e-6
+        assert float(net.embed.weight.grad[0].abs().sum()) == 0 and float(net.embed.weight.grad[1].abs().sum()) > 0
+    elif mode != "one hot":
+        for a, b in zip(net.embed.parameters(), fe_mod.parameters()):
+            assert maxdiff(a.grad.cpu(), b.grad) < 3e-6
+    out = net.validation_step(tb, 0)
+    assert set(out) == {"val_loss", "val_loss with TF"} and abs(float(out["val_loss with TF"]) - float(ref)) < 3e-6
+    assert len(net.configure_optimizers()[0][0].param_groups[0]["params"]) > 10
