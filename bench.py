@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not tell the optimiser pass the next minibatch's style (disables the fused next-theta GEMV)")
     ap.add_argument("--tune", action="append", default=[], help="kernel-variant knob key=value (caphn_tune), for A/B runs")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a hipGraph (single GPU).  Default is host-launched kernels: the step is "
@@ -151,7 +153,12 @@ def main():
         torch.cuda.synchronize()
 
     use_graph = (world == 1) and args.graph
-    do_step = tr.step_graphed if use_graph else tr.step
+    if use_graph or args.no_prefetch:
+        do_step = tr.step_graphed if use_graph else tr.step
+    else:
+        # the loader is one batch ahead, so the next batch's style is known when the optimiser runs
+        def do_step(f, c, style_token):
+            return tr.step(f, c, style_token=style_token, next_style_token=style_token)
     if use_graph:                                  # two passes over the batch buffers: eager, then capture
         for _ in range(2):
             for f, c in batches:
@@ -216,6 +223,7 @@ def main():
                        "V": V, "hypernet_params": int(sum(q.numel() for q in net.hn_base.parameters()) +
                                                       sum(q.numel() for q in net.hn_heads.parameters())),
                        "parallelism": f"dp{world}", "launch": "hipGraph" if use_graph else "eager",
+                       "next_theta_in_adam_pass": not (use_graph or args.no_prefetch),
                        "final_loss": float(loss[0])},
             "roofline": {"bound": "hbm", "kernel": "adam_rank_kernel(hn_heads.0.2.weight)",
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -84,6 +84,9 @@ SIGNATURES = {
     "caphn_adam_dense_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp, c_fp, c_fp, C.POINTER(AdamHParams), c_fp]),
     "caphn_adam_rank_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_size_t,
                                       c_fp, C.c_size_t, c_fp, C.POINTER(AdamHParams), c_fp]),
+    "caphn_adam_rank_gemv_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_size_t,
+                                           c_fp, C.c_size_t, c_fp, C.POINTER(AdamHParams), c_fp, c_fp, c_fp, c_fp]),
+    "caphn_hyper_forward_acts": (C.c_int, [C.POINTER(HyperDesc), c_fp, c_fp, c_fp]),
     "caphn_outer_f32": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
     "caphn_tune": (C.c_int, [C.c_int, C.c_int]),
 }

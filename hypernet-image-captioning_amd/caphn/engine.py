@@ -54,6 +54,7 @@ class FusedTrainer:
         self._acts_layout = ops.hyper_acts_layout(self.shape)
         self._acts = torch.zeros(self._acts_layout["_total"][1], dtype=torch.float32, device=dev)
         self._hyper_ws = None
+        self._readopted = False
         self._tok = torch.zeros(1, dtype=torch.int64, device=dev)
         self._nh = nh
         # step-dependent Adam scalars live in device memory so a captured hipGraph replays for any step
@@ -61,6 +62,10 @@ class FusedTrainer:
         self._adam_host = torch.zeros(2, dtype=torch.float32).pin_memory()
         self._graphs: Dict[tuple, object] = {}
         self._seen = set()
+        # next-step theta produced during the optimiser pass (fused GEMV in caphn_adam_rank_gemv_f32)
+        self._theta_next = None
+        self._acts_next = torch.zeros_like(self._acts)
+        self._next_key = None
 
     # ------------------------------------------------------------------ parameter arenas
     def _build_arena(self):
@@ -126,6 +131,7 @@ class FusedTrainer:
         sub-module transplant :424-428).  Re-adopt any parameter whose storage left the arena."""
         hyper = self.net.hyper_named_tensors()
         dec = {"captioner." + n: t for n, t in self.cap._named_tensors().items() if n in self._dec_names}
+        self._readopted = False
         for name in self.offs:
             cur = hyper.get(name, dec.get(name))
             o, n, shape = self.offs[name]
@@ -133,11 +139,13 @@ class FusedTrainer:
                 if tuple(cur.shape) != shape:
                     raise CaphnError(f"{name}: shape changed to {tuple(cur.shape)}, arena holds {shape}")
                 self._adopt(name, cur)
+                self._readopted = True
         for i in range(self._nh):
             w = hyper[f"hn_heads.{i}.2.weight"]
             if w is not self.W2[i] or not w.data.is_contiguous():
                 w.data = w.data.contiguous()
                 self.W2[i] = w
+                self._readopted = True
 
     # ------------------------------------------------------------------ per-shape buffers
     def _buffers(self, B, T, P):
@@ -190,7 +198,15 @@ class FusedTrainer:
         theta = getattr(self, "_theta", None)
         if theta is None:
             theta = self._theta = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)
-        ops.hyper_forward(self.shape, hp, x, theta=theta, acts=self._acts)
+        key = ("tok", int(style_token)) if style_token is not None else ("x", x_style.data_ptr())
+        if self._next_key is not None and self._next_key == key and not self._readopted:
+            # theta for this input was already produced by the previous optimiser pass
+            self._theta, self._theta_next = self._theta_next, self._theta
+            self._acts, self._acts_next = self._acts_next, self._acts
+            theta = self._theta
+        else:
+            ops.hyper_forward(self.shape, hp, x, theta=theta, acts=self._acts)
+        self._next_key = None
         params = self._dec_tensors(theta, grads=False)
         ops.decoder_forward(dims, params, features, captions, buf["ws"], logits=buf["logits"], alphas=buf["alphas"],
                             validate=validate)
@@ -245,7 +261,7 @@ class FusedTrainer:
         self._adam_host[1] = b
         self._adam_dev.copy_(self._adam_host, non_blocking=True)
 
-    def _optimizer_impl(self):
+    def _optimizer_impl(self, next_x_style=None, next_style_token=None):
         R = dp.world(self.group)
         gfac, acts_all = self._exchange()
         part = ops.sumsq_partials(self.flat_g, self._part)
@@ -256,25 +272,48 @@ class FusedTrainer:
             ao, an = self._acts_layout[f"a{i}"]
             gi, ai = gfac[:, o:o + w], acts_all[:, ao:ao + an]
             ops.rank_sumsq(gi, ai, self._acc)
-            segs.append((gi, ai))
+            segs.append((gi, ai, o, w, ao, an))
             o += w
         ops.clip_coef(part, self._acc, self.max_norm, 1.0 / R, out=self._coef)
         step = max(self.step_count, 1)
         ops.adam_dense(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self._coef, self.lr, step,
                        self.betas, self.eps, dev_scalars=self._adam_dev)
-        for i, (gi, ai) in enumerate(segs):
+        prefetch = (next_x_style is not None) or (next_style_token is not None)
+        if prefetch:
+            # the small layers (and the style row of the embedding) are already updated: compute the next
+            # step's head activations, then let the rank-1 Adam pass emit theta_next = W2' a' + b2' row by row
+            hp = {n: self._owned[n].data for n in self.shape.param_names() if n in self._owned}
+            for i in range(self._nh):
+                hp[f"hn_heads.{i}.2.weight"] = self.W2[i].data
+            if next_style_token is not None:
+                xn = self._view(self.flat_p, "captioner.embed.weight")[int(next_style_token)]
+                self._next_key = ("tok", int(next_style_token))
+            else:
+                xn = next_x_style.reshape(-1).to(device=self.dev, dtype=torch.float32)
+                self._next_key = ("x", next_x_style.data_ptr())
+            ops.hyper_forward_acts(self.shape, hp, xn, self._acts_next)
+            if self._theta_next is None:
+                self._theta_next = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)
+        for i, (gi, ai, o, w, ao, an) in enumerate(segs):
+            kw = {}
+            if prefetch:
+                kw = dict(next_a=self._acts_next[ao:ao + an], next_bias=self._owned[f"hn_heads.{i}.2.bias"].data,
+                          next_theta=self._theta_next[o:o + w])
             ops.adam_rank(self.W2[i].data, self.W2_m[i], self.W2_v[i], gi, ai, self._coef, self.lr, step,
-                          self.betas, self.eps, dev_scalars=self._adam_dev)
+                          self.betas, self.eps, dev_scalars=self._adam_dev, **kw)
         return self._coef
 
-    def optimizer_step(self):
-        """clip_grad_norm_(max_norm) over ALL gradients + Adam, on device, no host sync."""
+    def optimizer_step(self, next_x_style=None, next_style_token=None):
+        """clip_grad_norm_(max_norm) over ALL gradients + Adam, on device, no host sync.
+        If the NEXT minibatch's style row is already known (the data loader is one batch ahead), pass it:
+        the Adam pass over the big second-layer weights then also produces the next step's theta, saving that
+        step's 576 MB forward read (the following forward_backward must be called with that same input)."""
         self._begin_step()
-        return self._optimizer_impl()
+        return self._optimizer_impl(next_x_style, next_style_token)
 
-    def step(self, features, captions, x_style=None, style_token=None):
+    def step(self, features, captions, x_style=None, style_token=None, next_x_style=None, next_style_token=None):
         loss = self.forward_backward(features, captions, x_style, style_token)
-        self.optimizer_step()
+        self.optimizer_step(next_x_style, next_style_token)
         return loss
 
     def step_graphed(self, features, captions, x_style=None, style_token=None):

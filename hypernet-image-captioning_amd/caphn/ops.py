@@ -387,17 +387,36 @@ def adam_dense(p, m, v, g, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_sca
                                      L.stream_ptr()), "caphn_adam_dense_f32")
 
 
-def adam_rank(W, m, v, gfac, afac, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_scalars=None) -> None:
-    """Adam on W [rows,k] with gradient coef * sum_r gfac[r,:,None] * afac[r,None,:] (never materialised)."""
+def adam_rank(W, m, v, gfac, afac, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_scalars=None,
+              next_a=None, next_bias=None, next_theta=None) -> None:
+    """Adam on W [rows,k] with gradient coef * sum_r gfac[r,:,None] * afac[r,None,:] (never materialised).
+    With next_a / next_bias / next_theta the pass also emits next_theta = W' next_a + next_bias (the next
+    step's forward GEMV on the updated weights, at no extra HBM traffic)."""
     lib = L.load()
     hp = _hp(lr, betas, eps, step, dev_scalars)
     rows, k = W.shape
     R = gfac.shape[0]
     assert gfac.shape[1] == rows and afac.shape[1] == k and afac.shape[0] == R
     assert gfac.stride(1) == 1 and afac.stride(1) == 1
-    L.check(lib.caphn_adam_rank_f32(R, rows, k, L.ptr(W), L.ptr(m), L.ptr(v), gfac.data_ptr(), gfac.stride(0),
-                                    afac.data_ptr(), afac.stride(0), L.ptr(coef), C.byref(hp), L.stream_ptr()),
-            "caphn_adam_rank_f32")
+    if next_a is None:
+        L.check(lib.caphn_adam_rank_f32(R, rows, k, L.ptr(W), L.ptr(m), L.ptr(v), gfac.data_ptr(), gfac.stride(0),
+                                        afac.data_ptr(), afac.stride(0), L.ptr(coef), C.byref(hp), L.stream_ptr()),
+                "caphn_adam_rank_f32")
+    else:
+        assert next_a.numel() == k and next_bias.numel() == rows and next_theta.numel() == rows
+        L.check(lib.caphn_adam_rank_gemv_f32(R, rows, k, L.ptr(W), L.ptr(m), L.ptr(v), gfac.data_ptr(), gfac.stride(0),
+                                             afac.data_ptr(), afac.stride(0), L.ptr(coef), C.byref(hp),
+                                             next_a.data_ptr(), next_bias.data_ptr(), next_theta.data_ptr(),
+                                             L.stream_ptr()), "caphn_adam_rank_gemv_f32")
+
+
+def hyper_forward_acts(shape: HyperShape, p: Dict[str, torch.Tensor], x: torch.Tensor, acts: torch.Tensor) -> None:
+    """hn_base and the heads' first layers only (fills acts; no pass over the big second layers)."""
+    lib = L.load()
+    d = _hyper_desc(shape, p)
+    x = x.reshape(-1)
+    L.check(lib.caphn_hyper_forward_acts(C.byref(d), L.ptr(x.contiguous()), L.ptr(acts), L.stream_ptr()),
+            "caphn_hyper_forward_acts")
 
 
 def outer(g: torch.Tensor, a: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -12,13 +12,58 @@
 #include <algorithm>
 
 int g_tune_rec_rotate = 1;
+int g_tune_fork = 1;        // 1: independent branches of the composites run on side streams (fork/join); 0: one stream
 #define RUN(x) do { int _rc = (x); if (_rc != CAPHN_OK) return _rc; } while (0)
 
 namespace {
 
+// Side streams for the independent branches of one composite call.  Created on first use (outside any
+// graph capture); fork/join is expressed with events, so a capturing caller stream captures the branches too.
+// Not thread-safe: one host thread drives one device (as the reference's training loop does).
+struct Side {
+    hipStream_t st[3];
+    hipEvent_t fork, join[3], x[2];
+    bool ready = false, on = false;
+    hipStream_t main = nullptr;
+    int init() {
+        if (ready) return CAPHN_OK;
+        for (auto& s : st) if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return CAPHN_ELAUNCH;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
+        for (auto& e : join) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
+        for (auto& e : x) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
+        ready = true;
+        return CAPHN_OK;
+    }
+    int begin(hipStream_t m, bool enable) {
+        main = m; on = enable;
+        if (!on) return CAPHN_OK;
+        return init();
+    }
+    hipStream_t s(int i) const { return on ? st[i] : main; }
+    // branch i starts after everything enqueued on main so far
+    int forkto(int i) {
+        if (!on) return CAPHN_OK;
+        if (hipEventRecord(fork, main) != hipSuccess) return CAPHN_ELAUNCH;
+        return hipStreamWaitEvent(st[i], fork, 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+    }
+    // main continues only after branch i's work so far
+    int jointo(int i) {
+        if (!on) return CAPHN_OK;
+        if (hipEventRecord(join[i], st[i]) != hipSuccess) return CAPHN_ELAUNCH;
+        return hipStreamWaitEvent(main, join[i], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+    }
+    // `to` waits for what `from` has enqueued so far (cross-branch dependency), via event slot k
+    int dep(hipStream_t from, hipStream_t to, int k) {
+        if (!on || from == to) return CAPHN_OK;
+        if (hipEventRecord(x[k], from) != hipSuccess) return CAPHN_ELAUNCH;
+        return hipStreamWaitEvent(to, x[k], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+    }
+};
+Side g_side;
+
 struct Ws {   // float offsets into the workspace
     size_t Y1, f, meanf, h0, c0, Waf, G, Xe, Xg, Hs, Hprev, gates, hn, Cs, Cprev, uah, alphas, idx;
-    size_t dHs, dgi, dgh, duah, de, dh0, dc0, ctx, dctx, dXe, dWaf, dmeanf, df, dY1, apart, vtmp, colws, prof;
+    size_t dHs, dgi, dgh, duah, de, dh0, dc0, ctx, dctx, dXe, dWaf, dmeanf, df, dY1, apart, vtmp, colws, colws_s[3], prof;
     size_t total;
     int npc, pchunk, NG;
 };
@@ -51,6 +96,12 @@ inline Ws layout(const caphn_decoder_dims* d) {
     need(B * T, V); need(B * T, NG * H); need(B * T, H); need(B * P, H); need(B * P, F); need(B, H);
     need(B * w.npc, H + 1);
     w.colws = take(cs);
+    {   // side-stream branches run their own (small) column sums concurrently
+        size_t c2 = 0;
+        auto need2 = [&](size_t M, size_t N) { c2 = std::max(c2, caphn_colsum_workspace_bytes((int)M, (int)N) / sizeof(float)); };
+        need2(B * T, NG * H); need2(B * T, H); need2(B * P, H); need2(B * P, F); need2(B, H); need2(B * w.npc, H + 1);
+        for (int i = 0; i < 3; ++i) w.colws_s[i] = take(c2);
+    }
     w.prof = take(64);        // 2 x 8 uint64 phase counters (forward, backward) of the recurrent kernels
     w.total = o;
     (void)D;
@@ -116,15 +167,19 @@ static int decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_p
         RUN(caphn_gemm_f32(0, 1, BP, F, F, ws + w.Y1, F, p->fc2_w, F, ws + w.f, F, p->fc2_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
         f = ws + w.f;
     }
-    // init_hidden: mean over positions -> Linear(F,H) (and init_c for the LSTM)      :122-135 / :255-260
-    RUN(caphn_launch_mean_p(B, P, F, f, ws + w.meanf, s));
-    RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->inith_w, F, ws + w.h0, H, p->inith_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    Side& sd = g_side;
+    RUN(sd.begin(s, g_tune_fork != 0));
+    RUN(sd.forkto(0)); RUN(sd.forkto(1));
+    // branch 0 -- init_hidden: mean over positions -> Linear(F,H) (and init_c for the LSTM)      :122-135 / :255-260
+    RUN(caphn_launch_mean_p(B, P, F, f, ws + w.meanf, sd.s(0)));
+    RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->inith_w, F, ws + w.h0, H, p->inith_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, sd.s(0)));
     if (lstm)
-        RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->initc_w, F, ws + w.c0, H, p->initc_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
-    // t-invariant attention projection W_a f + b      attention.py:34
-    RUN(caphn_gemm_f32(0, 1, BP, H, F, f, F, p->Wa_w, F, ws + w.Waf, H, p->Wa_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
-    // G = f W_ih[:, E:]^T  (context side of the gate pre-activations, hoisted)
+        RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->initc_w, F, ws + w.c0, H, p->initc_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, sd.s(0)));
+    // branch 1 -- t-invariant attention projection W_a f + b      attention.py:34
+    RUN(caphn_gemm_f32(0, 1, BP, H, F, f, F, p->Wa_w, F, ws + w.Waf, H, p->Wa_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, sd.s(1)));
+    // main -- G = f W_ih[:, E:]^T  (context side of the gate pre-activations, hoisted)
     RUN(caphn_gemm_f32(0, 1, BP, GH, F, f, F, p->w_ih + E, EF, ws + w.G, GH, nullptr, nullptr, 0, 0, 1, s));
+    RUN(sd.jointo(0)); RUN(sd.jointo(1));
     *f_out = f;
     return CAPHN_OK;
 }
@@ -225,9 +280,15 @@ extern "C" int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_d
     float* dgi = ws + w.dgi;
     float* dgh = lstm ? dgi : ws + w.dgh;          // LSTM: d(gi) == d(gh)
 
-    // vocab projection: dW = dlogits^T Hs, db = colsum, dHs = dlogits W
-    RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, s));
-    RUN(caphn_colsum_f32(BT, V, dlogits, V, g->out_b, cws, s));
+    Side& sd = g_side;
+    RUN(sd.begin(s, g_tune_fork != 0));
+    void* cw0 = ws + w.colws_s[0]; void* cw1 = ws + w.colws_s[1]; void* cw2 = ws + w.colws_s[2];
+
+    // vocab projection.  dHs = dlogits W feeds BPTT (main); dW = dlogits^T Hs and db = colsum(dlogits) are only
+    // needed by the optimiser: branch 0 computes them beside the BPTT kernel, which occupies B of the 256 CUs.
+    RUN(sd.forkto(0));
+    RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, sd.s(0)));
+    RUN(caphn_colsum_f32(BT, V, dlogits, V, g->out_b, cws, sd.s(0)));
     RUN(gemm_auto(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, s));
 
     RecBwdArgs a;
@@ -243,38 +304,44 @@ extern "C" int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_d
     a.rotate = g_tune_rec_rotate;
     RUN(caphn_launch_rec_bwd(a, lstm, s));
 
-    // recurrent weights: dW_hh = dgh^T Hprev, dU_a = duah^T Hprev, biases by column sums
-    RUN(gemm_auto(1, 0, GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, nullptr, 0, s));
-    RUN(caphn_colsum_f32(BT, GH, dgh, GH, g->b_hh, cws, s));
-    RUN(gemm_auto(1, 0, H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, nullptr, 0, s));
-    RUN(caphn_colsum_f32(BT, H, ws + w.duah, H, g->Ua_b, cws, s));
-    RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cws, s));
-    // input weights: dW_ih[:, :E] = dgi^T Xe ; dW_ih[:, E:] = dgi^T ctx
-    RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, s));
-    RUN(gemm_auto(1, 0, GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, nullptr, 0, s));
-    RUN(gemm_auto(1, 0, GH, F, BT, dgi, GH, ws + w.ctx, F, g->w_ih + E, EF, nullptr, 0, s));
-    // embedding: dXe = dgi W_ih[:, :E] scattered to the rows looked up in the forward
-    RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, s));
-    if (hipMemsetAsync(g->embed_w, 0, sizeof(float) * (size_t)V * E, s) != hipSuccess) return CAPHN_ELAUNCH;
-    RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, s));
-    // attention parameters
+    // ---- after BPTT three more independent branches (1, 2 and main); branch 0 keeps running
+    RUN(sd.forkto(1)); RUN(sd.forkto(2));
+    // branch 1 -- recurrent weights: dW_hh = dgh^T Hprev, dU_a = duah^T Hprev, biases by column sums; init_h / init_c
+    {
+        hipStream_t b1 = sd.s(1);
+        RUN(gemm_auto(1, 0, GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, nullptr, 0, b1));
+        RUN(caphn_colsum_f32(BT, GH, dgh, GH, g->b_hh, cw1, b1));
+        RUN(gemm_auto(1, 0, H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, nullptr, 0, b1));
+        RUN(caphn_colsum_f32(BT, H, ws + w.duah, H, g->Ua_b, cw1, b1));
+        RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cw1, b1));
+        RUN(gemm_auto(1, 0, H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, nullptr, 0, b1));
+        RUN(caphn_colsum_f32(B, H, ws + w.dh0, H, g->inith_b, cw1, b1));
+        if (lstm) {
+            RUN(gemm_auto(1, 0, H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, nullptr, 0, b1));
+            RUN(caphn_colsum_f32(B, H, ws + w.dc0, H, g->initc_b, cw1, b1));
+        }
+    }
+    // branch 2 -- input weights dW_ih[:, :E] = dgi^T Xe, dW_ih[:, E:] = dgi^T ctx; embedding gradient
+    {
+        hipStream_t b2 = sd.s(2);
+        RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, b2));
+        RUN(gemm_auto(1, 0, GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, nullptr, 0, b2));
+        RUN(gemm_auto(1, 0, GH, F, BT, dgi, GH, ws + w.ctx, F, g->w_ih + E, EF, nullptr, 0, b2));
+        RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, b2));
+        if (hipMemsetAsync(g->embed_w, 0, sizeof(float) * (size_t)V * E, b2) != hipSuccess) return CAPHN_ELAUNCH;
+        RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, b2));
+    }
+    // main -- attention parameters, then the chain into f and feature_fc
     AttnGradArgs ag;
     ag.T = T; ag.P = P; ag.H = H; ag.pchunk = w.pchunk;
     ag.Waf = ws + w.Waf; ag.uah = ws + w.uah; ag.de = ws + w.de; ag.v_a = p->va_w;
     ag.dWaf = ws + w.dWaf; ag.part = ws + w.apart;
     RUN(caphn_launch_attn_param_grads(ag, B, w.npc, s));
-    RUN(caphn_colsum_f32(B * w.npc, H + 1, ws + w.apart, H + 1, ws + w.vtmp, cws, s));
+    RUN(caphn_colsum_f32(B * w.npc, H + 1, ws + w.apart, H + 1, ws + w.vtmp, cw0, s));
     if (hipMemcpyAsync(g->va_w, ws + w.vtmp, sizeof(float) * H, hipMemcpyDeviceToDevice, s) != hipSuccess) return CAPHN_ELAUNCH;
     if (hipMemcpyAsync(g->va_b, ws + w.vtmp + H, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return CAPHN_ELAUNCH;
     RUN(gemm_auto(1, 0, H, F, BP, ws + w.dWaf, H, f, F, g->Wa_w, F, nullptr, 0, s));
-    RUN(caphn_colsum_f32(BP, H, ws + w.dWaf, H, g->Wa_b, cws, s));
-    // init_h (and init_c)
-    RUN(gemm_auto(1, 0, H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, nullptr, 0, s));
-    RUN(caphn_colsum_f32(B, H, ws + w.dh0, H, g->inith_b, cws, s));
-    if (lstm) {
-        RUN(gemm_auto(1, 0, H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, nullptr, 0, s));
-        RUN(caphn_colsum_f32(B, H, ws + w.dc0, H, g->initc_b, cws, s));
-    }
+    RUN(caphn_colsum_f32(BP, H, ws + w.dWaf, H, g->Wa_b, cw0, s));
     if (!raw) {
         if (!g->fc0_w || !g->fc0_b || !g->fc2_w || !g->fc2_b) return CAPHN_EINVAL;
         // context path into f, initial-state path into mean f
@@ -287,11 +354,13 @@ extern "C" int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_d
         RUN(caphn_gemm_f32(0, 0, BP, F, H, ws + w.dWaf, H, p->Wa_w, F, ws + w.df, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
         // feature_fc backward
         RUN(gemm_auto(1, 0, F, F, BP, ws + w.df, F, ws + w.Y1, F, g->fc2_w, F, nullptr, 0, s));
-        RUN(caphn_colsum_f32(BP, F, ws + w.df, F, g->fc2_b, cws, s));
+        RUN(caphn_colsum_f32(BP, F, ws + w.df, F, g->fc2_b, cw0, s));
         RUN(caphn_gemm_f32(0, 0, BP, F, F, ws + w.df, F, p->fc2_w, F, ws + w.dY1, F, nullptr, ws + w.Y1, F, CAPHN_GEMM_MASK, 1, s));
         RUN(gemm_auto(1, 0, F, D, BP, ws + w.dY1, F, features, D, g->fc0_w, D, nullptr, 0, s));
-        RUN(caphn_colsum_f32(BP, F, ws + w.dY1, F, g->fc0_b, cws, s));
+        RUN(caphn_colsum_f32(BP, F, ws + w.dY1, F, g->fc0_b, cw0, s));
     }
+    RUN(sd.jointo(0)); RUN(sd.jointo(1)); RUN(sd.jointo(2));
+    (void)cw2;
     (void)captions;
     return caphn_launch_status();
 }

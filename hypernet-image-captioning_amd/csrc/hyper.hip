@@ -325,9 +325,17 @@ extern "C" int caphn_hyper_acts_floats(const caphn_hyper_desc* d) {
     return acts_layout(d).total;
 }
 
+static int hyper_forward_impl(const caphn_hyper_desc* d, const float* x, float* theta, float* acts, caphn_stream_t stream);
 extern "C" int caphn_hyper_forward(const caphn_hyper_desc* d, const float* x, float* theta, float* acts,
                                    caphn_stream_t stream) {
-    if (!desc_ok(d) || !x || !theta || !acts) return CAPHN_EINVAL;
+    if (!theta) return CAPHN_EINVAL;
+    return hyper_forward_impl(d, x, theta, acts, stream);
+}
+extern "C" int caphn_hyper_forward_acts(const caphn_hyper_desc* d, const float* x, float* acts, caphn_stream_t stream) {
+    return hyper_forward_impl(d, x, nullptr, acts, stream);
+}
+static int hyper_forward_impl(const caphn_hyper_desc* d, const float* x, float* theta, float* acts, caphn_stream_t stream) {
+    if (!desc_ok(d) || !x || !acts) return CAPHN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const ActsLayout L = acts_layout(d);
     if (hipMemcpyAsync(acts + L.x, x, sizeof(float) * d->he, hipMemcpyDeviceToDevice, s) != hipSuccess)
@@ -351,7 +359,7 @@ extern "C" int caphn_hyper_forward(const caphn_hyper_desc* d, const float* x, fl
         }
         launch_gemv_fwd(jobs, b0, s);
     }
-    {   // second layers: theta = cat_i (W2_i a_i + b2_i)
+    if (theta) {   // second layers: theta = cat_i (W2_i a_i + b2_i)
         GemvJobs jobs; jobs.n = d->n_heads; int b0 = 0; size_t off = 0;
         for (int i = 0; i < d->n_heads; ++i) {
             GemvJob& J = jobs.j[i];
@@ -479,10 +487,12 @@ extern "C" int caphn_outer_f32(int rows, int k, const float* gv, const float* av
 extern int g_tune_adam;
 extern int g_tune_gemm;
 extern int g_tune_rec_rotate;
+extern int g_tune_fork;
 extern "C" int caphn_tune(int key, int value) {
     if (key == 0) { g_tune_gemv = value; return CAPHN_OK; }
     if (key == 1) { g_tune_adam = value; return CAPHN_OK; }
     if (key == 2) { g_tune_gemm = value; return CAPHN_OK; }
     if (key == 3) { g_tune_rec_rotate = value; return CAPHN_OK; }
+    if (key == 4) { g_tune_fork = value; return CAPHN_OK; }
     return CAPHN_EINVAL;
 }

@@ -219,11 +219,18 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(size_t n, float* __rest
 constexpr int RMAX = 8;
 // RB rows per wave iteration (3*RB*QMAX independent dwordx4 loads in flight), NTL / NTS: non-temporal
 // loads / stores.  Variant chosen by caphn_tune(1, v) -- measured A/B.
+struct NextGemv { const float* a; const float* bias; float* theta; };   // theta[row] = W'[row,:] . a + bias[row]
 template <int QMAX, int RB, bool NTL, bool NTS>
 __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W, float* m, float* v,
                                                const float* gfac, size_t ldg, const float* afac, size_t lda,
-                                               float c, const AdamK& K, int wave_g, int nwaves, int lane) {
+                                               float c, const AdamK& K, int wave_g, int nwaves, int lane, NextGemv nx) {
     const int k4 = k >> 2;
+    f32x4 an[QMAX];            // next step's head activations (fused forward GEMV on the updated weights)
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+        const int cidx = lane + 64 * q;
+        an[q] = (nx.a && cidx < k4) ? reinterpret_cast<const f32x4*>(nx.a)[cidx] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     f32x4 a1[QMAX];            // column factors stay in registers for every row (R == 1 fast path)
 #pragma unroll
     for (int q = 0; q < QMAX; ++q) {
@@ -252,6 +259,7 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
         for (int i = 0; i < RB; ++i) {
             if (row0 + i >= rows) continue;
             const size_t base = (size_t)(row0 + i) * k;
+            float dot = 0.f;
             float gr[RMAX];
 #pragma unroll
             for (int r = 0; r < RMAX; ++r) gr[r] = r < R ? gfac[(size_t)r * ldg + row0 + i] * c : 0.f;
@@ -270,6 +278,7 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
                     f32x4 po = pp[i][q], mo = mm[i][q], vo = vv[i][q];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { float me = mo[e], ve = vo[e]; po[e] = adam_elem(po[e], g[e], me, ve, K); mo[e] = me; vo[e] = ve; }
+                    dot += po[0] * an[q][0] + po[1] * an[q][1] + po[2] * an[q][2] + po[3] * an[q][3];
                     f32x4* qw = reinterpret_cast<f32x4*>(W + base) + cidx;
                     f32x4* qm = reinterpret_cast<f32x4*>(m + base) + cidx;
                     f32x4* qv = reinterpret_cast<f32x4*>(v + base) + cidx;
@@ -277,21 +286,25 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
                     else { *qw = po; *qm = mo; *qv = vo; }
                 }
             }
+            if (nx.a) {                      // wave-uniform
+                dot = wave_sum(dot);
+                if (lane == 0) nx.theta[row0 + i] = dot + nx.bias[row0 + i];
+            }
         }
     }
 }
 template <int RB, bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void adam_rank_kernel(int R, int rows, int k, float* W, float* m, float* v,
                                                         const float* gfac, size_t ldg, const float* afac, size_t lda,
-                                                        const float* coef, AdamK K, int vec) {
+                                                        const float* coef, AdamK K, int vec, NextGemv nx) {
     const float c = coef[0];
     if (K.dev) { K.lr_bc1 = K.dev[0]; K.sqrt_bc2 = K.dev[1]; }
     if (vec && k <= 2048) {
         const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4, lane = threadIdx.x & 63;
-        if (k <= 256) adam_rank_rows<1, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
-        else if (k <= 512) adam_rank_rows<2, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
-        else if (k <= 1024) adam_rank_rows<4, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
-        else adam_rank_rows<8, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane);
+        if (k <= 256) adam_rank_rows<1, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane, nx);
+        else if (k <= 512) adam_rank_rows<2, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane, nx);
+        else if (k <= 1024) adam_rank_rows<4, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane, nx);
+        else adam_rank_rows<8, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane, nx);
     } else {
         const size_t n = (size_t)rows * k, stride = (size_t)gridDim.x * 256;
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -300,6 +313,16 @@ __global__ __launch_bounds__(256) void adam_rank_kernel(int R, int rows, int k, 
             for (int r = 0; r < R; ++r) g += gfac[(size_t)r * ldg + row] * afac[(size_t)r * lda + col];
             float me = m[i], ve = v[i]; W[i] = adam_elem(W[i], g * c, me, ve, K); m[i] = me; v[i] = ve;
         }
+    }
+}
+// generic-shape companion of the fused GEMV (k % 4 != 0 or unaligned): theta[row] = W[row,:] . a + bias[row]
+__global__ __launch_bounds__(256) void rowdot_kernel(int rows, int k, const float* __restrict__ W, NextGemv nx) {
+    const int grp = threadIdx.x >> 3, s = threadIdx.x & 7;
+    for (int r = blockIdx.x * 32 + grp; r < rows; r += gridDim.x * 32) {
+        float sum = 0.f;
+        for (int c = s; c < k; c += 8) sum += W[(size_t)r * k + c] * nx.a[c];
+        sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 1, 64);
+        if (s == 0) nx.theta[r] = sum + nx.bias[r];
     }
 }
 
@@ -399,18 +422,26 @@ extern "C" int caphn_adam_dense_f32(size_t n, float* p, float* m, float* v, cons
     hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), n, p, m, v, g, coef, make_adam(hp), vec);
     return caphn_launch_status();
 }
-extern "C" int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, float* v,
-                                   const float* gfac, size_t ldg, const float* afac, size_t lda,
-                                   const float* coef, const caphn_adam_hparams* hp, caphn_stream_t stream) {
+static int adam_rank_launch(int R, int rows, int k, float* W, float* m, float* v,
+                            const float* gfac, size_t ldg, const float* afac, size_t lda,
+                            const float* coef, const caphn_adam_hparams* hp, NextGemv nx, caphn_stream_t stream) {
     if (R <= 0 || R > RMAX || rows <= 0 || k <= 0 || !W || !m || !v || !gfac || !afac || !coef || !hp || hp->step < 1) return CAPHN_EINVAL;
-    const int vec = (k % 4 == 0) && (lda % 4 == 0) && caphn_aligned16(W) && caphn_aligned16(m) && caphn_aligned16(v) && caphn_aligned16(afac);
+    const int vec = (k % 4 == 0) && (lda % 4 == 0) && caphn_aligned16(W) && caphn_aligned16(m) && caphn_aligned16(v) && caphn_aligned16(afac)
+                    && (!nx.a || caphn_aligned16(nx.a));
     long nb = ((long)rows + 3) / 4;
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const AdamK K = make_adam(hp);
+    const bool fused = vec && k <= 2048;
+    NextGemv nk = fused ? nx : NextGemv{nullptr, nullptr, nullptr};
 #define ADAM_RANK_LAUNCH(RB, NTL, NTS) hipLaunchKernelGGL((adam_rank_kernel<RB, NTL, NTS>), dim3((unsigned)nb), dim3(256), 0, s, \
-        R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, vec)
+        R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, vec, nk)
+    if (nk.a && g_tune_adam == 3) {
+        // fused next-theta GEMV: the per-row shuffle reduction would sit between one row's stores and the next
+        // row's loads; with two rows per iteration both rows' loads are issued before either reduction
+        ADAM_RANK_LAUNCH(2, true, true);
+    } else
     switch (g_tune_adam) {      // default 3: one row per wave iteration, non-temporal loads and stores
         case 0: ADAM_RANK_LAUNCH(1, false, false); break;
         case 1: ADAM_RANK_LAUNCH(1, true, false); break;
@@ -421,7 +452,24 @@ extern "C" int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, f
         default: ADAM_RANK_LAUNCH(1, true, true); break;
     }
 #undef ADAM_RANK_LAUNCH
+    if (nx.a && !fused) {
+        long nr = ((long)rows + 31) / 32; if (nr > 2048) nr = 2048;
+        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)nr), dim3(256), 0, s, rows, k, W, nx);
+    }
     return caphn_launch_status();
+}
+extern "C" int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, float* v,
+                                   const float* gfac, size_t ldg, const float* afac, size_t lda,
+                                   const float* coef, const caphn_adam_hparams* hp, caphn_stream_t stream) {
+    return adam_rank_launch(R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, hp, NextGemv{nullptr, nullptr, nullptr}, stream);
+}
+extern "C" int caphn_adam_rank_gemv_f32(int R, int rows, int k, float* W, float* m, float* v,
+                                        const float* gfac, size_t ldg, const float* afac, size_t lda,
+                                        const float* coef, const caphn_adam_hparams* hp,
+                                        const float* next_a, const float* next_bias, float* next_theta,
+                                        caphn_stream_t stream) {
+    if (!next_a || !next_bias || !next_theta) return CAPHN_EINVAL;
+    return adam_rank_launch(R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, hp, NextGemv{next_a, next_bias, next_theta}, stream);
 }
 
 extern "C" int caphn_abi_version(void) { return 1; }

@@ -91,6 +91,10 @@ int caphn_hyper_acts_floats(const caphn_hyper_desc* d);
 int caphn_hyper_forward(const caphn_hyper_desc* d, const float* x, float* theta, float* acts,
                         caphn_stream_t stream);
 
+/* Only hn_base and the heads' first layers: fills acts (x, a0, base, a_i) without streaming the second layers.
+ * Used with caphn_adam_rank_gemv_f32 to produce the NEXT step's theta during the optimiser pass. */
+int caphn_hyper_forward_acts(const caphn_hyper_desc* d, const float* x, float* acts, caphn_stream_t stream);
+
 /* Gradient sinks of caphn_hyper_backward.  Any pointer may be NULL (that gradient is skipped),
  * except that the chain needs what lies downstream of a requested gradient.  The second-layer
  * weight gradient dW2_i = dtheta_i (x) a_i is rank-1 and is only materialised when g_w2[i] != NULL
@@ -219,6 +223,13 @@ int caphn_adam_dense_f32(size_t n, float* p, float* m, float* v, const float* g,
 int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, float* v,
                         const float* gfac, size_t ldg, const float* afac, size_t lda,
                         const float* coef, const caphn_adam_hparams* hp, caphn_stream_t stream);
+/* Same update, and while the updated row W'[row,:] is still in registers also the next forward GEMV
+ * next_theta[row] = W'[row,:] . next_a + next_bias[row]   (next_bias must already hold its updated value):
+ * the following step's caphn_hyper_forward for this head needs no HBM pass of its own. */
+int caphn_adam_rank_gemv_f32(int R, int rows, int k, float* W, float* m, float* v,
+                             const float* gfac, size_t ldg, const float* afac, size_t lda,
+                             const float* coef, const caphn_adam_hparams* hp,
+                             const float* next_a, const float* next_bias, float* next_theta, caphn_stream_t stream);
 /* dense outer product out[rows,k] = g[rows] (x) a[k]  (module API: torch optimisers want dW2 dense) */
 int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out, caphn_stream_t stream);
 

@@ -317,3 +317,38 @@ def test_hypernet_cc_front_ends(mode):
     out = net.validation_step(tb, 0)
     assert set(out) == {"val_loss", "val_loss with TF"} and abs(float(out["val_loss with TF"]) - float(ref)) < 3e-6
     assert len(net.configure_optimizers()[0][0].param_groups[0]["params"]) > 10
+
+
+@pytest.mark.parametrize("name", ["gru_tiny_cc", "gru_tiny_flickr", "gru_odd_cc"])
+def test_next_theta_fused_into_adam_pass(name):
+    """optimizer_step(next_...) produces the next step's theta inside the rank-1 Adam pass
+    (caphn_adam_rank_gemv_f32): same trajectory as recomputing it with caphn_hyper_forward."""
+    from caphn.engine import FusedTrainer
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    feats, caps = g["features"].to(DEV), g["captions"].to(DEV)
+    xs = None if tok is not None else x.to(DEV)
+    ta = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
+    tb = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
+    la, lb = [], []
+    for i in range(5):
+        la.append(float(ta.step(feats, caps, x_style=xs, style_token=tok)[0]))
+        lb.append(float(tb.step(feats, caps, x_style=xs, style_token=tok, next_x_style=xs, next_style_token=tok)[0]))
+        if i < 4:
+            assert tb._next_key is not None
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
+    # the prefetched theta equals a fresh hypernet forward on the updated parameters
+    hp = {n: tb._owned[n].data for n in tb.shape.param_names() if n in tb._owned}
+    for i in range(tb._nh):
+        hp[f"hn_heads.{i}.2.weight"] = tb.W2[i].data
+    from caphn import ops
+    xin = tb._view(tb.flat_p, "captioner.embed.weight")[tok] if tok is not None else xs
+    fresh, _ = ops.hyper_forward(tb.shape, hp, xin)
+    assert maxdiff(fresh.cpu(), tb._theta_next.cpu()) < 2e-6
+    # a different input invalidates the prefetch
+    other = 5 if tok is not None else None
+    xo = None if tok is not None else torch.roll(xs, 1)
+    l_new = tb.forward_backward(feats, caps, x_style=xo, style_token=other)
+    l_ref = ta.forward_backward(feats, caps, x_style=xo, style_token=other)
+    assert abs(float(l_new[0]) - float(l_ref[0])) < 1e-4
