@@ -72,6 +72,9 @@ SIGNATURES = {
                                                 C.c_char_p, c_fp, c_fp, c_fp, c_fp]),
     "caphn_decoder_backward": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
                                          c_fp, c_fp, C.POINTER(DecoderGrads), c_fp, c_fp]),
+    "caphn_decoder_hyper_backward": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
+                                               c_fp, c_fp, C.POINTER(DecoderGrads), c_fp,
+                                               C.POINTER(HyperDesc), c_fp, C.POINTER(HyperGrads), c_fp, c_fp]),
     "caphn_ce_workspace_bytes": (C.c_size_t, [C.c_int]),
     "caphn_cross_entropy_fwd_bwd": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
     "caphn_embedding_gather": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
@@ -80,6 +83,9 @@ SIGNATURES = {
     "caphn_sumsq_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp]),
     "caphn_rank_sumsq_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, C.c_size_t, c_fp, C.c_size_t,
                                        c_fp, c_fp, c_fp]),
+    "caphn_rank_sumsq_multi_f32": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                                             C.POINTER(C.c_size_t), c_fp, c_fp, c_fp]),
     "caphn_clip_coef": (C.c_int, [C.c_int, c_fp, c_fp, C.c_double, C.c_double, c_fp, c_fp]),
     "caphn_adam_dense_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp, c_fp, c_fp, C.POINTER(AdamHParams), c_fp]),
     "caphn_adam_rank_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_size_t,

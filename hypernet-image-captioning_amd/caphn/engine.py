@@ -214,7 +214,6 @@ class FusedTrainer:
         buf["loss"].copy_(lib_loss)
         dtheta = self.flat_g[:self.theta_size]
         grads = self._dec_tensors(dtheta, grads=True)
-        ops.decoder_backward(dims, params, features, captions, dlogits, grads, buf["ws"])
         hg = {n: self._view(self.flat_g, n) for n in self.offs if n.startswith("hn_")}
         if self._hyper_ws is None:
             import ctypes as C
@@ -222,13 +221,14 @@ class FusedTrainer:
             d = ops._hyper_desc(self.shape, hp)
             self._hyper_ws = torch.empty(L.load().caphn_hyper_backward_workspace_bytes(C.byref(d)),
                                          dtype=torch.uint8, device=self.dev)
+        # decoder backward with the hypernet VJP hooked in: it starts on a side stream as soon as dtheta is
+        # complete and streams the 576 MB of second-layer weights beside the attention / feature_fc chain
+        gx = ops.decoder_hyper_backward(dims, params, features, captions, dlogits, grads, buf["ws"],
+                                        self.shape, hp, self._acts, hg, self._hyper_ws,
+                                        want_x=style_token is not None)
         work = None
         if style_token is None:
-            # the decoder part of the arena is final: start its all-reduce so it overlaps the
-            # hypernet VJP, which streams the 576 MB of second-layer weights
             work = dp.all_reduce_dense(self.flat_g[self._hyper_small_end:], self.group, async_op=True)
-        gx = ops.hyper_backward(self.shape, hp, dtheta, self._acts, hg, want_x=style_token is not None,
-                                ws=self._hyper_ws)
         if style_token is not None:
             # Flickr path: the style row of the embedding also feeds the hypernet -- add its VJP to the
             # embedding gradient before that gradient is reduced
@@ -271,9 +271,9 @@ class FusedTrainer:
         for i, (k, w) in enumerate(self.shape.heads):
             ao, an = self._acts_layout[f"a{i}"]
             gi, ai = gfac[:, o:o + w], acts_all[:, ao:ao + an]
-            ops.rank_sumsq(gi, ai, self._acc)
             segs.append((gi, ai, o, w, ao, an))
             o += w
+        ops.rank_sumsq_multi([(s[0], s[1]) for s in segs], self._acc)
         ops.clip_coef(part, self._acc, self.max_norm, 1.0 / R, out=self._coef)
         step = max(self.step_count, 1)
         ops.adam_dense(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self._coef, self.lr, step,

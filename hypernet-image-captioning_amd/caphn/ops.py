@@ -357,6 +357,48 @@ def rank_sumsq(gfac: torch.Tensor, afac: torch.Tensor, acc: torch.Tensor) -> Non
             "caphn_rank_sumsq_f32")
 
 
+def rank_sumsq_multi(pairs, acc: torch.Tensor, ws: Optional[torch.Tensor] = None) -> None:
+    """acc[0] += sum over (gfac [R,rows], afac [R,k]) pairs of || sum_r gfac[r] (x) afac[r] ||_F^2, one launch."""
+    lib = L.load()
+    n = len(pairs)
+    R = pairs[0][0].shape[0]
+    if ws is None:
+        ws = torch.empty(2 * R * R * n, dtype=torch.float64, device=acc.device)
+    rows = (C.c_int * n)(*[g.shape[1] for g, _ in pairs])
+    ks = (C.c_int * n)(*[a.shape[1] for _, a in pairs])
+    gp = (C.c_void_p * n)(*[g.data_ptr() for g, _ in pairs])
+    ap = (C.c_void_p * n)(*[a.data_ptr() for _, a in pairs])
+    ldg = (C.c_size_t * n)(*[g.stride(0) for g, _ in pairs])
+    lda = (C.c_size_t * n)(*[a.stride(0) for _, a in pairs])
+    L.check(lib.caphn_rank_sumsq_multi_f32(R, n, rows, ks, gp, ldg, ap, lda, L.ptr(acc, torch.float64),
+                                           L.ptr(ws, torch.float64), L.stream_ptr()), "caphn_rank_sumsq_multi_f32")
+
+
+def decoder_hyper_backward(dims: DecDims, params, features, captions, dlogits, grads, ws,
+                           shape: HyperShape, hyper_params, acts, hyper_grads, hyper_ws, want_x: bool = False):
+    """decoder_backward + hyper_backward in one call; the hypernet VJP overlaps the decoder's tail.
+    The cell gradients in `grads` must be consecutive views of one dtheta buffer (theta order)."""
+    lib = L.load()
+    cd = dims.c()
+    ps = _dec_struct(L.DecoderParams, dims, params)
+    gs = _dec_struct(L.DecoderGrads, dims, grads)
+    hd = _hyper_desc(shape, hyper_params)
+    g = L.HyperGrads()
+    gp = lambda n: (L.ptr(hyper_grads[n]).value if n in hyper_grads and hyper_grads[n] is not None else None)
+    g.g_base_w0 = gp("hn_base.0.weight"); g.g_base_b0 = gp("hn_base.0.bias")
+    g.g_base_w2 = gp("hn_base.2.weight"); g.g_base_b2 = gp("hn_base.2.bias")
+    for i in range(len(shape.heads)):
+        g.g_w1[i] = gp(f"hn_heads.{i}.0.weight"); g.g_b1[i] = gp(f"hn_heads.{i}.0.bias")
+        g.g_w2[i] = gp(f"hn_heads.{i}.2.weight"); g.g_b2[i] = gp(f"hn_heads.{i}.2.bias")
+    gx = _f32(shape.he, device=dlogits.device) if want_x else None
+    g.g_x = gx.data_ptr() if gx is not None else None
+    L.check(lib.caphn_decoder_hyper_backward(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64),
+                                             L.ptr(dlogits), None, C.byref(gs), C.c_void_p(ws.data_ptr()),
+                                             C.byref(hd), L.ptr(acts), C.byref(g), C.c_void_p(hyper_ws.data_ptr()),
+                                             L.stream_ptr()), "caphn_decoder_hyper_backward")
+    return gx
+
+
 def clip_coef(partial: torch.Tensor, extra: Optional[torch.Tensor], max_norm: float, scale: float,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = L.load()

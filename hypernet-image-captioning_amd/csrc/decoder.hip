@@ -260,10 +260,34 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     return caphn_launch_status();
 }
 
+struct HyperHook { const caphn_hyper_desc* hd; const float* acts; const caphn_hyper_grads* hg; void* ws; };
+static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decoder_params* p,
+                                 const float* features, const int64_t* captions, float* dlogits, const float* dalphas,
+                                 const caphn_decoder_grads* g, void* ws_, const HyperHook* hook, caphn_stream_t stream);
 extern "C" int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_decoder_params* p,
                                       const float* features, const int64_t* captions,
                                       float* dlogits, const float* dalphas,
                                       const caphn_decoder_grads* g, void* ws_, caphn_stream_t stream) {
+    return decoder_backward_impl(d, p, features, captions, dlogits, dalphas, g, ws_, nullptr, stream);
+}
+extern "C" int caphn_decoder_hyper_backward(const caphn_decoder_dims* d, const caphn_decoder_params* p,
+                                            const float* features, const int64_t* captions,
+                                            float* dlogits, const float* dalphas,
+                                            const caphn_decoder_grads* g, void* ws_,
+                                            const caphn_hyper_desc* hd, const float* acts, const caphn_hyper_grads* hg, void* hyper_ws,
+                                            caphn_stream_t stream) {
+    if (!hd || !acts || !hg || !hyper_ws || !g) return CAPHN_EINVAL;
+    const size_t NG = d && d->cell == CAPHN_CELL_LSTM ? 4 : 3;
+    if (d) {   // dtheta must be one contiguous block in theta order
+        const size_t GH = NG * d->H, EF = (size_t)d->E + d->F;
+        if (g->w_hh != g->w_ih + GH * EF || g->b_ih != g->w_hh + GH * d->H || g->b_hh != g->b_ih + GH) return CAPHN_EINVAL;
+    }
+    HyperHook hook{hd, acts, hg, hyper_ws};
+    return decoder_backward_impl(d, p, features, captions, dlogits, dalphas, g, ws_, &hook, stream);
+}
+static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decoder_params* p,
+                                 const float* features, const int64_t* captions, float* dlogits, const float* dalphas,
+                                 const caphn_decoder_grads* g, void* ws_, const HyperHook* hook, caphn_stream_t stream) {
     if (!dims_ok(d) || !p || !features || !captions || !dlogits || !g || !ws_) return CAPHN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = layout(d);
@@ -330,6 +354,12 @@ extern "C" int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_d
         RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, b2));
         if (hipMemsetAsync(g->embed_w, 0, sizeof(float) * (size_t)V * E, b2) != hipSuccess) return CAPHN_ELAUNCH;
         RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, b2));
+    }
+    if (hook) {
+        // dL/dtheta = [dW_ih | dW_hh | db_ih | db_hh] is complete once branches 1 and 2 are: the hypernet VJP
+        // (HBM-bound transposed GEMV over the second-layer weights) runs on branch 1 beside the main chain
+        RUN(sd.dep(sd.s(2), sd.s(1), 0));
+        RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, sd.s(1)));
     }
     // main -- attention parameters, then the chain into f and feature_fc
     AttnGradArgs ag;

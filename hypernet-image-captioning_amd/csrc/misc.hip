@@ -135,17 +135,20 @@ __global__ __launch_bounds__(256) void sumsq_kernel(size_t n, const float* __res
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// Gram matrices of R rank-1 factors: ws[r*R+s] = g_r . g_s ; ws[R*R + r*R+s] = a_r . a_s
-// grid (R*R, 2, chunks): every block reduces one chunk and adds it with one fp64 atomic (ws zeroed first)
+// Gram matrices of R rank-1 factors, several (gfac, afac) pairs per launch:
+// ws[job][which][r*R+s] = g_r . g_s (which = 0) or a_r . a_s (which = 1).
+// grid (R*R, 2*njobs, chunks): every block reduces one chunk and adds it with one fp64 atomic (ws zeroed first)
 constexpr int GRAM_CHUNKS = 64;
-__global__ __launch_bounds__(256) void rank_gram_kernel(int R, int rows, int k, const float* __restrict__ gfac, size_t ldg,
-                                                        const float* __restrict__ afac, size_t lda, double* __restrict__ ws) {
+struct GramJob { const float* gfac; size_t ldg; const float* afac; size_t lda; int rows, k; };
+struct GramJobs { GramJob j[CAPHN_MAX_HEADS]; int n; };
+__global__ __launch_bounds__(256) void rank_gram_kernel(int R, GramJobs jobs, double* __restrict__ ws) {
     __shared__ double red[4];
-    const int pair = blockIdx.x, which = blockIdx.y;      // which: 0 = g, 1 = a
+    const int pair = blockIdx.x, job = blockIdx.y >> 1, which = blockIdx.y & 1;
+    const GramJob& J = jobs.j[job];
     const int r = pair / R, s = pair % R;
-    const float* u = which ? afac + (size_t)r * lda : gfac + (size_t)r * ldg;
-    const float* v = which ? afac + (size_t)s * lda : gfac + (size_t)s * ldg;
-    const int n = which ? k : rows;
+    const float* u = which ? J.afac + (size_t)r * J.lda : J.gfac + (size_t)r * J.ldg;
+    const float* v = which ? J.afac + (size_t)s * J.lda : J.gfac + (size_t)s * J.ldg;
+    const int n = which ? J.k : J.rows;
     const int per = (n + GRAM_CHUNKS - 1) / GRAM_CHUNKS;
     const int i0 = blockIdx.z * per, i1 = min(n, i0 + per);
     if (i0 >= i1) return;
@@ -154,12 +157,13 @@ __global__ __launch_bounds__(256) void rank_gram_kernel(int R, int rows, int k, 
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&ws[(size_t)which * R * R + pair], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) atomicAdd(&ws[((size_t)job * 2 + which) * R * R + pair], red[0] + red[1] + red[2] + red[3]);
 }
-__global__ void rank_gram_finish_kernel(int R, const double* __restrict__ ws, double* acc) {
+__global__ void rank_gram_finish_kernel(int R, int njobs, const double* __restrict__ ws, double* acc) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double t = 0.0;
-        for (int i = 0; i < R * R; ++i) t += ws[i] * ws[R * R + i];
+        for (int j = 0; j < njobs; ++j)
+            for (int i = 0; i < R * R; ++i) t += ws[((size_t)j * 2) * R * R + i] * ws[((size_t)j * 2 + 1) * R * R + i];
         acc[0] += t;
     }
 }
@@ -400,9 +404,27 @@ extern "C" int caphn_rank_sumsq_f32(int R, int rows, int k, const float* gfac, s
                                     double* acc, double* ws, caphn_stream_t stream) {
     if (R <= 0 || R > RMAX || rows <= 0 || k <= 0 || !gfac || !afac || !acc || !ws) return CAPHN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    GramJobs jobs; jobs.n = 1;
+    jobs.j[0] = GramJob{gfac, ldg, afac, lda, rows, k};
     if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * R * R, s) != hipSuccess) return CAPHN_ELAUNCH;
-    hipLaunchKernelGGL(rank_gram_kernel, dim3(R * R, 2, GRAM_CHUNKS), dim3(256), 0, s, R, rows, k, gfac, ldg, afac, lda, ws);
-    hipLaunchKernelGGL(rank_gram_finish_kernel, dim3(1), dim3(64), 0, s, R, ws, acc);
+    hipLaunchKernelGGL(rank_gram_kernel, dim3(R * R, 2, GRAM_CHUNKS), dim3(256), 0, s, R, jobs, ws);
+    hipLaunchKernelGGL(rank_gram_finish_kernel, dim3(1), dim3(64), 0, s, R, 1, ws, acc);
+    return caphn_launch_status();
+}
+extern "C" int caphn_rank_sumsq_multi_f32(int R, int n, const int* rows, const int* k, const float* const* gfac, const size_t* ldg,
+                                          const float* const* afac, const size_t* lda, double* acc, double* ws,
+                                          caphn_stream_t stream) {
+    if (R <= 0 || R > RMAX || n <= 0 || n > CAPHN_MAX_HEADS || !rows || !k || !gfac || !ldg || !afac || !lda || !acc || !ws)
+        return CAPHN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GramJobs jobs; jobs.n = n;
+    for (int i = 0; i < n; ++i) {
+        if (rows[i] <= 0 || k[i] <= 0 || !gfac[i] || !afac[i]) return CAPHN_EINVAL;
+        jobs.j[i] = GramJob{gfac[i], ldg[i], afac[i], lda[i], rows[i], k[i]};
+    }
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * R * R * n, s) != hipSuccess) return CAPHN_ELAUNCH;
+    hipLaunchKernelGGL(rank_gram_kernel, dim3(R * R, 2 * n, GRAM_CHUNKS), dim3(256), 0, s, R, jobs, ws);
+    hipLaunchKernelGGL(rank_gram_finish_kernel, dim3(1), dim3(64), 0, s, R, n, ws, acc);
     return caphn_launch_status();
 }
 extern "C" int caphn_clip_coef(int nparts, const double* partial, const double* extra, double max_norm, double scale,
@@ -440,7 +462,7 @@ static int adam_rank_launch(int R, int rows, int k, float* W, float* m, float* v
     if (nk.a && g_tune_adam == 3) {
         // fused next-theta GEMV: the per-row shuffle reduction would sit between one row's stores and the next
         // row's loads; with two rows per iteration both rows' loads are issued before either reduction
-        ADAM_RANK_LAUNCH(2, true, true);
+        if (k > 256) ADAM_RANK_LAUNCH(2, true, true); else ADAM_RANK_LAUNCH(4, true, true);   // same bytes in flight
     } else
     switch (g_tune_adam) {      // default 3: one row per wave iteration, non-temporal loads and stores
         case 0: ADAM_RANK_LAUNCH(1, false, false); break;

@@ -174,6 +174,16 @@ int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_decoder_para
                            float* dlogits, const float* dalphas,
                            const caphn_decoder_grads* g, void* ws, caphn_stream_t stream);
 
+/* caphn_decoder_backward followed by caphn_hyper_backward, with the hypernet VJP started on a side stream as
+ * soon as dL/dtheta (g->w_ih, w_hh, b_ih, b_hh -- which must be contiguous in theta order, i.e. g->w_ih is
+ * dtheta) is complete, so its 576 MB transposed GEMV overlaps the attention / feature_fc backward chain. */
+int caphn_decoder_hyper_backward(const caphn_decoder_dims* d, const caphn_decoder_params* p,
+                                 const float* features, const int64_t* captions,
+                                 float* dlogits, const float* dalphas,
+                                 const caphn_decoder_grads* g, void* ws,
+                                 const caphn_hyper_desc* hd, const float* acts, const caphn_hyper_grads* hg, void* hyper_ws,
+                                 caphn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Loss: F.cross_entropy(logits.view(-1,V), caps.view(-1), ignore_index)   [hypernet_attention.py:183,
  * cc_train_hypernet.py:153].  Writes the mean loss to loss_out[0], the number of non-ignored
@@ -204,6 +214,10 @@ int caphn_sumsq_f32(size_t n, const float* x, double* partial, caphn_stream_t st
  * afac [R,k] (lda).  Adds the value (double) to acc[0].  ws: R*R*2 doubles. */
 int caphn_rank_sumsq_f32(int R, int rows, int k, const float* gfac, size_t ldg, const float* afac, size_t lda,
                          double* acc, double* ws, caphn_stream_t stream);
+/* The same for n (gfac, afac) pairs -- one per hypernet head -- in a single launch; host arrays of length n.
+ * acc[0] += sum over pairs.  ws: n*R*R*2 doubles. */
+int caphn_rank_sumsq_multi_f32(int R, int n, const int* rows, const int* k, const float* const* gfac, const size_t* ldg,
+                               const float* const* afac, const size_t* lda, double* acc, double* ws, caphn_stream_t stream);
 /* coef_out[0] = scale * min(1, max_norm / (scale * sqrt(sum partial + extra[0]) + 1e-6));
  * coef_out[1] = scale * sqrt(...) (the total norm).  `scale` = 1/world_size. */
 int caphn_clip_coef(int nparts, const double* partial, const double* extra, double max_norm, double scale,
