@@ -32,7 +32,10 @@ def all_gather_factors(pack_local: torch.Tensor, out: Optional[torch.Tensor] = N
     if R == 1:
         out[0].copy_(pack_local)
         return out
-    dist.all_gather_into_tensor(out.view(-1), pack_local.contiguous(), group=group)
+    if dist.get_backend(group) == "gloo":          # gloo has no all_gather_into_tensor
+        dist.all_gather([out[r] for r in range(R)], pack_local.contiguous(), group=group)
+    else:
+        dist.all_gather_into_tensor(out.view(-1), pack_local.contiguous(), group=group)
     return out
 
 
