@@ -91,14 +91,6 @@ __device__ __forceinline__ void gemv_rows_wave(const GemvJob& J, int wave_g, int
     }
 }
 
-template <int RB, bool NTL>
-__device__ __forceinline__ void gemv_rows_wave_k(const GemvJob& J, int wave_g, int nwaves, int lane) {
-    if (J.k <= 256) gemv_rows_wave<1, RB, NTL>(J, wave_g, nwaves, lane);
-    else if (J.k <= 512) gemv_rows_wave<2, RB, NTL>(J, wave_g, nwaves, lane);
-    else if (J.k <= 1024) gemv_rows_wave<4, RB, NTL>(J, wave_g, nwaves, lane);
-    else gemv_rows_wave<8, RB, NTL>(J, wave_g, nwaves, lane);
-}
-
 // 8 lanes per row: any k, vector or scalar loads
 __device__ __forceinline__ void gemv_rows_oct(const GemvJob& J, int lb, int tid) {
     const int grp = tid >> 3, s = tid & 7;
@@ -125,30 +117,38 @@ __device__ __forceinline__ void gemv_rows_oct(const GemvJob& J, int lb, int tid)
     }
 }
 
-template <int RB, bool NTL>
+// QMAX (chunks of 256 columns per row) is a KERNEL template parameter picked on the host from the widest job:
+// with all widths inlined into one kernel the register allocation is that of QMAX = 8 (185-256 VGPRs, 1-2
+// waves/SIMD) whatever k is; per-width kernels need ~40-70 VGPRs and keep 8 waves/SIMD in flight.
+template <int RB, bool NTL, int QMAX>
 __global__ __launch_bounds__(256) void gemv_fwd_kernel(GemvJobs jobs) {
     int ji = 0;
     for (int i = 1; i < jobs.n; ++i) if ((int)blockIdx.x >= jobs.j[i].block0) ji = i;
     const GemvJob& J = jobs.j[ji];
     const int lb = blockIdx.x - J.block0, tid = threadIdx.x;
-    if (J.vec && J.k >= 128 && J.k <= 2048) {
+    if (J.vec && J.k >= 128 && J.k <= 256 * QMAX) {
         const int wave_g = lb * 4 + (tid >> 6), nwaves = J.nblocks * 4, lane = tid & 63;
-        gemv_rows_wave_k<RB, NTL>(J, wave_g, nwaves, lane);
+        gemv_rows_wave<QMAX, RB, NTL>(J, wave_g, nwaves, lane);
     } else {
         gemv_rows_oct(J, lb, tid);
     }
 }
 }  // namespace
-int g_tune_gemv = 1;      // 0: RB=4 plain loads  1: RB=4 non-temporal loads (default: 115 vs 126 us)  2/3: RB=8 (3x slower)
-static void launch_gemv_fwd(const GemvJobs& jobs, int nblocks, hipStream_t s) {
-    switch (g_tune_gemv) {
-        case 0: hipLaunchKernelGGL((gemv_fwd_kernel<4, false>), dim3(nblocks), dim3(256), 0, s, jobs); break;
-        case 2: hipLaunchKernelGGL((gemv_fwd_kernel<8, false>), dim3(nblocks), dim3(256), 0, s, jobs); break;
-        case 3: hipLaunchKernelGGL((gemv_fwd_kernel<8, true>), dim3(nblocks), dim3(256), 0, s, jobs); break;
-        default: hipLaunchKernelGGL((gemv_fwd_kernel<4, true>), dim3(nblocks), dim3(256), 0, s, jobs); break;
-    }
-}
+int g_tune_gemv = 1;      // 0: plain loads  1 (default): non-temporal loads (115 vs 126 us on the canonical hypernet)
 namespace {
+template <int QMAX>
+static void launch_gemv_fwd_q(const GemvJobs& jobs, int nblocks, hipStream_t s) {
+    if (g_tune_gemv == 0) hipLaunchKernelGGL((gemv_fwd_kernel<4, false, QMAX>), dim3(nblocks), dim3(256), 0, s, jobs);
+    else hipLaunchKernelGGL((gemv_fwd_kernel<4, true, QMAX>), dim3(nblocks), dim3(256), 0, s, jobs);
+}
+static void launch_gemv_fwd(const GemvJobs& jobs, int nblocks, hipStream_t s) {
+    int kmax = 0;
+    for (int i = 0; i < jobs.n; ++i) if (jobs.j[i].vec && jobs.j[i].k <= 2048) kmax = std::max(kmax, jobs.j[i].k);
+    if (kmax <= 256) launch_gemv_fwd_q<1>(jobs, nblocks, s);
+    else if (kmax <= 512) launch_gemv_fwd_q<2>(jobs, nblocks, s);
+    else if (kmax <= 1024) launch_gemv_fwd_q<4>(jobs, nblocks, s);
+    else launch_gemv_fwd_q<8>(jobs, nblocks, s);
+}
 
 // ---------------------------------------------------------------- backward: y = W^T d (W [rows,k])
 // large matrices: lanes own column chunks, waves own rows; per-block partial sums -> ws, then reduce
@@ -196,17 +196,15 @@ __device__ __forceinline__ void gemv_t_wave(const GemvTJob& J, int lb, int tid, 
         J.partial[(size_t)lb * J.k + c] = red[c] + red[J.k + c] + red[2 * J.k + c] + red[3 * J.k + c];
 }
 
+template <int QMAX>
 __global__ __launch_bounds__(256) void gemv_t_partial_kernel(GemvTJobs jobs) {
     extern __shared__ __attribute__((aligned(16))) float red[];
     int ji = 0;
     for (int i = 1; i < jobs.n; ++i) if ((int)blockIdx.x >= jobs.j[i].block0) ji = i;
     const GemvTJob& J = jobs.j[ji];
     const int lb = blockIdx.x - J.block0, tid = threadIdx.x;
-    if (J.vec && J.k <= 2048) {
-        if (J.k <= 256) gemv_t_wave<1>(J, lb, tid, red);
-        else if (J.k <= 512) gemv_t_wave<2>(J, lb, tid, red);
-        else if (J.k <= 1024) gemv_t_wave<4>(J, lb, tid, red);
-        else gemv_t_wave<8>(J, lb, tid, red);
+    if (J.vec && J.k <= 256 * QMAX) {
+        gemv_t_wave<QMAX>(J, lb, tid, red);
     } else {
         // generic: thread per column, this block's row range
         const int per = (J.rows + J.nblocks - 1) / J.nblocks;
@@ -421,7 +419,13 @@ extern "C" int caphn_hyper_backward(const caphn_hyper_desc* d, const float* dthe
             J.block0 = b0; J.nblocks = W.nblocks[i]; b0 += J.nblocks;
             kmax = std::max(kmax, J.k);
         }
-        hipLaunchKernelGGL(gemv_t_partial_kernel, dim3(b0), dim3(256), sizeof(float) * 4 * kmax, s, jobs);
+        int kv = 0;
+        for (int i = 0; i < nh; ++i) if (jobs.j[i].vec && jobs.j[i].k <= 2048) kv = std::max(kv, jobs.j[i].k);
+        const size_t shm = sizeof(float) * 4 * kmax;
+        if (kv <= 256) hipLaunchKernelGGL(gemv_t_partial_kernel<1>, dim3(b0), dim3(256), shm, s, jobs);
+        else if (kv <= 512) hipLaunchKernelGGL(gemv_t_partial_kernel<2>, dim3(b0), dim3(256), shm, s, jobs);
+        else if (kv <= 1024) hipLaunchKernelGGL(gemv_t_partial_kernel<4>, dim3(b0), dim3(256), shm, s, jobs);
+        else hipLaunchKernelGGL(gemv_t_partial_kernel<8>, dim3(b0), dim3(256), shm, s, jobs);
         // dz_i = da_i * lrelu'(a_i)  (also the first-layer bias grad)
         ReduceJobs rj; rj.n = nh;
         for (int i = 0; i < nh; ++i) {

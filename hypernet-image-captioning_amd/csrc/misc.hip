@@ -297,18 +297,17 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
         }
     }
 }
-template <int RB, bool NTL, bool NTS>
+// QMAX is a kernel template parameter chosen on the host (see gemv_fwd_kernel in hyper.hip: with every width
+// inlined the kernel allocated 255 VGPRs and ran at 1-2 waves/SIMD).
+template <int RB, bool NTL, bool NTS, int QMAX>
 __global__ __launch_bounds__(256) void adam_rank_kernel(int R, int rows, int k, float* W, float* m, float* v,
                                                         const float* gfac, size_t ldg, const float* afac, size_t lda,
                                                         const float* coef, AdamK K, int vec, NextGemv nx) {
     const float c = coef[0];
     if (K.dev) { K.lr_bc1 = K.dev[0]; K.sqrt_bc2 = K.dev[1]; }
-    if (vec && k <= 2048) {
+    if (vec && k <= 256 * QMAX) {
         const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4, lane = threadIdx.x & 63;
-        if (k <= 256) adam_rank_rows<1, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane, nx);
-        else if (k <= 512) adam_rank_rows<2, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane, nx);
-        else if (k <= 1024) adam_rank_rows<4, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane, nx);
-        else adam_rank_rows<8, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane, nx);
+        adam_rank_rows<QMAX, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane, nx);
     } else {
         const size_t n = (size_t)rows * k, stride = (size_t)gridDim.x * 256;
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -331,7 +330,8 @@ __global__ __launch_bounds__(256) void rowdot_kernel(int rows, int k, const floa
 }
 
 }  // namespace
-int g_tune_adam = 3;   // measured: 3 (non-temporal loads + stores) 503 us vs 0 (plain) 524 us on 240000x480
+int g_tune_adam = 6;   // measured on 240000x480 after the occupancy fix: 6 (non-temporal, 2 rows/iteration) 497 us,
+                       // 3 (non-temporal, 1 row) 508 us, 0 (plain) 541 us
 namespace {
 inline AdamK make_adam(const caphn_adam_hparams* hp) {
     AdamK k;
@@ -457,22 +457,20 @@ static int adam_rank_launch(int R, int rows, int k, float* W, float* m, float* v
     const AdamK K = make_adam(hp);
     const bool fused = vec && k <= 2048;
     NextGemv nk = fused ? nx : NextGemv{nullptr, nullptr, nullptr};
-#define ADAM_RANK_LAUNCH(RB, NTL, NTS) hipLaunchKernelGGL((adam_rank_kernel<RB, NTL, NTS>), dim3((unsigned)nb), dim3(256), 0, s, \
+#define ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, Q) hipLaunchKernelGGL((adam_rank_kernel<RB, NTL, NTS, Q>), dim3((unsigned)nb), dim3(256), 0, s, \
         R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, vec, nk)
-    if (nk.a && g_tune_adam == 3) {
-        // fused next-theta GEMV: the per-row shuffle reduction would sit between one row's stores and the next
-        // row's loads; with two rows per iteration both rows' loads are issued before either reduction
-        if (k > 256) ADAM_RANK_LAUNCH(2, true, true); else ADAM_RANK_LAUNCH(4, true, true);   // same bytes in flight
-    } else
-    switch (g_tune_adam) {      // default 3: one row per wave iteration, non-temporal loads and stores
-        case 0: ADAM_RANK_LAUNCH(1, false, false); break;
-        case 1: ADAM_RANK_LAUNCH(1, true, false); break;
-        case 2: ADAM_RANK_LAUNCH(1, false, true); break;
-        case 4: ADAM_RANK_LAUNCH(2, false, false); break;
-        case 5: ADAM_RANK_LAUNCH(2, true, false); break;
-        case 6: ADAM_RANK_LAUNCH(2, true, true); break;
-        default: ADAM_RANK_LAUNCH(1, true, true); break;
-    }
+#define ADAM_RANK_LAUNCH(RB, NTL, NTS) do { \
+        if (k <= 256) ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, 1); else if (k <= 512) ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, 2); \
+        else if (k <= 1024) ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, 4); else ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, 8); } while (0)
+    // caphn_tune(1, v): 0 plain loads/stores, RB=1; 3 (default) non-temporal, RB=1; 6 non-temporal, RB=2
+    if (nk.a && g_tune_adam != 0) {
+        // fused next-theta GEMV: with two (four for short rows) rows per iteration all loads are issued before
+        // either row's shuffle reduction
+        if (k > 256) ADAM_RANK_LAUNCH(2, true, true); else ADAM_RANK_LAUNCH(4, true, true);
+    } else if (g_tune_adam == 0) ADAM_RANK_LAUNCH(1, false, false);
+    else if (g_tune_adam == 3) ADAM_RANK_LAUNCH(1, true, true);
+    else ADAM_RANK_LAUNCH(2, true, true);
+#undef ADAM_RANK_LAUNCH_Q
 #undef ADAM_RANK_LAUNCH
     if (nx.a && !fused) {
         long nr = ((long)rows + 31) / 32; if (nr > 2048) nr = 2048;
