@@ -23,7 +23,7 @@ namespace {
 // Not thread-safe: one host thread drives one device (as the reference's training loop does).
 struct Side {
     hipStream_t st[3];
-    hipEvent_t fork, join[3], x[2];
+    hipEvent_t fork, join[3], x[6];
     bool ready = false, on = false;
     hipStream_t main = nullptr;
     int init() {
@@ -52,6 +52,15 @@ struct Side {
         if (!on) return CAPHN_OK;
         if (hipEventRecord(join[i], st[i]) != hipSuccess) return CAPHN_ELAUNCH;
         return hipStreamWaitEvent(main, join[i], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+    }
+    // cross-branch dependency in two halves: record slot k at the producer's current tail, wait later on the consumer
+    int record(int k, hipStream_t from) {
+        if (!on) return CAPHN_OK;
+        return hipEventRecord(x[k], from) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+    }
+    int wait(int k, hipStream_t to) {
+        if (!on) return CAPHN_OK;
+        return hipStreamWaitEvent(to, x[k], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
     }
     // `to` waits for what `from` has enqueued so far (cross-branch dependency), via event slot k
     int dep(hipStream_t from, hipStream_t to, int k) {
@@ -332,74 +341,82 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     a.rotate = g_tune_rec_rotate;
     RUN(caphn_launch_rec_bwd(a, lstm, s));
 
-    // ---- after BPTT three more independent branches (1, 2 and main); branch 0 keeps running
+    // ---- after BPTT.  Only  attn_param_grads -> df -> dY1 -> dW_fc0  is a true chain (main stream); every other
+    // product is a leaf of it.  Leaves run on branches 0-2; E0..E4 are record/wait events between streams.
+    //   E0 dctx ready (b2)   E1 dmeanf ready (b1)   E2 dWaf ready (main)   E3 dW_ih ready (b2)   E4 df ready (main)
+    hipStream_t b0 = sd.s(0), b1 = sd.s(1), b2 = sd.s(2);
     RUN(sd.forkto(1)); RUN(sd.forkto(2));
-    if (late) {
+    if (late) {   // the optimiser-only vocab gradients
         RUN(sd.forkto(0));
-        RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, sd.s(0)));
-        RUN(caphn_colsum_f32(BT, V, dlogits, V, g->out_b, cws, sd.s(0)));
+        RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, b0));
+        RUN(caphn_colsum_f32(BT, V, dlogits, V, g->out_b, cws, b0));
     }
-    // branch 1 -- recurrent weights: dW_hh = dgh^T Hprev, dU_a = duah^T Hprev, biases by column sums; init_h / init_c
-    {
-        hipStream_t b1 = sd.s(1);
-        RUN(gemm_auto(1, 0, GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, nullptr, 0, b1));
-        RUN(caphn_colsum_f32(BT, GH, dgh, GH, g->b_hh, cw1, b1));
-        RUN(gemm_auto(1, 0, H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, nullptr, 0, b1));
-        RUN(caphn_colsum_f32(BT, H, ws + w.duah, H, g->Ua_b, cw1, b1));
-        RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cw1, b1));
-        RUN(gemm_auto(1, 0, H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, nullptr, 0, b1));
-        RUN(caphn_colsum_f32(B, H, ws + w.dh0, H, g->inith_b, cw1, b1));
-        if (lstm) {
-            RUN(gemm_auto(1, 0, H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, nullptr, 0, b1));
-            RUN(caphn_colsum_f32(B, H, ws + w.dc0, H, g->initc_b, cw1, b1));
-        }
+    if (!raw) {
+        if (!g->fc0_w || !g->fc0_b || !g->fc2_w || !g->fc2_b) return CAPHN_EINVAL;
+        // b2: context path into f        b1: initial-state path into mean f
+        RUN(caphn_gemm_f32(0, 0, BT, F, GH, dgi, GH, p->w_ih + E, EF, ws + w.dctx, F, nullptr, nullptr, 0, 0, 1, b2));
+        RUN(sd.record(0, b2));
+        RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dh0, H, p->inith_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, 0, 1, b1));
+        if (lstm)
+            RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dc0, H, p->initc_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, b1));
+        RUN(sd.record(1, b1));
     }
-    // branch 2 -- input weights dW_ih[:, :E] = dgi^T Xe, dW_ih[:, E:] = dgi^T ctx; embedding gradient
-    {
-        hipStream_t b2 = sd.s(2);
-        RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, b2));
-        RUN(gemm_auto(1, 0, GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, nullptr, 0, b2));
-        RUN(gemm_auto(1, 0, GH, F, BT, dgi, GH, ws + w.ctx, F, g->w_ih + E, EF, nullptr, 0, b2));
-        RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, b2));
-        if (hipMemsetAsync(g->embed_w, 0, sizeof(float) * (size_t)V * E, b2) != hipSuccess) return CAPHN_ELAUNCH;
-        RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, b2));
-    }
-    if (hook) {
-        // dL/dtheta = [dW_ih | dW_hh | db_ih | db_hh] is complete once branches 1 and 2 are: the hypernet VJP
-        // (HBM-bound transposed GEMV over the second-layer weights) runs on branch 1 beside the main chain
-        RUN(sd.dep(sd.s(2), sd.s(1), 0));
-        RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, sd.s(1)));
-    }
-    // main -- attention parameters, then the chain into f and feature_fc
+    // main: attention parameter gradients (dWaf, partial d v_a)
     AttnGradArgs ag;
     ag.T = T; ag.P = P; ag.H = H; ag.pchunk = w.pchunk;
     ag.Waf = ws + w.Waf; ag.uah = ws + w.uah; ag.de = ws + w.de; ag.v_a = p->va_w;
     ag.dWaf = ws + w.dWaf; ag.part = ws + w.apart;
     RUN(caphn_launch_attn_param_grads(ag, B, w.npc, s));
-    RUN(caphn_colsum_f32(B * w.npc, H + 1, ws + w.apart, H + 1, ws + w.vtmp, cw0, s));
-    if (hipMemcpyAsync(g->va_w, ws + w.vtmp, sizeof(float) * H, hipMemcpyDeviceToDevice, s) != hipSuccess) return CAPHN_ELAUNCH;
-    if (hipMemcpyAsync(g->va_b, ws + w.vtmp + H, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return CAPHN_ELAUNCH;
-    RUN(gemm_auto(1, 0, H, F, BP, ws + w.dWaf, H, f, F, g->Wa_w, F, nullptr, 0, s));
-    RUN(caphn_colsum_f32(BP, H, ws + w.dWaf, H, g->Wa_b, cw0, s));
+    RUN(sd.record(2, s));
+    // b2 -- input weights dW_ih[:, :E] = dgi^T Xe, dW_ih[:, E:] = dgi^T ctx; embedding gradient
+    RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, b2));
+    RUN(gemm_auto(1, 0, GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, nullptr, 0, b2));
+    RUN(gemm_auto(1, 0, GH, F, BT, dgi, GH, ws + w.ctx, F, g->w_ih + E, EF, nullptr, 0, b2));
+    RUN(sd.record(3, b2));
+    RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, b2));
+    if (hipMemsetAsync(g->embed_w, 0, sizeof(float) * (size_t)V * E, b2) != hipSuccess) return CAPHN_ELAUNCH;
+    RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, b2));
+    // b1 -- recurrent weights dW_hh = dgh^T Hprev, dU_a = duah^T Hprev, biases by column sums; init_h / init_c
+    RUN(gemm_auto(1, 0, GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, nullptr, 0, b1));
+    RUN(caphn_colsum_f32(BT, GH, dgh, GH, g->b_hh, cw1, b1));
+    RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cw1, b1));
+    if (hook) {
+        // dL/dtheta = [dW_ih | dW_hh | db_ih | db_hh] is complete once E3 has fired: the hypernet VJP (HBM-bound
+        // transposed GEMV over the 576 MB of second-layer weights) runs here, beside the main chain
+        RUN(sd.wait(3, b1));
+        RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, b1));
+    }
+    RUN(gemm_auto(1, 0, H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, nullptr, 0, b1));
+    RUN(caphn_colsum_f32(BT, H, ws + w.duah, H, g->Ua_b, cw1, b1));
+    RUN(gemm_auto(1, 0, H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, nullptr, 0, b1));
+    RUN(caphn_colsum_f32(B, H, ws + w.dh0, H, g->inith_b, cw1, b1));
+    if (lstm) {
+        RUN(gemm_auto(1, 0, H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, nullptr, 0, b1));
+        RUN(caphn_colsum_f32(B, H, ws + w.dc0, H, g->initc_b, cw1, b1));
+    }
+    // main -- df = alpha^T dctx + dmean/P + dWaf W_a, then feature_fc backward
     if (!raw) {
-        if (!g->fc0_w || !g->fc0_b || !g->fc2_w || !g->fc2_b) return CAPHN_EINVAL;
-        // context path into f, initial-state path into mean f
-        RUN(caphn_gemm_f32(0, 0, BT, F, GH, dgi, GH, p->w_ih + E, EF, ws + w.dctx, F, nullptr, nullptr, 0, 0, 1, s));
-        RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dh0, H, p->inith_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, 0, 1, s));
-        if (lstm)
-            RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dc0, H, p->initc_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
-        // df = alpha^T dctx + dmean/P + dWaf W_a
+        RUN(sd.wait(0, s)); RUN(sd.wait(1, s));
         RUN(caphn_launch_df(B, T, P, F, ws + w.alphas, ws + w.dctx, ws + w.dmeanf, ws + w.df, s));
         RUN(caphn_gemm_f32(0, 0, BP, F, H, ws + w.dWaf, H, p->Wa_w, F, ws + w.df, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
-        // feature_fc backward
-        RUN(gemm_auto(1, 0, F, F, BP, ws + w.df, F, ws + w.Y1, F, g->fc2_w, F, nullptr, 0, s));
-        RUN(caphn_colsum_f32(BP, F, ws + w.df, F, g->fc2_b, cw0, s));
+        RUN(sd.record(4, s));
         RUN(caphn_gemm_f32(0, 0, BP, F, F, ws + w.df, F, p->fc2_w, F, ws + w.dY1, F, nullptr, ws + w.Y1, F, CAPHN_GEMM_MASK, 1, s));
         RUN(gemm_auto(1, 0, F, D, BP, ws + w.dY1, F, features, D, g->fc0_w, D, nullptr, 0, s));
         RUN(caphn_colsum_f32(BP, F, ws + w.dY1, F, g->fc0_b, cw0, s));
     }
+    // b2 (leaves of the chain) -- d v_a, d b_va, dW_a, db_Wa once dWaf exists; fc2 gradients once df exists
+    RUN(sd.wait(2, b2));
+    RUN(caphn_colsum_f32(B * w.npc, H + 1, ws + w.apart, H + 1, ws + w.vtmp, cw2, b2));
+    if (hipMemcpyAsync(g->va_w, ws + w.vtmp, sizeof(float) * H, hipMemcpyDeviceToDevice, b2) != hipSuccess) return CAPHN_ELAUNCH;
+    if (hipMemcpyAsync(g->va_b, ws + w.vtmp + H, sizeof(float), hipMemcpyDeviceToDevice, b2) != hipSuccess) return CAPHN_ELAUNCH;
+    RUN(gemm_auto(1, 0, H, F, BP, ws + w.dWaf, H, f, F, g->Wa_w, F, nullptr, 0, b2));
+    RUN(caphn_colsum_f32(BP, H, ws + w.dWaf, H, g->Wa_b, cw2, b2));
+    if (!raw) {
+        RUN(sd.wait(4, b2));
+        RUN(gemm_auto(1, 0, F, F, BP, ws + w.df, F, ws + w.Y1, F, g->fc2_w, F, nullptr, 0, b2));
+        RUN(caphn_colsum_f32(BP, F, ws + w.df, F, g->fc2_b, cw2, b2));
+    }
     RUN(sd.jointo(0)); RUN(sd.jointo(1)); RUN(sd.jointo(2));
-    (void)cw2;
     (void)captions;
     return caphn_launch_status();
 }
