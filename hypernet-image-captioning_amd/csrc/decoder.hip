@@ -99,7 +99,7 @@ inline Ws layout(const caphn_decoder_dims* d) {
     w.ctx = take(B * T * F); w.dctx = take(raw ? 0 : B * T * F);
     w.dXe = take(B * T * E); w.dWaf = take(B * P * H); w.dmeanf = take(raw ? 0 : B * F); w.df = take(raw ? 0 : B * P * F);
     w.dY1 = take(raw ? 0 : B * P * F);
-    w.pchunk = 7; w.npc = (int)((P + w.pchunk - 1) / w.pchunk);
+    w.pchunk = 1; w.npc = (int)((P + w.pchunk - 1) / w.pchunk);     // one workgroup per (caption, position)
     w.apart = take(B * w.npc * (H + 1)); w.vtmp = take(H + 1);
     size_t cs = 0;
     auto need = [&](size_t M, size_t N) { cs = std::max(cs, caphn_colsum_workspace_bytes((int)M, (int)N) / sizeof(float)); };

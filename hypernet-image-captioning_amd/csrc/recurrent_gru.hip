@@ -113,6 +113,18 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
     const KG m = kg_map(tid, H);
     const int rotU = a.rotate ? (int)(((unsigned)b * 13u) % (unsigned)H) : 0;
     const int rotW = a.rotate ? (int)(((unsigned)b * 37u) % (unsigned)GH) : 0;
+    // W_a f is t-invariant and every wave scores the same positions each step: keep this lane's Waf[p][k]
+    // (WP positions x WK column chunks) in registers for the whole loop when it fits (P <= 64, H <= 256)
+    constexpr int WP = 4, WK = 4;
+    const bool waf_regs = (P <= WP * (NT / 64)) && (H <= WK * 64);
+    float wreg[WP][WK];
+#pragma unroll
+    for (int i = 0; i < WP; ++i)
+#pragma unroll
+        for (int q = 0; q < WK; ++q) {
+            const int p = wave + i * (NT / 64), k = lane + 64 * q;
+            wreg[i][q] = (waf_regs && p < P && k < H) ? Waf_b[p * H + k] : 0.f;
+        }
     __syncthreads();
     const bool prof_on = (b == 0 && tid == 0 && a.prof != nullptr);
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = prof_on ? clock64() : 0;
@@ -125,11 +137,28 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
         __syncthreads();
         PSTAMP(0);
         // B: e_p = v_a . tanh(Waf_p + uah) + b_va   (one wave per position, shuffle reduction)
-        for (int p = wave; p < P; p += NT / 64) {
-            float s = 0.f;
-            for (int k = lane; k < H; k += 64) s += va_s[k] * caphn_tanh(Waf_b[p * H + k] + uah_s[k]);
-            s = wave_sum(s);
-            if (lane == 0) e_s[p] = s + bva;
+        if (waf_regs) {
+#pragma unroll
+            for (int i = 0; i < WP; ++i) {
+                const int p = wave + i * (NT / 64);
+                if (p < P) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int q = 0; q < WK; ++q) {
+                        const int k = lane + 64 * q;
+                        if (k < H) s += va_s[k] * caphn_tanh(wreg[i][q] + uah_s[k]);
+                    }
+                    s = wave_sum(s);
+                    if (lane == 0) e_s[p] = s + bva;
+                }
+            }
+        } else {
+            for (int p = wave; p < P; p += NT / 64) {
+                float s = 0.f;
+                for (int k = lane; k < H; k += 64) s += va_s[k] * caphn_tanh(Waf_b[p * H + k] + uah_s[k]);
+                s = wave_sum(s);
+                if (lane == 0) e_s[p] = s + bva;
+            }
         }
         __syncthreads();
         PSTAMP(1);
@@ -389,6 +418,7 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
 
 // dWaf[b,p,k] = v_k sum_t de[b,t,p] (1 - tanh^2(Waf[b,p,k] + uah[b,t,k]))
 // part[(b,pc)][k] = sum_{t, p in chunk} de tanh(.)   (-> d v_a) ; part[..][H] = sum de (-> d b_va)
+// One workgroup per (b, chunk of `pchunk` positions); threads over k.  pchunk = 1 gives B*P workgroups.
 __global__ void attn_param_grads_kernel(AttnGradArgs a) {
     const int b = blockIdx.x, pc = blockIdx.y;
     const int P = a.P, H = a.H, T = a.T;
@@ -400,6 +430,7 @@ __global__ void attn_param_grads_kernel(AttnGradArgs a) {
         for (int p = p0; p < p1; ++p) {
             const float w = a.Waf[((size_t)b * P + p) * H + k];
             float s = 0.f;
+#pragma unroll 4
             for (int t = 0; t < T; ++t) {
                 const float de = a.de[((size_t)b * T + t) * P + p];
                 const float tv = caphn_tanh(w + a.uah[((size_t)b * T + t) * H + k]);
