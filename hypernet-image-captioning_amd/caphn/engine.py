@@ -36,6 +36,10 @@ class FusedTrainer:
         self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
         self.group = group
         self.step_count = 0
+        # the loss ignores <pad> targets (ignore_index = 0): their logits / d logits rows are dead work, so the three
+        # vocab GEMMs only touch live rows.  Loss and every gradient are unchanged; logits rows of ignored targets
+        # are simply never produced (the engine does not return logits).
+        self.skip_ignored_rows = True
         dev = self.cap.fc.weight.device
         if dev.type != "cuda":
             raise CaphnError("FusedTrainer needs the model on a CUDA(HIP) device")
@@ -152,7 +156,8 @@ class FusedTrainer:
         key = (B, T, P)
         b = self._bufs.get(key)
         if b is None:
-            dims = self.cap.dec_dims(B, T, P)
+            import dataclasses
+            dims = dataclasses.replace(self.cap.dec_dims(B, T, P), rows=self.skip_ignored_rows)
             b = {"dims": dims, "ws": ops.decoder_workspace(dims, self.dev),
                  "logits": torch.empty(B, T, dims.V, dtype=torch.float32, device=self.dev),
                  "alphas": torch.empty(B, T, P, dtype=torch.float32, device=self.dev),
@@ -208,6 +213,8 @@ class FusedTrainer:
             ops.hyper_forward(self.shape, hp, x, theta=theta, acts=self._acts)
         self._next_key = None
         params = self._dec_tensors(theta, grads=False)
+        if dims.rows:
+            ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
         ops.decoder_forward(dims, params, features, captions, buf["ws"], logits=buf["logits"], alphas=buf["alphas"],
                             validate=validate)
         lib_loss, dlogits = ops.cross_entropy_fwd_bwd(buf["logits"], captions, 0, dlogits=buf["logits"])

@@ -172,6 +172,7 @@ class DecDims:
     V: int
     cell: str = "gru"        # "gru" (AttentionGru) or "lstm" (AttentionLstm)
     raw: bool = False        # True: no feature_fc, attention over the raw D-channel features (F == D)
+    rows: bool = False       # True: vocab GEMMs only touch rows with a live target (decoder_prepare_rows first)
 
     @property
     def NG(self) -> int:
@@ -179,7 +180,7 @@ class DecDims:
 
     def c(self) -> L.DecoderDims:
         return L.DecoderDims(self.B, self.T, self.P, self.D, self.F, self.E, self.H, self.V,
-                             1 if self.cell == "lstm" else 0, int(self.raw))
+                             1 if self.cell == "lstm" else 0, int(self.raw), int(self.rows))
 
     def fields(self):
         """Ordered (C struct field, parameter name) pairs this configuration uses."""
@@ -262,6 +263,14 @@ def decoder_forward(dims: DecDims, params: Dict[str, torch.Tensor], features: to
                                       L.ptr(logits), L.ptr(alphas), C.c_void_p(ws.data_ptr()), L.stream_ptr()),
             "caphn_decoder_forward")
     return logits, alphas
+
+
+def decoder_prepare_rows(dims: DecDims, targets: torch.Tensor, ignore_index: int, ws: torch.Tensor) -> None:
+    """Row map of the (b,t) positions whose target is not ignore_index, kept in the workspace (dims.rows=True)."""
+    lib = L.load()
+    cd = dims.c()
+    L.check(lib.caphn_decoder_prepare_rows(C.byref(cd), L.ptr(targets.reshape(-1), torch.int64), ignore_index,
+                                           C.c_void_p(ws.data_ptr()), L.stream_ptr()), "caphn_decoder_prepare_rows")
 
 
 def decoder_forward_sampled(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor,

@@ -9,6 +9,7 @@
 //             (K = B*T or B*P, split-K) -> attention / feature_fc chain.
 #include "common.h"
 #include "decoder_internal.h"
+#include "gemm_internal.h"
 #include <algorithm>
 
 int g_tune_rec_rotate = 1;
@@ -73,7 +74,7 @@ Side g_side;
 
 struct Ws {   // float offsets into the workspace
     size_t Y1, f, meanf, h0, c0, Waf, G, Xe, Xg, Hs, Hprev, gates, hn, Cs, Cprev, uah, alphas, idx;
-    size_t dHs, dgi, dgh, duah, de, dh0, dc0, ctx, dctx, dXe, dWaf, dmeanf, df, dY1, apart, vtmp, colws, colws_s[3], prof;
+    size_t dHs, dgi, dgh, duah, de, dh0, dc0, ctx, dctx, dXe, dWaf, dmeanf, df, dY1, apart, vtmp, colws, colws_s[3], prof, rowmap;
     size_t total;
     int npc, pchunk, NG;
 };
@@ -113,9 +114,35 @@ inline Ws layout(const caphn_decoder_dims* d) {
         for (int i = 0; i < 3; ++i) w.colws_s[i] = take(c2);
     }
     w.prof = take(64);        // 2 x 8 uint64 phase counters (forward, backward) of the recurrent kernels
+    w.rowmap = take(B * T + 4);   // int: [0] = number of valid rows, [4..] = their physical (b*T+t) indices
     w.total = o;
     (void)D;
     return w;
+}
+
+// stable compaction of the rows whose target is not ignored: map[0] = count, map[4 + j] = j-th valid row
+__global__ __launch_bounds__(1024) void valid_rows_kernel(int n, const int64_t* __restrict__ tgt, int64_t ignore, int* __restrict__ map) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + tid;
+        const int v = (i < n && tgt[i] != ignore) ? 1 : 0;
+        const unsigned long long ball = __ballot(v);
+        const int before = __popcll(ball & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(ball);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) { if (q < wave) woff += wsum[q]; tot += wsum[q]; }
+        const int base = base_s;
+        if (v) map[4 + base + woff + before] = i;
+        __syncthreads();
+        if (tid == 0) base_s = base + tot;
+        __syncthreads();
+    }
+    if (tid == 0) map[0] = base_s;
 }
 
 __global__ void build_idx_kernel(int B, int T, const int64_t* __restrict__ caps, int64_t* __restrict__ idx) {
@@ -150,8 +177,16 @@ inline int pick_splitk(int M, int N, int K) {
 
 // C = A^T-or-not . B with optional split-K (zero-fills C first when splitting)
 inline int gemm_auto(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                     float* C, int ldc, const float* bias, int flags, hipStream_t s) {
+                     float* C, int ldc, const float* bias, int flags, hipStream_t s,
+                     const int* rowmap = nullptr, int map_mode = 0) {
     int sk = pick_splitk(M, N, K);
+    if (rowmap) {      // row subset: rowmap[0] = count (device), rowmap + 4 = indices
+        if (sk > 1) {
+            if (ldc == N) { if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, s) != hipSuccess) return CAPHN_ELAUNCH; }
+            else if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, s) != hipSuccess) return CAPHN_ELAUNCH;
+        }
+        return caphn_gemm_mapped(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, sk, rowmap + 4, rowmap, map_mode, s);
+    }
     if (sk > 1 && (flags & ~CAPHN_GEMM_BIAS) == 0) {
         if (ldc == N) {
             if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, s) != hipSuccess) return CAPHN_ELAUNCH;
@@ -227,6 +262,15 @@ extern "C" size_t caphn_decoder_workspace_bytes(const caphn_decoder_dims* d) {
     return layout(d).total * sizeof(float);
 }
 
+extern "C" int caphn_decoder_prepare_rows(const caphn_decoder_dims* d, const int64_t* targets, int64_t ignore_index,
+                                          void* ws_, caphn_stream_t stream) {
+    if (!dims_ok(d) || !targets || !ws_) return CAPHN_EINVAL;
+    const Ws w = layout(d);
+    hipLaunchKernelGGL(valid_rows_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), d->B * d->T, targets,
+                       ignore_index, reinterpret_cast<int*>(static_cast<float*>(ws_) + w.rowmap));
+    return caphn_launch_status();
+}
+
 extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_decoder_params* p,
                                      const float* features, const int64_t* captions,
                                      float* logits, float* alphas, void* ws_, caphn_stream_t stream) {
@@ -263,7 +307,11 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     RUN(caphn_launch_rec_fwd(a, lstm, s));
 
     // vocab projection for all (b,t) at once      decoderlstm.py:105
-    RUN(caphn_gemm_f32(0, 1, BT, V, H, ws + w.Hs, H, p->out_w, H, logits, V, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    if (d->row_subset)     // only rows with a live target (caphn_decoder_prepare_rows)
+        RUN(caphn_gemm_mapped(0, 1, BT, V, H, ws + w.Hs, H, p->out_w, H, logits, V, p->out_b, CAPHN_GEMM_BIAS, 1,
+                              reinterpret_cast<const int*>(ws + w.rowmap) + 4, reinterpret_cast<const int*>(ws + w.rowmap), 1, s));
+    else
+        RUN(caphn_gemm_f32(0, 1, BT, V, H, ws + w.Hs, H, p->out_w, H, logits, V, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
     if (alphas)
         if (hipMemcpyAsync(alphas, ws + w.alphas, sizeof(float) * (size_t)BT * P, hipMemcpyDeviceToDevice, s) != hipSuccess)
             return CAPHN_ELAUNCH;
@@ -320,12 +368,18 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
 
     // vocab projection.  dHs = dlogits W feeds BPTT (main); dW = dlogits^T Hs and db = colsum(dlogits) are only
     // needed by the optimiser: branch 0 computes them beside the BPTT kernel, which occupies B of the 256 CUs.
+    const int* rmap = d->row_subset ? reinterpret_cast<const int*>(ws + w.rowmap) : nullptr;
     const bool late = g_tune_fork != 2;
     if (!late) {
         RUN(sd.forkto(0));
-        RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, sd.s(0)));
+        RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, sd.s(0), rmap, 2));
         RUN(caphn_colsum_f32(BT, V, dlogits, V, g->out_b, cws, sd.s(0)));
     }
+    if (rmap) {   // rows of ignored targets have d logits == 0: dHs of those rows is zero, the others are gathered
+        if (hipMemsetAsync(ws + w.dHs, 0, sizeof(float) * (size_t)BT * H, s) != hipSuccess) return CAPHN_ELAUNCH;
+        RUN(caphn_gemm_mapped(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, pick_splitk(BT, H, V),
+                              rmap + 4, rmap, 1, s));
+    } else
     RUN(gemm_auto(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, s));
 
     RecBwdArgs a;
@@ -348,7 +402,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     RUN(sd.forkto(1)); RUN(sd.forkto(2));
     if (late) {   // the optimiser-only vocab gradients
         RUN(sd.forkto(0));
-        RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, b0));
+        RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, b0, rmap, 2));
         RUN(caphn_colsum_f32(BT, V, dlogits, V, g->out_b, cws, b0));
     }
     if (!raw) {

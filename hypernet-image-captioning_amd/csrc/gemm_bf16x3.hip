@@ -46,8 +46,18 @@ struct TileS {
     static constexpr int PLANE = KC ? BMN * PITCH : BK * PITCHM;   // bf16 elements per plane
     static constexpr int ELEMS = 3 * PLANE;
 
+    // pr: physical rows (KC) ; kmap: physical row of a logical k (!KC), may be null
+    // physical rows of this thread's NV logical rows (KC operands); looked up once, not per K-slab
+    __device__ static __forceinline__ void phys_rows(int (&pr)[NV], int rows, int r0, int tid, const int* __restrict__ rmap) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int row = r0 + ((tid + 256 * i) >> 3);
+            pr[i] = (rmap && row < rows) ? rmap[row] : row;
+        }
+    }
     __device__ static __forceinline__ void load(f32x4 (&r)[NV], const float* __restrict__ G, int ld,
-                                                int rows, int K, int r0, int k0, int vec, int tid) {
+                                                int rows, int K, int r0, int k0, int vec, int tid,
+                                                const int (&pr)[NV], const int* __restrict__ kmap) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -56,7 +66,7 @@ struct TileS {
                 const int row = r0 + (idx >> 3);
                 const int k = k0 + (idx & 7) * 4;
                 if (row < rows) {
-                    const float* p = G + (size_t)row * ld + k;
+                    const float* p = G + (size_t)pr[i] * ld + k;
                     if (vec && k + 3 < K) v = *reinterpret_cast<const f32x4*>(p);
                     else {
 #pragma unroll
@@ -67,7 +77,7 @@ struct TileS {
                 const int m = r0 + (idx % (BMN / 4)) * 4;
                 const int k = k0 + idx / (BMN / 4);
                 if (k < K) {
-                    const float* p = G + (size_t)k * ld + m;
+                    const float* p = G + (size_t)(kmap ? kmap[k] : k) * ld + m;
                     if (vec && m + 3 < rows) v = *reinterpret_cast<const f32x4*>(p);
                     else {
 #pragma unroll
@@ -122,12 +132,17 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, kh = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // row subset: effective extents come from device memory (no host round trip)
+    const int* rmapA = nullptr; const int* kmap = nullptr;
+    if (g.map_mode == 1) { g.M = min(g.M, g.dev_count[0]); rmapA = g.row_map; if (m0 >= g.M) return; }
+    if (g.map_mode == 2) { g.K = min(g.K, g.dev_count[0]); kmap = g.row_map; }
 
     const int nslab_total = (g.K + BK - 1) / BK;
     int slab0 = 0, slab1 = nslab_total;
     if (g.splitk > 1) {
-        slab0 = blockIdx.z * g.slabs_per_split;
-        slab1 = min(nslab_total, slab0 + g.slabs_per_split);
+        const int sps = g.map_mode == 2 ? (nslab_total + g.splitk - 1) / g.splitk : g.slabs_per_split;
+        slab0 = blockIdx.z * sps;
+        slab1 = min(nslab_total, slab0 + sps);
         if (slab0 >= slab1) return;
     }
 
@@ -140,8 +155,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     f32x4 ra[TileA::NV], rb[TileB::NV];
-    TileA::load(ra, g.A, g.lda, g.M, g.K, m0, slab0 * BK, g.vecA, tid);
-    TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, slab0 * BK, g.vecB, tid);
+    int pra[TileA::NV], prb[TileB::NV];
+    TileA::phys_rows(pra, g.M, m0, tid, rmapA);
+    TileB::phys_rows(prb, g.N, n0, tid, nullptr);
+    TileA::load(ra, g.A, g.lda, g.M, g.K, m0, slab0 * BK, g.vecA, tid, pra, kmap);
+    TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, slab0 * BK, g.vecB, tid, prb, kmap);
     TileA::store(ra, As, tid);
     TileB::store(rb, Bs, tid);
     __syncthreads();
@@ -149,8 +167,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     for (int slab = slab0; slab < slab1; ++slab) {
         const bool more = slab + 1 < slab1;
         if (more && !(g.flags & (1 << 19))) {
-            TileA::load(ra, g.A, g.lda, g.M, g.K, m0, (slab + 1) * BK, g.vecA, tid);
-            TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, (slab + 1) * BK, g.vecB, tid);
+            TileA::load(ra, g.A, g.lda, g.M, g.K, m0, (slab + 1) * BK, g.vecA, tid, pra, kmap);
+            TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, (slab + 1) * BK, g.vecB, tid, prb, kmap);
         }
         const int nks = (g.K - slab * BK) > 16 ? 2 : 1;      // skip the all-zero second k-step of a short tail
 #pragma unroll
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                 const int row = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row >= g.M) continue;
                 float v = acc[a][b][r] + bv;
-                float* c = g.C + (size_t)row * g.ldc + col;
+                float* c = g.C + (size_t)(rmapA ? rmapA[row] : row) * g.ldc + col;
                 if ((g.flags & (1 << 17)) && v != 12345.678f) continue;      // ablation: no epilogue stores
                 if (atomic) { atomicAdd(c, v); continue; }
                 if (g.flags & CAPHN_GEMM_ACCUM) v += *c;

@@ -184,6 +184,25 @@ int launch_cfg(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 
 }  // namespace
 
+int caphn_gemm_mapped(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                      float* C, int ldc, const float* bias, int flags, int splitk,
+                      const int* row_map, const int* dev_count, int map_mode, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || !row_map || !dev_count) return CAPHN_EINVAL;
+    if ((flags & CAPHN_GEMM_BIAS) && !bias) return CAPHN_EINVAL;
+    if (splitk > 1 && (flags & 0xFFFF & ~CAPHN_GEMM_BIAS)) return CAPHN_EINVAL;
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.bias = bias; g.mask = nullptr; g.ldmask = 0; g.flags = flags;
+    const int nslab = (K + 31) / 32;
+    if (splitk > nslab) splitk = nslab;
+    g.splitk = splitk > 1 ? splitk : 1;
+    g.slabs_per_split = (nslab + g.splitk - 1) / g.splitk;
+    g.vecA = caphn_aligned16(A) && (lda % 4 == 0);
+    g.vecB = caphn_aligned16(B) && (ldb % 4 == 0);
+    g.row_map = row_map; g.dev_count = dev_count; g.map_mode = map_mode;
+    return caphn_gemm_bf16x3_launch(g, ta, tb, s);      // the row subset lives in the split-bf16 back end
+}
+
 extern "C" int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
                               const float* A, int lda, const float* B, int ldb,
                               float* C, int ldc, const float* bias,
@@ -196,6 +215,7 @@ extern "C" int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.mask = mask; g.ldmask = ldmask; g.flags = flags;
+    g.row_map = nullptr; g.dev_count = nullptr; g.map_mode = 0;
     if (g_tune_gemm == 1) {          // split-bf16 back end: three bf16 planes per operand, 6 MFMAs per K=16
         const int nslab = (K + 31) / 32;
         if (splitk > nslab) splitk = nslab;

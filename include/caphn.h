@@ -125,6 +125,10 @@ typedef struct caphn_decoder_dims {
     int cell;           /* CAPHN_CELL_* ; NG = 3 (GRU) or 4 (LSTM) gate blocks of H rows */
     int raw_features;   /* 1: no feature_fc, attention runs directly over the D-channel features
                            (reference AttentionLstm, decoderlstm.py:242); then F must equal D */
+    int row_subset;     /* 1: the caller has run caphn_decoder_prepare_rows on this workspace: the vocab projection and
+                           its two backward GEMMs touch only rows whose target is not ignored by the loss (logits rows
+                           of ignored targets are left unwritten, their d logits must be zero).  For fused training;
+                           the module API, which must return every logits row, uses 0. */
 } caphn_decoder_dims;
 
 typedef struct caphn_decoder_params {   /* reference state_dict names in comments */
@@ -159,6 +163,10 @@ size_t caphn_decoder_workspace_bytes(const caphn_decoder_dims* d);
 int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_decoder_params* p,
                           const float* features, const int64_t* captions,
                           float* logits, float* alphas, void* ws, caphn_stream_t stream);
+/* Compacts the (b,t) rows whose target differs from ignore_index into a row map kept in the workspace (count stays on
+ * the device: no host synchronisation).  Call before caphn_decoder_forward / _backward with dims.row_subset = 1. */
+int caphn_decoder_prepare_rows(const caphn_decoder_dims* d, const int64_t* targets, int64_t ignore_index,
+                               void* ws, caphn_stream_t stream);
 /* Free-running / scheduled-sampling forward (validation, inference; keeps no backward state).
  * use_sampling is a HOST array of T flags: the reference's per-step draw np.random.random() < sample_prob
  * (decoderlstm.py:79-80); entry 0 is ignored (step 0 never samples).  A sampling step feeds back

@@ -47,8 +47,10 @@ def test_full_size_forward_backward(full):
     # forward logits were overwritten in place by d logits; recompute the forward for the logits check
     buf = tr._buffers(*[int(z[k]) for k in ("B", "T", "P")])
     from caphn import ops
+    import dataclasses
     params = tr._dec_tensors(tr._theta, grads=False)
-    logits, alphas = ops.decoder_forward(buf["dims"], params, feats, caps, buf["ws"])
+    full_dims = dataclasses.replace(buf["dims"], rows=False)      # every logits row, as the module API returns them
+    logits, alphas = ops.decoder_forward(full_dims, params, feats, caps, buf["ws"])
     assert abs(float(loss[0]) - float(z["loss"])) < 5e-6
     lg = logits.cpu().numpy()
     for i, (b, t) in enumerate(z["logit_rows_bt"]):
@@ -88,11 +90,13 @@ def test_full_size_step_properties(full):
     feats, caps = batch["features"].to(DEV), batch["captions"].to(DEV)
     x = torch.zeros(dims.he, device=DEV); x[3] = 1.0
     from caphn import ops
+    import dataclasses
     buf = tr._buffers(128, 20, 49)
     params = tr._dec_tensors(tr._theta, grads=False)
-    l1, a1 = ops.decoder_forward(buf["dims"], params, feats, caps, buf["ws"])
+    full_dims = dataclasses.replace(buf["dims"], rows=False)
+    l1, a1 = ops.decoder_forward(full_dims, params, feats, caps, buf["ws"])
     l1 = l1.clone()
-    l2, _ = ops.decoder_forward(buf["dims"], params, feats, caps, buf["ws"])
+    l2, _ = ops.decoder_forward(full_dims, params, feats, caps, buf["ws"])
     assert torch.equal(l1, l2)
     assert float((a1.sum(-1) - 1).abs().max()) < 1e-5
     losses = []

@@ -205,6 +205,47 @@ def test_decoder_free_running_and_scheduled_sampling(ops, name):
     assert maxdiff(l0.cpu(), g["logits"]) < 2e-6
 
 
+@pytest.mark.parametrize("name", ["gru_tiny_cc", "gru_odd_cc"])
+def test_decoder_row_subset_equals_full(ops, name):
+    """dims.rows=True (vocab GEMMs restricted to rows whose target is not <pad>): identical loss and gradients;
+    logits identical on the live rows (the others are never written)."""
+    import dataclasses
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    B, T = g["captions"].shape
+    P = g["features"].shape[1]
+    dd = dec_dims(dims, B, T, P)
+    dr = dataclasses.replace(dd, rows=True)
+    params = dec_params_from_oracle(p, g["theta"], dims, DEV)
+    feats, caps = g["features"].to(DEV), g["captions"].to(DEV).clone()
+    caps[0, -2:] = 0; caps[1, -1] = 0; caps[B - 1, 3:] = 0      # ragged captions: <pad> tails of different lengths
+    assert int((caps == 0).sum()) > 0
+    out = {}
+    for tag, d_ in (("full", dd), ("rows", dr)):
+        ws = ops.decoder_workspace(d_, DEV)
+        logits = torch.full((B, T, dims.V), 7.0, device=DEV)
+        if d_.rows:
+            ops.decoder_prepare_rows(d_, caps, 0, ws)
+        ops.decoder_forward(d_, params, feats, caps, ws, logits=logits)
+        lo, dl = ops.cross_entropy_fwd_bwd(logits, caps, 0)
+        grads = {n: torch.full(s, float("nan"), device=DEV) for n, s in d_.param_shapes().items()}
+        ops.decoder_backward(d_, params, feats, caps, dl, grads, ws)
+        out[tag] = (logits, float(lo[0]), grads)
+    live = (caps != 0)
+    assert torch.equal(out["rows"][0][live], out["full"][0][live])
+    assert float((out["rows"][0][~live] - 7.0).abs().max()) == 0.0          # untouched
+    assert out["rows"][1] == out["full"][1]
+    for n in out["full"][2]:
+        assert maxdiff(out["rows"][2][n].cpu(), out["full"][2][n].cpu()) < 2e-7, n
+    # and both agree with the oracle on these ragged captions
+    xs = p["captioner.embed.weight"][int(g["style_token"])] if "style_token" in g and int(g["style_token"]) >= 0 else g["x_style"]
+    _, _, _, _, gref = O.forward_backward(dims, p, None if xs.dim() and "x_style" not in g else xs, g["features"], caps.cpu(),
+                                          style_token=int(g["style_token"]) if int(g["style_token"]) >= 0 else None)
+    for n in out["rows"][2]:
+        if not n.startswith("gru."):
+            assert maxdiff(out["rows"][2][n].cpu(), gref["captioner." + n]) < 2e-6, n
+
+
 def test_decoder_lstm_raw_features_tiny(ops):
     """LSTM cell, attention over the raw features (no feature_fc): the reference's AttentionLstm
     (models/decoderlstm.py:188-261) with hypernet-injected weights, golden case lstm_tiny."""
