@@ -397,23 +397,23 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
 
     // ---- after BPTT.  Only  attn_param_grads -> df -> dY1 -> dW_fc0  is a true chain (main stream); every other
     // product is a leaf of it.  Leaves run on branches 0-2; E0..E4 are record/wait events between streams.
-    //   E0 dctx ready (b2)   E1 dmeanf ready (b1)   E2 dWaf ready (main)   E3 dW_ih ready (b2)   E4 df ready (main)
+    //   E2 dWaf ready (main)   E3 dW_ih ready (b2)   E4 df ready (main)
     hipStream_t b0 = sd.s(0), b1 = sd.s(1), b2 = sd.s(2);
     RUN(sd.forkto(1)); RUN(sd.forkto(2));
-    if (late) {   // the optimiser-only vocab gradients
-        RUN(sd.forkto(0));
+    const bool hold_big = late && !raw && g_tune_fork == 3;   // 3: release the two big leaves only once df exists (measured: no gain)
+    if (late) RUN(sd.forkto(0));
+    if (late && !hold_big) {   // the optimiser-only vocab gradients
         RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, b0, rmap, 2));
         RUN(caphn_colsum_f32(BT, V, dlogits, V, g->out_b, cws, b0));
     }
     if (!raw) {
         if (!g->fc0_w || !g->fc0_b || !g->fc2_w || !g->fc2_b) return CAPHN_EINVAL;
-        // b2: context path into f        b1: initial-state path into mean f
-        RUN(caphn_gemm_f32(0, 0, BT, F, GH, dgi, GH, p->w_ih + E, EF, ws + w.dctx, F, nullptr, nullptr, 0, 0, 1, b2));
-        RUN(sd.record(0, b2));
-        RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dh0, H, p->inith_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, 0, 1, b1));
+        // The chain's own small inputs stay on the chain's stream: waiting on a side-stream event here stalled
+        // the chain for ~275 us in the kernel trace although the producers had long finished.
+        RUN(caphn_gemm_f32(0, 0, BT, F, GH, dgi, GH, p->w_ih + E, EF, ws + w.dctx, F, nullptr, nullptr, 0, 0, 1, s));
+        RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dh0, H, p->inith_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, 0, 1, s));
         if (lstm)
-            RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dc0, H, p->initc_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, b1));
-        RUN(sd.record(1, b1));
+            RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dc0, H, p->initc_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
     }
     // main: attention parameter gradients (dWaf, partial d v_a)
     AttnGradArgs ag;
@@ -434,7 +434,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     RUN(gemm_auto(1, 0, GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, nullptr, 0, b1));
     RUN(caphn_colsum_f32(BT, GH, dgh, GH, g->b_hh, cw1, b1));
     RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cw1, b1));
-    if (hook) {
+    if (hook && !hold_big) {
         // dL/dtheta = [dW_ih | dW_hh | db_ih | db_hh] is complete once E3 has fired: the hypernet VJP (HBM-bound
         // transposed GEMV over the 576 MB of second-layer weights) runs here, beside the main chain
         RUN(sd.wait(3, b1));
@@ -450,10 +450,21 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     }
     // main -- df = alpha^T dctx + dmean/P + dWaf W_a, then feature_fc backward
     if (!raw) {
-        RUN(sd.wait(0, s)); RUN(sd.wait(1, s));
         RUN(caphn_launch_df(B, T, P, F, ws + w.alphas, ws + w.dctx, ws + w.dmeanf, ws + w.df, s));
         RUN(caphn_gemm_f32(0, 0, BP, F, H, ws + w.dWaf, H, p->Wa_w, F, ws + w.df, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
         RUN(sd.record(4, s));
+        if (hold_big) {
+            // The chain's small kernels are starved while big leaf kernels fill the machine (a 160-275 us stall of
+            // df_kernel in the kernel trace), so the latency-critical front of the chain runs first; the optimiser-only
+            // vocab gradients (b0) and the hypernet VJP (b1) start here, beside the two remaining chain GEMMs.
+            RUN(sd.wait(4, b0));
+            RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, b0, rmap, 2));
+            RUN(caphn_colsum_f32(BT, V, dlogits, V, g->out_b, cws, b0));
+            if (hook) {
+                RUN(sd.wait(3, b1)); RUN(sd.wait(4, b1));
+                RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, b1));
+            }
+        }
         RUN(caphn_gemm_f32(0, 0, BP, F, F, ws + w.df, F, p->fc2_w, F, ws + w.dY1, F, nullptr, ws + w.Y1, F, CAPHN_GEMM_MASK, 1, s));
         RUN(gemm_auto(1, 0, F, D, BP, ws + w.dY1, F, features, D, g->fc0_w, D, nullptr, 0, s));
         RUN(caphn_colsum_f32(BP, F, ws + w.dY1, F, g->fc0_b, cw0, s));
