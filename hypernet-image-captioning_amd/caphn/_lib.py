@@ -53,6 +53,11 @@ class AdamHParams(C.Structure):
                 ("step", C.c_int), ("dev_scalars", c_fp)]
 
 
+class SearchCfg(C.Structure):
+    _fields_ = [("n_images", C.c_int), ("beam", C.c_int), ("max_steps", C.c_int), ("zero_pad_rule", C.c_int),
+                ("lookup_first", C.c_int), ("first_token", C.c_int64), ("end_token", C.c_int64)]
+
+
 # name -> (restype, argtypes); must list every symbol include/caphn.h declares
 SIGNATURES = {
     "caphn_abi_version": (C.c_int, []),
@@ -76,6 +81,13 @@ SIGNATURES = {
     "caphn_decoder_hyper_backward": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
                                                c_fp, c_fp, C.POINTER(DecoderGrads), c_fp,
                                                C.POINTER(HyperDesc), c_fp, C.POINTER(HyperGrads), c_fp, c_fp]),
+    "caphn_decoder_search_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDims), C.POINTER(SearchCfg)]),
+    "caphn_decoder_search_begin": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), C.POINTER(SearchCfg),
+                                             c_fp, c_fp, c_fp, c_fp]),
+    "caphn_decoder_search_steps": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), C.POINTER(SearchCfg),
+                                             C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_decoder_search_result": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(SearchCfg), C.c_int, c_fp, c_fp,
+                                              c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "caphn_ce_workspace_bytes": (C.c_size_t, [C.c_int]),
     "caphn_cross_entropy_fwd_bwd": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
     "caphn_embedding_gather": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),

@@ -296,6 +296,59 @@ def decoder_forward_sampled(dims: DecDims, params: Dict[str, torch.Tensor], feat
     return logits, alphas
 
 
+def decoder_search(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor, beam: int, max_steps: int,
+                   end_token: int = 2, first_token: int = 0, greedy: bool = False, poll_every: int = 8,
+                   want_alphas: bool = False):
+    """Batched device-resident decoding.  greedy=False: beam search of HyperNet.test_step
+    (hypernet_attention.py:251-306; beam=3, max_steps=51 there).  greedy=True: AttentionGru.greedy_search
+    (models/decoderlstm.py:138-175; beam must be 1, max_steps = max_sentence).
+
+    dims.B is the number of IMAGES (dims.T is ignored); features [B, P, D].  The host looks at the device only
+    every `poll_every` steps (one 4-byte read) to stop once every image's beam has emptied.
+    Returns (seqs [B, max_steps+1] int64 starting with first_token, lengths [B], scores [B], finished [B] bool,
+    alphas [B, max_steps, P] or None)."""
+    lib = L.load()
+    n = dims.B
+    if tuple(features.shape) != (n, dims.P, dims.D):
+        raise L.CaphnError(f"features {tuple(features.shape)} do not match {dims}")
+    if greedy and beam != 1:
+        raise L.CaphnError("greedy search is the beam == 1 case")
+    if want_alphas and beam != 1:
+        raise L.CaphnError("attention maps are only tracked for beam == 1")
+    rows = DecDims(n * beam, 1, dims.P, dims.D, dims.F, dims.E, dims.H, dims.V, dims.cell, dims.raw, False)
+    cd = rows.c()
+    cfg = L.SearchCfg(n, beam, max_steps, 0 if greedy else 1, 1 if greedy else 0, first_token, end_token)
+    ps = _dec_struct(L.DecoderParams, rows, params)
+    dev = features.device
+    nbytes = lib.caphn_decoder_search_workspace_bytes(C.byref(cd), C.byref(cfg))
+    if nbytes == 0:
+        raise L.CaphnError(f"unsupported search configuration (beam {beam}, {dims})")
+    ws = decoder_workspace(rows, dev)
+    sws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    seqs = torch.zeros(n, max_steps + 1, dtype=torch.int64, device=dev)
+    lengths = torch.zeros(n, dtype=torch.int32, device=dev)
+    scores = _f32(n, device=dev)
+    finished = torch.zeros(n, dtype=torch.int32, device=dev)
+    n_active = torch.zeros(1, dtype=torch.int32, device=dev)
+    alphas = torch.zeros(n, max_steps, dims.P, dtype=torch.float32, device=dev) if want_alphas else None
+    wsp, swp = C.c_void_p(ws.data_ptr()), C.c_void_p(sws.data_ptr())
+    L.check(lib.caphn_decoder_search_begin(C.byref(cd), C.byref(ps), C.byref(cfg), L.ptr(features), wsp, swp,
+                                           L.stream_ptr()), "caphn_decoder_search_begin")
+    done = 0
+    while done < max_steps:
+        chunk = min(poll_every, max_steps - done)
+        L.check(lib.caphn_decoder_search_steps(C.byref(cd), C.byref(ps), C.byref(cfg), done + 1, chunk,
+                                               L.ptr(alphas, allow_none=True), wsp, swp, L.stream_ptr()),
+                "caphn_decoder_search_steps")
+        done += chunk
+        L.check(lib.caphn_decoder_search_result(C.byref(cd), C.byref(cfg), done, wsp, swp, L.ptr(seqs, torch.int64),
+                                                L.ptr(lengths, torch.int32), L.ptr(scores), L.ptr(finished, torch.int32),
+                                                L.ptr(n_active, torch.int32), L.stream_ptr()), "caphn_decoder_search_result")
+        if int(n_active.item()) == 0:
+            break
+    return seqs, lengths, scores, finished.bool(), alphas
+
+
 def decoder_backward(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,
                      dlogits: torch.Tensor, grads: Dict[str, torch.Tensor], ws: torch.Tensor,
                      dalphas: Optional[torch.Tensor] = None) -> None:

@@ -544,3 +544,110 @@ extern "C" int caphn_decoder_forward_sampled(const caphn_decoder_dims* d, const 
     }
     return caphn_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ search
+// Beam search (hypernet_attention.py:251-306) and greedy search (models/decoderlstm.py:138-175) for a batch of
+// images; the decode state lives in the search workspace (search.hip) and one step is six launches on `stream`.
+namespace {
+struct SearchWs {   // byte offsets
+    size_t h_cur, logits, cand_val, cand_idx, score, idx, k_alive, n_comp, seqs0, seqs1, comp_seqs, comp_len, comp_score, total;
+};
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline bool search_ok(const caphn_decoder_dims* d, const caphn_search_cfg* c) {
+    return dims_ok(d) && c && d->cell == CAPHN_CELL_GRU && d->T == 1 && c->beam >= 1 && c->beam <= SEARCH_MAX_BEAM &&
+           c->n_images >= 1 && d->B == c->n_images * c->beam && c->max_steps >= 1 && !d->row_subset;
+}
+inline SearchWs search_layout(const caphn_decoder_dims* d, const caphn_search_cfg* c) {
+    SearchWs w;
+    const size_t R = d->B, k = c->beam, N = c->n_images, L = (size_t)c->max_steps + 1;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += up256(bytes); return r; };
+    w.h_cur = take(4 * R * d->H); w.logits = take(4 * R * d->V); w.cand_val = take(4 * R * k); w.cand_idx = take(4 * R * k);
+    w.score = take(4 * R); w.idx = take(8 * R); w.k_alive = take(4 * N); w.n_comp = take(4 * N);
+    w.seqs0 = take(8 * R * L); w.seqs1 = take(8 * R * L);
+    w.comp_seqs = take(8 * N * k * L); w.comp_len = take(4 * N * k); w.comp_score = take(4 * N * k);
+    w.total = o;
+    return w;
+}
+inline SearchArgs search_args(const caphn_decoder_dims* d, const caphn_search_cfg* c, const Ws& w, float* ws, char* sw) {
+    const SearchWs q = search_layout(d, c);
+    SearchArgs a;
+    a.n_images = c->n_images; a.beam = c->beam; a.max_steps = c->max_steps; a.H = d->H;
+    a.zero_pad_rule = c->zero_pad_rule; a.end_token = c->end_token;
+    a.h_cur = reinterpret_cast<float*>(sw + q.h_cur); a.h_new = ws + w.Hs;
+    a.score = reinterpret_cast<float*>(sw + q.score); a.idx = reinterpret_cast<int64_t*>(sw + q.idx);
+    a.cand_val = reinterpret_cast<float*>(sw + q.cand_val); a.cand_idx = reinterpret_cast<int*>(sw + q.cand_idx);
+    a.k_alive = reinterpret_cast<int*>(sw + q.k_alive); a.n_comp = reinterpret_cast<int*>(sw + q.n_comp);
+    a.seqs[0] = reinterpret_cast<int64_t*>(sw + q.seqs0); a.seqs[1] = reinterpret_cast<int64_t*>(sw + q.seqs1);
+    a.comp_seqs = reinterpret_cast<int64_t*>(sw + q.comp_seqs); a.comp_len = reinterpret_cast<int*>(sw + q.comp_len);
+    a.comp_score = reinterpret_cast<float*>(sw + q.comp_score);
+    return a;
+}
+}  // namespace
+
+extern "C" size_t caphn_decoder_search_workspace_bytes(const caphn_decoder_dims* d, const caphn_search_cfg* c) {
+    if (!search_ok(d, c)) return 0;
+    return search_layout(d, c).total;
+}
+
+extern "C" int caphn_decoder_search_begin(const caphn_decoder_dims* d, const caphn_decoder_params* p, const caphn_search_cfg* c,
+                                          const float* features, void* ws_, void* sws_, caphn_stream_t stream) {
+    if (!search_ok(d, c) || !p || !features || !ws_ || !sws_) return CAPHN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = layout(d);
+    float* ws = static_cast<float*>(ws_);
+    if (caphn_rec_resident_gates(d->P, d->H, w.NG) < 0) return CAPHN_ELIMIT;
+    // feature_fc / init_hidden / W_a f / G once per IMAGE: the beams of an image share its slabs (slab_div)
+    caphn_decoder_dims di = *d;
+    di.B = c->n_images;
+    const float* f = nullptr;
+    RUN(decoder_precompute(&di, p, w, ws, features, &f, s));
+    const SearchArgs a = search_args(d, c, w, ws, static_cast<char*>(sws_));
+    return caphn_launch_search_init(a, ws + w.h0, c->first_token, c->lookup_first, s);
+}
+
+extern "C" int caphn_decoder_search_steps(const caphn_decoder_dims* d, const caphn_decoder_params* p, const caphn_search_cfg* c,
+                                          int step0, int nsteps, float* alphas, void* ws_, void* sws_, caphn_stream_t stream) {
+    if (!search_ok(d, c) || !p || !ws_ || !sws_ || step0 < 1 || nsteps < 0 || step0 + nsteps - 1 > c->max_steps) return CAPHN_EINVAL;
+    if (alphas && c->beam != 1) return CAPHN_EINVAL;      // attention maps are only tracked without beam re-ordering
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = layout(d);
+    float* ws = static_cast<float*>(ws_);
+    char* sw = static_cast<char*>(sws_);
+    const SearchWs q = search_layout(d, c);
+    const SearchArgs sa = search_args(d, c, w, ws, sw);
+    const int R = d->B, P = d->P, E = d->E, F = d->F, H = d->H, V = d->V, GH = w.NG * H, EF = E + F;
+    const int RG = caphn_rec_resident_gates(P, H, w.NG);
+    if (RG < 0) return CAPHN_ELIMIT;
+    float* logits = reinterpret_cast<float*>(sw + q.logits);
+    for (int step = step0; step < step0 + nsteps; ++step) {
+        RUN(caphn_embedding_gather(R, E, p->embed_w, sa.idx, ws + w.Xe, s));
+        RUN(caphn_gemm_f32(0, 1, R, GH, E, ws + w.Xe, E, p->w_ih, EF, ws + w.Xg, GH, p->b_ih, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+        RecFwdArgs a;
+        a.B = R; a.T = 1; a.P = P; a.H = H; a.RG = RG; a.slab_div = c->beam;
+        a.Waf = ws + w.Waf; a.G = ws + w.G; a.Xg = ws + w.Xg; a.h0 = sa.h_cur; a.c0 = nullptr;
+        a.W_hh = p->w_hh; a.b_hh = p->b_hh; a.U_a = p->Ua_w; a.b_Ua = p->Ua_b; a.v_a = p->va_w; a.b_va = p->va_b;
+        a.Hs = ws + w.Hs; a.Hprev = ws + w.Hprev; a.alphas = ws + w.alphas; a.gates = ws + w.gates; a.hn = ws + w.hn;
+        a.Cs = nullptr; a.Cprev = nullptr; a.uah = ws + w.uah; a.prof = nullptr; a.rotate = 0;
+        a.vecW = (H % 4 == 0) && caphn_aligned16(p->w_hh) && caphn_aligned16(p->Ua_w);
+        a.vecS = (H % 4 == 0) && caphn_aligned16(ws);
+        RUN(caphn_launch_rec_fwd(a, false, s));
+        RUN(caphn_gemm_f32(0, 1, R, V, H, ws + w.Hs, H, p->out_w, H, logits, V, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+        if (alphas)
+            if (hipMemcpy2DAsync(alphas + (size_t)(step - 1) * P, sizeof(float) * (size_t)c->max_steps * P, ws + w.alphas,
+                                 sizeof(float) * P, sizeof(float) * P, R, hipMemcpyDeviceToDevice, s) != hipSuccess) return CAPHN_ELAUNCH;
+        RUN(caphn_launch_row_topk(R, V, c->beam, logits, sa.score, const_cast<float*>(sa.cand_val), const_cast<int*>(sa.cand_idx), s));
+        RUN(caphn_launch_beam_merge(sa, step, s));
+    }
+    return caphn_launch_status();
+}
+
+extern "C" int caphn_decoder_search_result(const caphn_decoder_dims* d, const caphn_search_cfg* c, int steps_done, void* ws_, void* sws_,
+                                           int64_t* seqs, int* lengths, float* scores, int* finished, int* n_active,
+                                           caphn_stream_t stream) {
+    if (!search_ok(d, c) || !ws_ || !sws_ || !seqs || !lengths || !scores || !finished || !n_active || steps_done < 0 ||
+        steps_done > c->max_steps) return CAPHN_EINVAL;
+    const Ws w = layout(d);
+    const SearchArgs sa = search_args(d, c, w, static_cast<float*>(ws_), static_cast<char*>(sws_));
+    return caphn_launch_search_result(sa, steps_done, seqs, lengths, scores, finished, n_active, static_cast<hipStream_t>(stream));
+}

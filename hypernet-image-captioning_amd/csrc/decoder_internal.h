@@ -22,6 +22,7 @@ struct RecFwdArgs {
     float* uah;                             // [B,T,H]  U_a h + b_Ua
     unsigned long long* prof;               // 8 counters: per-phase shader-clock sums of workgroup 0 (tuning aid)
     int vecW, vecS, rotate;
+    int slab_div = 1;   // rows b share the image slab b / slab_div of Waf and G (beam search: beams of one image)
 };
 struct RecBwdArgs {
     int B, T, P, H;
@@ -56,3 +57,23 @@ int caphn_launch_attn_param_grads(const AttnGradArgs& a, int B, int npc, hipStre
 int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const float* f, float* ctx, hipStream_t s);
 int caphn_launch_df(int B, int T, int P, int F, const float* alphas, const float* dctx, const float* dmean, float* df, hipStream_t s);
 int caphn_launch_mean_p(int B, int P, int F, const float* f, float* out, hipStream_t s);
+
+// Beam / greedy search state (search.hip); all pointers are device memory inside the caller's search workspace.
+constexpr int SEARCH_MAX_BEAM = 8;
+struct SearchArgs {
+    int n_images, beam, max_steps, H;
+    int zero_pad_rule;          // hypernet_attention.py:263-264
+    int64_t end_token;
+    float* h_cur; const float* h_new;       // [n_images*beam, H]
+    float* score;               // [rows] cumulative log-probability of each alive beam
+    int64_t* idx;               // [rows] next input token (-1: zero vector)
+    const float* cand_val; const int* cand_idx;   // [rows, beam]
+    int* k_alive; int* n_comp;  // [n_images]
+    int64_t* seqs[2];           // [rows, max_steps+1] ping-pong
+    int64_t* comp_seqs; int* comp_len; float* comp_score;   // [n_images, beam, (max_steps+1)]
+};
+int caphn_launch_row_topk(int R, int V, int k, const float* logits, const float* score, float* cand_val, int* cand_idx, hipStream_t s);
+int caphn_launch_beam_merge(const SearchArgs& a, int step, hipStream_t s);
+int caphn_launch_search_init(const SearchArgs& a, const float* h0, int64_t first_token, int lookup_first, hipStream_t s);
+int caphn_launch_search_result(const SearchArgs& a, int steps_done, int64_t* out_seq, int* out_len, float* out_score, int* finished,
+                               int* n_active, hipStream_t s);

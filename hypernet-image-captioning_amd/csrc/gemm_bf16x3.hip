@@ -251,8 +251,13 @@ int launch_cfg(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 
 }  // namespace
 
+int g_tune_gemm_tile = 0;     // 0: 128x128 when >= 512 such tiles else 64x64; 1: also try 128x64 when >= 512 such tiles
 int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.splitk;
     if (tiles128 >= 512) return launch_cfg<128, 128>(g, ta, tb, s);
+    if (g_tune_gemm_tile == 1) {
+        const long t12864 = (long)((g.M + 127) / 128) * ((g.N + 63) / 64) * g.splitk;
+        if (t12864 >= 512) return launch_cfg<128, 64>(g, ta, tb, s);
+    }
     return launch_cfg<64, 64>(g, ta, tb, s);
 }

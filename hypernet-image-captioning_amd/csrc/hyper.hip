@@ -492,11 +492,13 @@ extern int g_tune_adam;
 extern int g_tune_gemm;
 extern int g_tune_rec_rotate;
 extern int g_tune_fork;
+extern int g_tune_gemm_tile;
 extern "C" int caphn_tune(int key, int value) {
     if (key == 0) { g_tune_gemv = value; return CAPHN_OK; }
     if (key == 1) { g_tune_adam = value; return CAPHN_OK; }
     if (key == 2) { g_tune_gemm = value; return CAPHN_OK; }
     if (key == 3) { g_tune_rec_rotate = value; return CAPHN_OK; }
     if (key == 4) { g_tune_fork = value; return CAPHN_OK; }
+    if (key == 5) { g_tune_gemm_tile = value; return CAPHN_OK; }
     return CAPHN_EINVAL;
 }

@@ -102,14 +102,15 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
     float* e_s = gh_s + GH;
     float* part_s = e_s + Ppad;          // [ng][GH]
 
-    const float* Gb = a.G + (size_t)b * P * GH;
+    const int sb = a.slab_div > 1 ? b / a.slab_div : b;
+    const float* Gb = a.G + (size_t)sb * P * GH;
     load_G_resident(G_s, Gb, P, GH, RGH, a.vecS, tid);
     for (int k = tid; k < H; k += NT) {
         h_s[k] = a.h0[(size_t)b * H + k]; va_s[k] = a.v_a[k];
         c_s[k] = LSTM ? a.c0[(size_t)b * H + k] : 0.f;
     }
     const float bva = a.b_va[0];
-    const float* Waf_b = a.Waf + (size_t)b * P * H;
+    const float* Waf_b = a.Waf + (size_t)sb * P * H;
     const KG m = kg_map(tid, H);
     const int rotU = a.rotate ? (int)(((unsigned)b * 13u) % (unsigned)H) : 0;
     const int rotW = a.rotate ? (int)(((unsigned)b * 37u) % (unsigned)GH) : 0;

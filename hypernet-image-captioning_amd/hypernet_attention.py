@@ -2,8 +2,8 @@
 (hypernet_attention.py:32-121): hn_base + per-parameter heads emit the GRUCell weights of
 `captioner` for one style/domain row; forward(x) injects them and returns the captioner.
 
-The metric/beam-search/wandb parts of the reference class are out of scope (SURVEY.md section 2);
-pytorch_lightning is optional (the class is a plain nn.Module without it).
+Beam search (test_step, :242-306) runs batched and device-resident (`beam_search`); the text-metric / wandb
+parts of the reference class are out of scope; pytorch_lightning is optional (the class is a plain nn.Module without it).
 """
 import torch
 from torch import nn
@@ -122,3 +122,34 @@ class HyperNet(_Base):
             caps_pred, _ = self.captioner(caps.long(), img_feats, self.teacher_forcing_proba)
         return F.cross_entropy(caps_pred.view(-1, self.hparams['vocab_size']), caps.view(-1).long(),
                                ignore_index=self.vocab.w2i['<pad>'])
+
+    def beam_search(self, features, beam_size=None, max_step=50, end_token=None):
+        """Beam search of test_step (hypernet_attention.py:251-306) for a batch of encoder outputs [B,P,2048]
+        with the currently injected cell weights.  Returns a list with, per image, the best completed sequence
+        (token list starting with 0 and ending with </s>) or None when the loop ran past `max_step`
+        (the reference's `compute = False`), plus the tensor of their scores."""
+        if self.cell != 'gru':
+            raise NotImplementedError("beam search follows the reference's GRU captioner")
+        cap = self.captioner
+        k = self.beam_size if beam_size is None else beam_size
+        if end_token is None:
+            end_token = self.vocab.w2i['</s>']
+        B, P, D = features.shape
+        named = cap._named_tensors()
+        dims = cap.dec_dims(B, 1, P)
+        params = {n: named[n].detach().contiguous().float() for n in dims.names()}
+        seqs, lengths, scores, finished, _ = ops.decoder_search(dims, params, features.detach().float().contiguous(), k,
+                                                                max_step + 1, end_token=end_token)
+        seqs, lengths, fin = seqs.cpu(), lengths.cpu(), finished.cpu()
+        return [seqs[b, :int(lengths[b])].tolist() if bool(fin[b]) else None for b in range(B)], scores
+
+    def test_step(self, test_batch, batch_idx):
+        """hypernet_attention.py:242-320 without the text metrics: returns the beam-search caption (token list)."""
+        imgs, (style, (caps, lengths)) = test_batch
+        dev = self.captioner.embed.weight.device
+        style = torch.tensor([self.vocab(style)], dtype=torch.long, device=dev)
+        self.forward(self.captioner.embed(style))
+        with torch.no_grad():
+            features = self.image_encoder(imgs.float())
+            out, _ = self.beam_search(features)
+        return out[0] if len(out) == 1 else out

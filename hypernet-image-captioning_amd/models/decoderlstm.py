@@ -89,6 +89,36 @@ class AttentionGru(nn.Module):
         """models/decoderlstm.py:122-135 (features are post-feature_fc here, as in the reference)."""
         return self.init_h(torch.mean(features, dim=1))
 
+    def greedy_search(self, features, end_sentence=2, max_sentence=20):
+        """models/decoderlstm.py:138-175.  features are feature_fc outputs [1,P,F] -> (sentence, weights): the
+        token list (ending with end_sentence unless max_sentence was hit) and one attention map [1,P] per step.
+        A batch [B,P,F] decodes every image at once on the device and returns lists of those per image."""
+        if self.layers:
+            raise NotImplementedError("num_layers > 1 is not supported by the fused HIP path")
+        B, P, Fo = features.shape
+        if Fo != self.feature_out:
+            raise CaphnError(f"greedy_search takes feature_fc outputs ({self.feature_out} channels), got {Fo}")
+        named = self._named_tensors()
+        dims = ops.DecDims(B, 1, P, Fo, Fo, self.embedding_dim, self.hidden_dim, self.vocab_size, raw=True)
+        params = {n: named[n].detach().contiguous().float() for n in dims.names()}
+        seqs, lengths, _, _, alphas = ops.decoder_search(dims, params, features.detach().float().contiguous(), 1,
+                                                         max_sentence, end_token=end_sentence, greedy=True,
+                                                         want_alphas=True)
+        seqs, lengths = seqs.cpu(), lengths.cpu()
+        sents = [seqs[b, 1:int(lengths[b])].tolist() for b in range(B)]
+        wts = [[alphas[b:b + 1, t] for t in range(len(sents[b]))] for b in range(B)]
+        return (sents[0], wts[0]) if B == 1 else (sents, wts)
+
+    def infer(self, features, end_sentence=2, max_len=40, vocab=None):
+        """models/decoderlstm.py:178-185.  The reference unpickles data/vocab.pkl on every call; pass the
+        vocabulary object (anything with an `i2w` dict) instead."""
+        from utils import clean_sentence
+        if vocab is None:
+            raise ValueError("pass vocab= (the reference reads data/vocab.pkl here; this port does not unpickle files)")
+        feats = self.feature_fc(features)
+        output, _ = self.greedy_search(feats, end_sentence, max_len)
+        return clean_sentence(output, vocab)
+
 
 class GruNet(AttentionGru):
     """Name imported by train_gru.py:12 but defined nowhere in the reference; its constructor call

@@ -99,3 +99,10 @@ def get_hist_embedding(cap_dir1, vocab, list_domain, do_log=True):
             counter_word = [log(c + eps, 10) for c in counter_word]
         out[cur_domain.replace("\n", '')] = counter_word
     return out
+
+
+def clean_sentence(output, voc):
+    """utils.py:347-351: ids -> words without the markers and commas."""
+    words = [voc.i2w.get(idx) for idx in output]
+    words = [word for word in words if word not in ('<s>', ',', '<pad>', '</s>')]
+    return " ".join(words)

@@ -193,6 +193,40 @@ int caphn_decoder_hyper_backward(const caphn_decoder_dims* d, const caphn_decode
                                  caphn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Decoding (inference): beam search of HyperNet.test_step [hypernet_attention.py:251-306] and
+ * AttentionGru.greedy_search [models/decoderlstm.py:138-175] for a batch of images, with the whole decode
+ * state (beams, scores, sequences, completed lists) resident on the device.
+ *
+ * dims: B = n_images * beam rows, T = 1, cell = GRU; features [n_images, P, D] (raw_features = 1 with D = F when
+ * they are already feature_fc outputs, as greedy_search receives them).  Beams of one image share its
+ * attention slabs; h is re-ordered on the device.  Protocol: _begin once, _steps in chunks (steps are numbered
+ * from 1; step0 + nsteps - 1 <= max_steps), _result whenever the host wants to look (n_active[0] = images whose
+ * beam is not empty yet); nothing here synchronises.
+ *
+ * beam search : beam = k, first_token = 0, lookup_first = 0, zero_pad_rule = 1 (a <pad> at the head of the beam
+ *               zeroes every input embedding, :263-264), max_steps = 51 (the reference breaks after step 51, :300).
+ * greedy      : beam = 1, first_token = 0, lookup_first = 1 (embed(0) is fed, :150,156), zero_pad_rule = 0,
+ *               max_steps = max_sentence.
+ * Result per image: finished = 1 and the best completed sequence (first maximum of the cumulative
+ * log-probability, :311), or finished = 0 and the head of the beam as it stands.  Sequences start with
+ * first_token and include end_token; positions >= length are 0. */
+typedef struct {
+    int n_images, beam, max_steps;
+    int zero_pad_rule, lookup_first;
+    int64_t first_token, end_token;
+} caphn_search_cfg;
+size_t caphn_decoder_search_workspace_bytes(const caphn_decoder_dims* d, const caphn_search_cfg* c);
+int caphn_decoder_search_begin(const caphn_decoder_dims* d, const caphn_decoder_params* p, const caphn_search_cfg* c,
+                               const float* features, void* ws, void* search_ws, caphn_stream_t stream);
+/* alphas (optional, beam == 1 only): [n_images, max_steps, P] attention maps of the steps taken. */
+int caphn_decoder_search_steps(const caphn_decoder_dims* d, const caphn_decoder_params* p, const caphn_search_cfg* c,
+                               int step0, int nsteps, float* alphas, void* ws, void* search_ws, caphn_stream_t stream);
+/* seqs [n_images, max_steps+1] int64, lengths/finished [n_images] int32, scores [n_images] f32, n_active [1] int32. */
+int caphn_decoder_search_result(const caphn_decoder_dims* d, const caphn_search_cfg* c, int steps_done, void* ws, void* search_ws,
+                                int64_t* seqs, int* lengths, float* scores, int* finished, int* n_active,
+                                caphn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Loss: F.cross_entropy(logits.view(-1,V), caps.view(-1), ignore_index)   [hypernet_attention.py:183,
  * cc_train_hypernet.py:153].  Writes the mean loss to loss_out[0], the number of non-ignored
  * targets to loss_out[1], and d loss / d logits to dlogits (may alias logits).

@@ -288,6 +288,88 @@ def decoder_forward(dims: Dims, p: Dict[str, Tensor], cellw: Dict[str, Tensor],
     return torch.stack(outs, 1), torch.stack(alphas, 1)
 
 
+
+def _feature_fc(p: Dict[str, Tensor], features: Tensor) -> Tensor:
+    return F_.linear(torch.relu(F_.linear(features, p["captioner.feature_fc.0.weight"], p["captioner.feature_fc.0.bias"])),
+                     p["captioner.feature_fc.2.weight"], p["captioner.feature_fc.2.bias"])
+
+
+def greedy_search(p: Dict[str, Tensor], cellw: Dict[str, Tensor], feats: Tensor,
+                  end_sentence: int = 2, max_sentence: int = 20) -> Tuple[List[int], List[Tensor]]:
+    """AttentionGru.greedy_search, models/decoderlstm.py:138-175, for ONE image.  feats [1,P,F] are already
+    feature_fc outputs (infer applies feature_fc first, :181).  The first input is embed(0) -- looked up,
+    not zeroed (:150,156)."""
+    sentence, weights = [], []
+    word = torch.tensor([0])
+    h = F_.linear(feats.mean(dim=1), p["captioner.init_h.weight"], p["captioner.init_h.bias"])
+    while True:
+        emb = p["captioner.embed.weight"][word]
+        ctx, alpha = attention(p, feats, h)
+        h = gru_cell(torch.cat([emb, ctx], dim=1), h, cellw)
+        out = F_.linear(h, p["captioner.fc.weight"], p["captioner.fc.bias"])
+        top = torch.log_softmax(out, dim=1)[0].topk(1)[1]
+        sentence.append(int(top.item()))
+        weights.append(alpha)
+        word = top
+        if len(sentence) >= max_sentence or int(top.item()) == end_sentence:
+            break
+    return sentence, weights
+
+
+def beam_search(p: Dict[str, Tensor], cellw: Dict[str, Tensor], features: Tensor, k: int = 3,
+                end_token: int = 2, max_step: int = 50):
+    """Beam search of HyperNet.test_step, hypernet_attention.py:251-306, for ONE image.  features [1,P,D] are
+    encoder outputs (feature_fc is applied here, :252).  Returns (best completed sequence or None, its score,
+    all completed sequences, their scores, margin) -- None when the loop ran past `max_step` (the reference's
+    compute = False, :300-303).  margin = the smallest gap between a selected and the best rejected candidate
+    over all steps (how far the discrete outcome is from flipping under rounding)."""
+    V = p["captioner.fc.weight"].shape[0]
+    enc = _feature_fc(p, features)
+    enc = enc.view(1, -1, enc.size(-1)).expand(k, -1, -1)
+    prev = torch.zeros(k, 1, dtype=torch.long)
+    seqs = prev
+    top_scores = torch.zeros(k, 1)
+    complete, complete_scores = [], []
+    step, margin, compute = 1, float("inf"), False
+    h = F_.linear(enc.mean(dim=1), p["captioner.init_h.weight"], p["captioner.init_h.bias"])
+    while True:
+        emb = p["captioner.embed.weight"][prev].squeeze(1).clone()
+        if prev[0][0] == 0:
+            emb[:] = 0
+        ctx, _ = attention(p, enc, h)
+        h = gru_cell(torch.cat([emb, ctx], 1), h, cellw)
+        scores = torch.log_softmax(F_.linear(h, p["captioner.fc.weight"], p["captioner.fc.bias"]), dim=1)
+        scores = top_scores.expand_as(scores) + scores
+        flat = scores[0] if step == 1 else scores.view(-1)
+        vals, words = flat.topk(k + 1, 0, True, True)
+        margin = min(margin, float((vals[:-1] - vals[1:]).min()))
+        top_scores, top_words = vals[:k], words[:k]
+        prev_inds = top_words // V
+        next_inds = top_words % V
+        seqs = torch.cat([seqs[prev_inds], next_inds.unsqueeze(1)], dim=1)
+        incomplete = [i for i, w in enumerate(next_inds) if int(w) != end_token]
+        done = [i for i in range(len(next_inds)) if i not in incomplete]
+        if done:
+            compute = True
+            complete.extend(seqs[done].tolist())
+            complete_scores.extend(float(s) for s in top_scores[done])
+        k -= len(done)
+        if k == 0:
+            break
+        seqs = seqs[incomplete]
+        h = h[prev_inds[incomplete]]
+        enc = enc[prev_inds[incomplete]]
+        top_scores = top_scores[incomplete].unsqueeze(1)
+        prev = next_inds[incomplete].unsqueeze(1)
+        if step > max_step:
+            compute = False
+            break
+        step += 1
+    best = complete[complete_scores.index(max(complete_scores))] if compute else None
+    best_score = max(complete_scores) if compute else None
+    return best, best_score, complete, complete_scores, margin
+
+
 def caption_loss(logits: Tensor, captions: Tensor, pad: int = 0) -> Tensor:
     """hypernet_attention.py:183 / cc_train_hypernet.py:153: target at step t is
     caps[:,t]; mean over non-<pad> targets."""

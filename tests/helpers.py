@@ -13,6 +13,7 @@ TINY_DIMS = {
     "gru_tiny_cc": O.Dims(D=32, F=16, E=16, H=16, V=50, he=2),
     "gru_odd_cc": O.Dims(D=37, F=13, E=11, H=19, V=83, he=5),
     "lstm_tiny": O.Dims(D=12, F=12, E=8, H=8, V=40, he=8, cell="lstm"),
+    "gru_search": O.Dims(D=32, F=16, E=16, H=16, V=50, he=16),
 }
 
 

@@ -199,3 +199,35 @@ def test_full_size_samples():
         assert abs(mine - n) < 1e-4 * max(n, 1e-3), (k, mine, n)
         idx = z["gidx/" + k]
         assert np.abs(grads[k].flatten().numpy()[idx] - z["gval/" + k]).max() < 2e-6, k
+
+
+def test_greedy_and_beam_search():
+    """Oracle greedy_search / beam_search vs the reference's AttentionGru.greedy_search and the beam loop of
+    HyperNet.test_step run around the reference's sub-modules (tools/make_golden.py search_case)."""
+    dims = TINY_DIMS["gru_search"]
+    g, p = load_case("gru_search")
+    theta = O.hyper_forward(p, g["x_style"])
+    assert maxdiff(theta, g["theta"]) < ATOL
+    cellw = O.split_theta(dims, theta)
+    k, end, max_sentence = int(g["beam"]), int(g["end_token"]), int(g["max_sentence"])
+    feats = g["features"]
+    n_unfinished = 0
+    for n in range(feats.shape[0]):
+        f_post = O._feature_fc(p, feats[n:n + 1])
+        sent, weights = O.greedy_search(p, cellw, f_post, end, max_sentence)
+        L = int(g["greedy_len"][n])
+        assert sent == g["greedy_tokens"][n, :L].tolist()
+        assert maxdiff(torch.cat(weights, 0), g["greedy_alphas"][n, :L]) < ATOL
+        best, score, complete, cscores, margin = O.beam_search(p, cellw, feats[n:n + 1], k, end)
+        assert abs(margin - float(g["beam_margin"][n])) < 1e-5
+        if int(g["beam_finished"][n]):
+            bl = int(g["beam_len"][n])
+            assert best == g["beam_seq"][n, :bl].tolist()
+            assert abs(score - float(g["beam_score"][n])) < 1e-5
+        else:
+            n_unfinished += 1
+            assert best is None
+    assert n_unfinished >= 1          # the fixture covers the reference's `step > 50` exit
+    with open(os.path.join(GOLDEN, "meta.json")) as f:
+        meta = json.load(f)["gru_search"]
+    assert len(set(meta["greedy_len"])) >= 3 and len(set(meta["beam_len"])) >= 3

@@ -30,6 +30,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("CAPHN_REFERENCE", "/root/reference")
 OUT = os.path.join(REPO, "tests", "golden")
 
+SEARCH_END_BUMP = 1.2936  # added to fc.bias[</s>] so random-init captions terminate (config found by random search: varied lengths, one unfinished beam)
+SEARCH_SHARPEN = (6.0, 4.0, 8.0)
+
 
 def _import_reference():
     from transformers import BertTokenizer  # noqa: F401  (utils.py:20 imports it)
@@ -294,10 +297,133 @@ def full_case(name, seed):
     return {"grad_norms": norms, "heads": O.head_layout(dims)}
 
 
+
+def ref_captioner(dims, p, x_style):
+    """Reference AttentionGru with theta from the restated hypernet injected by the reference's own
+    flip_parameters_to_tensors / set_all_parameters (as HyperNet.forward does, hypernet_attention.py:111-121)."""
+    cap = AttentionGru(dims.D, dims.F, dims.E, dims.H, dims.V, p=0.0)
+    hn_base, hn_heads = build_ref_hypernet(cap.gru, dims.he)
+    msd = {k[len("captioner."):]: v.clone() for k, v in p.items() if k.startswith("captioner.")}
+    cap.load_state_dict(msd, strict=False)
+    hn_base.load_state_dict({k[len("hn_base."):]: v.clone() for k, v in p.items() if k.startswith("hn_base.")})
+    hn_heads.load_state_dict({k[len("hn_heads."):]: v.clone() for k, v in p.items() if k.startswith("hn_heads.")})
+    base_feat = hn_base(x_style)
+    theta = torch.cat([h(base_feat).flatten() for h in hn_heads], dim=0)
+    flip_parameters_to_tensors(cap.gru)
+    set_all_parameters(cap.gru, theta.reshape(1, -1))
+    return cap.eval(), theta.detach()
+
+
+def ref_beam_search(cap, features, k, vocab_size, end_token):
+    """The beam loop of HyperNet.test_step (hypernet_attention.py:251-306) RESTATED here -- the class cannot be
+    constructed offline (see module docstring) -- around the reference's own sub-modules feature_fc /
+    init_hidden / embed / attention / gru / fc.  Metric logging (:313-320) is dropped."""
+    encoder_out = cap.feature_fc(features)
+    encoder_dim = encoder_out.size(-1)
+    encoder_out = encoder_out.view(1, -1, encoder_dim)
+    num_pixels = encoder_out.size(1)
+    encoder_out = encoder_out.expand(k, num_pixels, encoder_dim)
+    k_prev_words = torch.LongTensor([[0]] * k)
+    seqs = k_prev_words
+    top_k_scores = torch.zeros(k, 1)
+    complete_seqs, complete_seqs_scores = [], []
+    step, compute, margin = 1, False, float("inf")
+    h = cap.init_hidden(encoder_out)
+    while True:
+        embeddings = cap.embed(k_prev_words).squeeze(1)
+        if k_prev_words[0][0] == 0:
+            embeddings[:] = 0
+        context, _ = cap.attention(encoder_out, h)
+        h = cap.gru(torch.cat([embeddings, context], 1), h)
+        scores = F.log_softmax(cap.fc(h), dim=1)
+        scores = top_k_scores.expand_as(scores) + scores
+        flat = scores[0] if step == 1 else scores.view(-1)
+        vals, _ = flat.topk(k + 1, 0, True, True)
+        margin = min(margin, float((vals[:-1] - vals[1:]).min()))
+        top_k_scores, top_k_words = flat.topk(k, 0, True, True)
+        prev_word_inds = top_k_words // vocab_size
+        next_word_inds = top_k_words % vocab_size
+        seqs = torch.cat([seqs[prev_word_inds], next_word_inds.unsqueeze(1)], dim=1)
+        incomplete_inds = [ind for ind, w in enumerate(next_word_inds) if w != end_token]
+        complete_inds = list(set(range(len(next_word_inds))) - set(incomplete_inds))
+        if len(complete_inds) > 0:
+            compute = True
+            complete_seqs.extend(seqs[complete_inds].tolist())
+            complete_seqs_scores.extend(top_k_scores[complete_inds])
+        k -= len(complete_inds)
+        if k == 0:
+            break
+        seqs = seqs[incomplete_inds]
+        h = h[prev_word_inds[incomplete_inds]]
+        encoder_out = encoder_out[prev_word_inds[incomplete_inds]]
+        top_k_scores = top_k_scores[incomplete_inds].unsqueeze(1)
+        k_prev_words = next_word_inds[incomplete_inds].unsqueeze(1)
+        if step > 50:
+            compute = False
+            break
+        step += 1
+    best = complete_seqs[complete_seqs_scores.index(max(complete_seqs_scores))] if compute else None
+    return best, [float(x) for x in complete_seqs_scores], complete_seqs, margin, step
+
+
+def search_case(name, dims, n_images, P, seed, end_bump, k=3, max_sentence=12, sharpen=(1.0, 1.0, 1.0), write=True):
+    """Greedy search by the reference's AttentionGru.greedy_search (models/decoderlstm.py:138-175) and the
+    beam loop above, image by image.  fc.bias[</s>] is raised by end_bump so that random-init captions end."""
+    p = O.init_params(dims, seed)
+    p["captioner.fc.bias"] = p["captioner.fc.bias"].clone()
+    p["captioner.fc.bias"][2] += end_bump
+    # random-init logits are nearly flat and image-independent: scale fc / embed / feature_fc so that captions differ
+    p["captioner.fc.weight"] = p["captioner.fc.weight"] * sharpen[0]
+    p["captioner.embed.weight"] = p["captioner.embed.weight"] * sharpen[1]
+    p["captioner.feature_fc.2.weight"] = p["captioner.feature_fc.2.weight"] * sharpen[2]
+    torch.manual_seed(seed)
+    feats = O.synth_batch(dims, n_images, 4, P, seed=seed + 1)["features"]
+    x_style = torch.zeros(dims.he); x_style[seed % dims.he] = 1.0
+    L = 52
+    with torch.no_grad():
+        cap, theta = ref_captioner(dims, p, x_style)
+        arrs = {"features": feats, "x_style": x_style, "theta": theta, "end_token": np.int64(2), "beam": np.int64(k),
+                "max_sentence": np.int64(max_sentence)}
+        for kk, v in p.items():
+            arrs["p/" + kk] = v
+        g_tok = np.zeros((n_images, max_sentence), np.int64); g_len = np.zeros(n_images, np.int64)
+        g_alpha = np.zeros((n_images, max_sentence, P), np.float32)
+        b_seq = np.zeros((n_images, L), np.int64); b_len = np.zeros(n_images, np.int64)
+        b_score = np.zeros(n_images, np.float32); b_fin = np.zeros(n_images, np.int64); b_margin = np.zeros(n_images, np.float64)
+        b_steps = np.zeros(n_images, np.int64)
+        comp = []
+        for n in range(n_images):
+            f_post = cap.feature_fc(feats[n:n + 1])
+            sent, weights = cap.greedy_search(f_post, end_sentence=2, max_sentence=max_sentence)
+            g_tok[n, :len(sent)] = sent; g_len[n] = len(sent)
+            for t, wgt in enumerate(weights):
+                g_alpha[n, t] = wgt[0].numpy()
+            best, cs, cseqs, margin, steps = ref_beam_search(cap, feats[n:n + 1], k, dims.V, 2)
+            b_margin[n] = margin; b_steps[n] = steps; b_fin[n] = best is not None
+            if best is not None:
+                b_seq[n, :len(best)] = best; b_len[n] = len(best); b_score[n] = max(cs)
+            comp.append({"scores": cs, "seqs": cseqs})
+    arrs.update({"greedy_tokens": g_tok, "greedy_len": g_len, "greedy_alphas": g_alpha, "beam_seq": b_seq, "beam_len": b_len,
+                 "beam_score": b_score, "beam_finished": b_fin, "beam_margin": b_margin, "beam_steps": b_steps})
+    if write:
+        save_npz(os.path.join(OUT, name + ".npz"), **arrs)
+    return {"greedy_len": g_len.tolist(), "beam_len": b_len.tolist(), "beam_finished": b_fin.tolist(),
+            "beam_margin": b_margin.tolist(), "beam_steps": b_steps.tolist(), "complete": comp}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     meta = {"torch": torch.__version__, "reference": "zacharie12/Hypernet-image-captioning @ /root/reference"}
+    if "--only-search" in sys.argv:            # refresh the search vectors, keep everything else as committed
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["gru_search"] = search_case("gru_search", O.Dims(D=32, F=16, E=16, H=16, V=50, he=16), n_images=6, P=7,
+                                         seed=462, end_bump=SEARCH_END_BUMP, sharpen=SEARCH_SHARPEN)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        print(json.dumps(meta["gru_search"], indent=1)[:3000])
+        return
     tiny = O.Dims(D=32, F=16, E=16, H=16, V=50, he=16)
     meta["gru_tiny_flickr"] = tiny_case("gru_tiny_flickr", tiny, B=3, T=6, P=7, seed=11, flickr=True, max_norm=5.0)
     # he = 2 forces head branch 3 (w//500 >= he) for weight_ih and a 1-D CC-style x; max_norm small
@@ -308,6 +434,7 @@ def main():
     odd = O.Dims(D=37, F=13, E=11, H=19, V=83, he=5)
     meta["gru_odd_cc"] = tiny_case("gru_odd_cc", odd, B=5, T=9, P=10, seed=31, flickr=False, max_norm=5.0)
     meta["lstm_tiny"] = lstm_case("lstm_tiny", seed=41)
+    meta["gru_search"] = search_case("gru_search", tiny, n_images=6, P=7, seed=462, end_bump=SEARCH_END_BUMP, sharpen=SEARCH_SHARPEN)
     if os.environ.get("CAPHN_GOLDEN_FULL", "1") == "1":
         meta["gru_full"] = full_case("gru_full", seed=2024)
     with open(os.path.join(OUT, "meta.json"), "w") as f:

@@ -12,7 +12,7 @@ from caphn import _lib, ops  # noqa: E402
 
 SHAPES = [  # name, ta, tb, M, N, K, splitk
     ("fc0 fwd", 0, 1, 6272, 200, 2048, 1), ("logits fwd", 0, 1, 2560, 9684, 200, 1),
-    ("dW_fc", 1, 0, 9684, 200, 2560, 2), ("dHs", 0, 0, 2560, 200, 9684, 7), ("dW_fc0", 1, 0, 200, 2048, 6272, 8),
+    ("dW_fc", 1, 0, 9684, 200, 2560, 2), ("dW_fc s4", 1, 0, 9684, 200, 2560, 4), ("dHs", 0, 0, 2560, 200, 9684, 7), ("dHs s14", 0, 0, 2560, 200, 9684, 14), ("dW_fc0", 1, 0, 200, 2048, 6272, 8), ("dW_fc0 s16", 1, 0, 200, 2048, 6272, 16), ("fc0 fwd big", 0, 1, 6272, 200, 2048, 1),
     ("G", 0, 1, 6272, 600, 200, 1), ("Xg", 0, 1, 2560, 600, 200, 1), ("dW_hh", 1, 0, 600, 200, 2560, 10),
     ("dY1", 0, 0, 6272, 200, 200, 1),
 ]
@@ -28,8 +28,8 @@ def main():
         ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
         out = torch.zeros(M, N, device=dev)
         line = f"{name:11s} M={M:5d} N={N:5d} K={K:5d}"
-        for mode in (0, 1):
-            lib.caphn_tune(2, mode)
+        for mode in (1, 2):
+            lib.caphn_tune(2, 1); lib.caphn_tune(5, mode - 1)
             ts = []
             for _ in range(6):
                 if sk > 1:
@@ -42,9 +42,9 @@ def main():
             err = float((out.double() - ref).abs().max())
             rel = err / float(ref.abs().max())
             t = float(np.median(ts[1:])) * 1e3
-            line += f" | {'f32' if mode == 0 else 'bf16x3'}: {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF err {err:.2e} (rel {rel:.1e})"
+            line += f" | {'64x64' if mode == 1 else '128x64'}: {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF err {err:.2e} (rel {rel:.1e})"
         print(line)
-    lib.caphn_tune(2, 0)
+    lib.caphn_tune(2, 1); lib.caphn_tune(5, 0)
 
 
 if __name__ == "__main__":
