@@ -21,7 +21,8 @@ class HyperDesc(C.Structure):
                 ("k", C.c_int * MAX_HEADS), ("w", C.c_int * MAX_HEADS),
                 ("base_w0", c_fp), ("base_b0", c_fp), ("base_w2", c_fp), ("base_b2", c_fp),
                 ("w1", c_fp * MAX_HEADS), ("b1", c_fp * MAX_HEADS),
-                ("w2", c_fp * MAX_HEADS), ("b2", c_fp * MAX_HEADS)]
+                ("w2", c_fp * MAX_HEADS), ("b2", c_fp * MAX_HEADS),
+                ("d_in", C.c_int), ("d_mid", C.c_int)]
 
 
 class HyperGrads(C.Structure):
@@ -51,6 +52,24 @@ class DecoderGrads(C.Structure):
 class AdamHParams(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("step", C.c_int), ("dev_scalars", c_fp)]
+
+
+MAX_LAYERS = 4
+
+
+class PlainDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "T", "E", "H", "V", "L", "cell")]
+
+
+class PlainParams(C.Structure):
+    _fields_ = [("embed_w", c_fp), ("out_w", c_fp), ("out_b", c_fp),
+                ("w_ih", c_fp * MAX_LAYERS), ("w_hh", c_fp * MAX_LAYERS), ("b_ih", c_fp * MAX_LAYERS), ("b_hh", c_fp * MAX_LAYERS)]
+
+
+class PlainGrads(C.Structure):
+    _fields_ = [("embed_w", c_fp), ("out_w", c_fp), ("out_b", c_fp),
+                ("w_ih", c_fp * MAX_LAYERS), ("w_hh", c_fp * MAX_LAYERS), ("b_ih", c_fp * MAX_LAYERS), ("b_hh", c_fp * MAX_LAYERS),
+                ("features", c_fp)]
 
 
 class SearchCfg(C.Structure):
@@ -88,6 +107,10 @@ SIGNATURES = {
                                              C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
     "caphn_decoder_search_result": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(SearchCfg), C.c_int, c_fp, c_fp,
                                               c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_plain_workspace_bytes": (C.c_size_t, [C.POINTER(PlainDims)]),
+    "caphn_plain_forward": (C.c_int, [C.POINTER(PlainDims), C.POINTER(PlainParams), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_plain_backward": (C.c_int, [C.POINTER(PlainDims), C.POINTER(PlainParams), c_fp, c_fp, c_fp, c_fp, c_fp,
+                                       C.POINTER(PlainGrads), c_fp, c_fp]),
     "caphn_ce_workspace_bytes": (C.c_size_t, [C.c_int]),
     "caphn_cross_entropy_fwd_bwd": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
     "caphn_embedding_gather": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),

@@ -68,3 +68,35 @@ def hyper_forward(shape: ops.HyperShape, x: torch.Tensor, named: Dict[str, torch
     if not x.is_cuda:
         raise CaphnError("HyperNet.forward runs on libcaphn's HIP kernels only (no CPU fallback)")
     return _HyperFn.apply(shape, x, *[named[n] for n in shape.param_names()])
+
+
+class _PlainDecoderFn(torch.autograd.Function):
+    """DecoderGRU / DecoderRNN forward with teacher forcing   later.py:394-447 / :254-317"""
+
+    @staticmethod
+    def forward(ctx, dims, features, captions, h0, c0, *tensors):
+        params = {n: t.detach().contiguous() for n, t in zip(dims.names(), tensors)}
+        features = features.detach().contiguous()
+        captions = captions.contiguous()
+        ws = ops.plain_workspace(dims, features.device)
+        logits = ops.plain_forward(dims, params, features, captions, h0, c0, ws)
+        ctx.dims, ctx.ws, ctx.params, ctx.features, ctx.captions, ctx.h0, ctx.c0 = dims, ws, params, features, captions, h0, c0
+        ctx.need_f = True
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        dims = ctx.dims
+        dev = ctx.features.device
+        grads = {n: torch.empty(s, dtype=torch.float32, device=dev) for n, s in dims.param_shapes().items()}
+        dfeat = torch.empty_like(ctx.features)
+        ops.plain_backward(dims, ctx.params, ctx.features, ctx.captions, ctx.h0, ctx.c0, dlogits.contiguous(), grads, ctx.ws, dfeat)
+        ctx.ws = None
+        return (None, dfeat, None, None, None) + tuple(grads[n] for n in dims.names())
+
+
+def plain_decoder_forward(dims: ops.PlainDims, features, captions, h0, c0, named: Dict[str, torch.Tensor]):
+    if not features.is_cuda:
+        raise CaphnError("DecoderGRU / DecoderRNN run on libcaphn's HIP kernels only: move the module and its inputs to a "
+                         "CUDA(HIP) device (there is no CPU fallback)")
+    return _PlainDecoderFn.apply(dims, features.float(), captions.long(), h0, c0, *[named[n] for n in dims.names()])

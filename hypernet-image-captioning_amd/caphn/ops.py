@@ -62,9 +62,20 @@ HYPER_NAMES = ("hn_base.0.weight", "hn_base.0.bias", "hn_base.2.weight", "hn_bas
 
 @dataclass
 class HyperShape:
-    """he and the (k_i, w_i) of every head (hypernet_attention.py:68-97)."""
+    """he and the (k_i, w_i) of every head (hypernet_attention.py:68-97).  d_in / d_mid (0 = he): input and
+    hidden width of hn_base when they differ from he (hypernet.py:55-60: Linear(E,4E), Linear(4E,8E))."""
     he: int
     heads: List[Tuple[int, int]]
+    d_in: int = 0
+    d_mid: int = 0
+
+    @property
+    def din(self) -> int:
+        return self.d_in or self.he
+
+    @property
+    def dmid(self) -> int:
+        return self.d_mid or self.he
 
     @property
     def theta_size(self) -> int:
@@ -78,7 +89,8 @@ class HyperShape:
 
     def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
         he = self.he
-        s = {"hn_base.0.weight": (he, he), "hn_base.0.bias": (he,), "hn_base.2.weight": (he, he), "hn_base.2.bias": (he,)}
+        s = {"hn_base.0.weight": (self.dmid, self.din), "hn_base.0.bias": (self.dmid,),
+             "hn_base.2.weight": (he, self.dmid), "hn_base.2.bias": (he,)}
         for i, (k, w) in enumerate(self.heads):
             s[f"hn_heads.{i}.0.weight"] = (k, he); s[f"hn_heads.{i}.0.bias"] = (k,)
             s[f"hn_heads.{i}.2.weight"] = (w, k); s[f"hn_heads.{i}.2.bias"] = (w,)
@@ -88,6 +100,9 @@ class HyperShape:
 def _hyper_desc(shape: HyperShape, p: Dict[str, torch.Tensor]) -> L.HyperDesc:
     d = L.HyperDesc()
     d.he = shape.he
+    d.d_in, d.d_mid = shape.d_in, shape.d_mid
+    if len(shape.heads) > L.MAX_HEADS:
+        raise L.CaphnError(f"{len(shape.heads)} hypernet heads; libcaphn supports {L.MAX_HEADS}")
     d.n_heads = len(shape.heads)
     exp = shape.param_shapes()
     for n, s in exp.items():
@@ -107,7 +122,7 @@ def hyper_acts_layout(shape: HyperShape) -> Dict[str, Tuple[int, int]]:
     """(offset, length) of x, a0, base and every a_i inside the acts buffer (segments padded to 4)."""
     up4 = lambda v: (v + 3) & ~3
     out, o = {}, 0
-    for name, n in [("x", shape.he), ("a0", shape.he), ("base", shape.he)] + \
+    for name, n in [("x", shape.din), ("a0", shape.dmid), ("base", shape.he)] + \
                    [(f"a{i}", k) for i, (k, _) in enumerate(shape.heads)]:
         out[name] = (o, n)
         o += up4(n)
@@ -121,8 +136,8 @@ def hyper_forward(shape: HyperShape, p: Dict[str, torch.Tensor], x: torch.Tensor
     lib = L.load()
     d = _hyper_desc(shape, p)
     x = x.reshape(-1)
-    if x.numel() != shape.he:
-        raise L.CaphnError(f"hypernet input has {x.numel()} elements, expected {shape.he}")
+    if x.numel() != shape.din:
+        raise L.CaphnError(f"hypernet input has {x.numel()} elements, expected {shape.din}")
     dev = x.device
     n_acts = lib.caphn_hyper_acts_floats(C.byref(d))
     if theta is None:
@@ -149,7 +164,7 @@ def hyper_backward(shape: HyperShape, p: Dict[str, torch.Tensor], dtheta: torch.
     for i in range(len(shape.heads)):
         g.g_w1[i] = gp(f"hn_heads.{i}.0.weight"); g.g_b1[i] = gp(f"hn_heads.{i}.0.bias")
         g.g_w2[i] = gp(f"hn_heads.{i}.2.weight"); g.g_b2[i] = gp(f"hn_heads.{i}.2.bias")
-    gx = _f32(shape.he, device=dtheta.device) if want_x else None
+    gx = _f32(shape.din, device=dtheta.device) if want_x else None
     g.g_x = gx.data_ptr() if gx is not None else None
     nbytes = lib.caphn_hyper_backward_workspace_bytes(C.byref(d))
     if ws is None or ws.numel() < nbytes:
@@ -530,3 +545,102 @@ def outer(g: torch.Tensor, a: torch.Tensor, out: Optional[torch.Tensor] = None) 
         out = _f32(rows, k, device=g.device)
     L.check(lib.caphn_outer_f32(rows, k, L.ptr(g), L.ptr(a), L.ptr(out), L.stream_ptr()), "caphn_outer_f32")
     return out
+
+
+# ------------------------------------------------------------------ non-attention decoders (hypernet.py / later.py)
+@dataclass(frozen=True)
+class PlainDims:
+    """DecoderGRU / DecoderRNN of later.py:362-457 / :227-330: B, T, embed, hidden, vocab, layers, cell."""
+    B: int
+    T: int
+    E: int
+    H: int
+    V: int
+    layers: int = 1
+    cell: str = "gru"
+
+    @property
+    def NG(self) -> int:
+        return 4 if self.cell == "lstm" else 3
+
+    def c(self) -> L.PlainDims:
+        return L.PlainDims(self.B, self.T, self.E, self.H, self.V, self.layers, 1 if self.cell == "lstm" else 0)
+
+    def names(self) -> List[str]:
+        """Reference state_dict names in the order named_parameters() yields them (hypernet.py:62-68 skips
+        embed / fc_out when sizing heads)."""
+        n = [f"lstm_cell.{q}" for q in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        for l in range(self.layers - 1):
+            n += [f"layers.{l}.{q}" for q in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        return n + ["fc_out.weight", "fc_out.bias", "embed.weight"]
+
+    def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        G, E, H, V = self.NG * self.H, self.E, self.H, self.V
+        s = {"lstm_cell.weight_ih": (G, E), "lstm_cell.weight_hh": (G, H), "lstm_cell.bias_ih": (G,), "lstm_cell.bias_hh": (G,)}
+        for l in range(self.layers - 1):
+            s.update({f"layers.{l}.weight_ih": (G, H), f"layers.{l}.weight_hh": (G, H), f"layers.{l}.bias_ih": (G,),
+                      f"layers.{l}.bias_hh": (G,)})
+        s.update({"fc_out.weight": (V, H), "fc_out.bias": (V,), "embed.weight": (V, E)})
+        return s
+
+
+def _plain_struct(cls, dims: PlainDims, t: Dict[str, torch.Tensor]):
+    if dims.layers > L.MAX_LAYERS:
+        raise L.CaphnError(f"{dims.layers} layers; libcaphn supports {L.MAX_LAYERS}")
+    st = cls()
+    for n, shp in dims.param_shapes().items():
+        if tuple(t[n].shape) != tuple(shp):
+            raise L.CaphnError(f"{n}: expected shape {shp}, got {tuple(t[n].shape)}")
+        L.ptr(t[n])
+    st.embed_w = t["embed.weight"].data_ptr(); st.out_w = t["fc_out.weight"].data_ptr(); st.out_b = t["fc_out.bias"].data_ptr()
+    for l in range(dims.layers):
+        pre = "lstm_cell." if l == 0 else f"layers.{l - 1}."
+        st.w_ih[l] = t[pre + "weight_ih"].data_ptr(); st.w_hh[l] = t[pre + "weight_hh"].data_ptr()
+        st.b_ih[l] = t[pre + "bias_ih"].data_ptr(); st.b_hh[l] = t[pre + "bias_hh"].data_ptr()
+    return st
+
+
+def plain_workspace(dims: PlainDims, device) -> torch.Tensor:
+    lib = L.load()
+    cd = dims.c()
+    n = lib.caphn_plain_workspace_bytes(C.byref(cd))
+    if n == 0:
+        raise L.CaphnError(f"bad plain-decoder dims {dims}")
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def _plain_check(dims: PlainDims, features, captions, h0, c0):
+    if tuple(features.shape) != (dims.B, dims.E) or tuple(captions.shape) != (dims.B, dims.T):
+        raise L.CaphnError(f"features {tuple(features.shape)} / captions {tuple(captions.shape)} do not match {dims}")
+    if tuple(h0.shape) != (dims.B, dims.H) or (dims.cell == "lstm" and (c0 is None or tuple(c0.shape) != (dims.B, dims.H))):
+        raise L.CaphnError("h0 / c0 must be [B, H]")
+
+
+def plain_forward(dims: PlainDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,
+                  h0: torch.Tensor, c0: Optional[torch.Tensor], ws: torch.Tensor) -> torch.Tensor:
+    """DecoderGRU / DecoderRNN forward with teacher forcing (later.py:394-447 / :254-317) -> logits [B,T,V]."""
+    lib = L.load()
+    _plain_check(dims, features, captions, h0, c0)
+    if bool((captions < 0).any()) or bool((captions >= dims.V).any()):
+        raise IndexError("caption token id out of range")
+    cd = dims.c()
+    ps = _plain_struct(L.PlainParams, dims, params)
+    logits = _f32(dims.B, dims.T, dims.V, device=features.device)
+    L.check(lib.caphn_plain_forward(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64), L.ptr(h0),
+                                    L.ptr(c0, allow_none=True), L.ptr(logits), C.c_void_p(ws.data_ptr()), L.stream_ptr()),
+            "caphn_plain_forward")
+    return logits
+
+
+def plain_backward(dims: PlainDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,
+                   h0: torch.Tensor, c0: Optional[torch.Tensor], dlogits: torch.Tensor, grads: Dict[str, torch.Tensor],
+                   ws: torch.Tensor, dfeatures: Optional[torch.Tensor] = None) -> None:
+    lib = L.load()
+    _plain_check(dims, features, captions, h0, c0)
+    cd = dims.c()
+    ps = _plain_struct(L.PlainParams, dims, params)
+    gs = _plain_struct(L.PlainGrads, dims, grads)
+    gs.features = dfeatures.data_ptr() if dfeatures is not None else None
+    L.check(lib.caphn_plain_backward(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64), L.ptr(h0),
+                                     L.ptr(c0, allow_none=True), L.ptr(dlogits), C.byref(gs), C.c_void_p(ws.data_ptr()),
+                                     L.stream_ptr()), "caphn_plain_backward")

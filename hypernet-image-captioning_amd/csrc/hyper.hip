@@ -294,19 +294,21 @@ inline int gemv_blocks(int rows, int k, int vec) {
     return (int)want;
 }
 
+inline int d_in(const caphn_hyper_desc* d) { return d->d_in > 0 ? d->d_in : d->he; }
+inline int d_mid(const caphn_hyper_desc* d) { return d->d_mid > 0 ? d->d_mid : d->he; }
 struct ActsLayout { int x, a0, base, a[CAPHN_MAX_HEADS], total; };
 inline ActsLayout acts_layout(const caphn_hyper_desc* d) {
     ActsLayout L;
     // every segment starts 16-byte aligned so the GEMVs may use dwordx4 loads of their input
     auto up4 = [](int v) { return (v + 3) & ~3; };
     int o = 0;
-    L.x = o; o += up4(d->he); L.a0 = o; o += up4(d->he); L.base = o; o += up4(d->he);
+    L.x = o; o += up4(d_in(d)); L.a0 = o; o += up4(d_mid(d)); L.base = o; o += up4(d->he);
     for (int i = 0; i < d->n_heads; ++i) { L.a[i] = o; o += up4(d->k[i]); }
     L.total = o;
     return L;
 }
 inline bool desc_ok(const caphn_hyper_desc* d) {
-    if (!d || d->he <= 0 || d->n_heads <= 0 || d->n_heads > CAPHN_MAX_HEADS) return false;
+    if (!d || d->he <= 0 || d->n_heads <= 0 || d->n_heads > CAPHN_MAX_HEADS || d->d_in < 0 || d->d_mid < 0) return false;
     if (!d->base_w0 || !d->base_b0 || !d->base_w2 || !d->base_b2) return false;
     for (int i = 0; i < d->n_heads; ++i)
         if (d->k[i] <= 0 || d->w[i] <= 0 || !d->w1[i] || !d->b1[i] || !d->w2[i] || !d->b2[i]) return false;
@@ -336,7 +338,7 @@ static int hyper_forward_impl(const caphn_hyper_desc* d, const float* x, float* 
     if (!desc_ok(d) || !x || !acts) return CAPHN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const ActsLayout L = acts_layout(d);
-    if (hipMemcpyAsync(acts + L.x, x, sizeof(float) * d->he, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    if (hipMemcpyAsync(acts + L.x, x, sizeof(float) * d_in(d), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return CAPHN_ELAUNCH;
     auto one = [&](const float* W, const float* b, const float* in, float* out, int rows, int k, int act) {
         GemvJobs jobs; jobs.n = 1;
@@ -345,8 +347,8 @@ static int hyper_forward_impl(const caphn_hyper_desc* d, const float* x, float* 
         J.vec = vec_ok(W, in, k); J.block0 = 0; J.nblocks = gemv_blocks(rows, k, J.vec);
         launch_gemv_fwd(jobs, J.nblocks, s);
     };
-    one(d->base_w0, d->base_b0, acts + L.x, acts + L.a0, d->he, d->he, 1);
-    one(d->base_w2, d->base_b2, acts + L.a0, acts + L.base, d->he, d->he, 1);
+    one(d->base_w0, d->base_b0, acts + L.x, acts + L.a0, d_mid(d), d_in(d), 1);
+    one(d->base_w2, d->base_b2, acts + L.a0, acts + L.base, d->he, d_mid(d), 1);
     {   // first layers of all heads in one launch
         GemvJobs jobs; jobs.n = d->n_heads; int b0 = 0;
         for (int i = 0; i < d->n_heads; ++i) {
@@ -383,7 +385,7 @@ inline BwdWs bwd_ws(const caphn_hyper_desc* d) {
     }
     for (int i = 0; i < d->n_heads; ++i) { w.dz[i] = o; o += caphn_align_up(d->k[i], 4); }
     w.dzb2 = o; o += caphn_align_up(d->he, 4);
-    w.dzb0 = o; o += caphn_align_up(d->he, 4);
+    w.dzb0 = o; o += caphn_align_up(d_mid(d), 4);
     w.total = o;
     return w;
 }
@@ -441,14 +443,14 @@ extern "C" int caphn_hyper_backward(const caphn_hyper_desc* d, const float* dthe
         hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(1024), 0, s, a);
     }
     {   // da0 = Wb2^T dzb2 ; dzb0 = da0 * lrelu'(a0)
-        SmallTArgs a; a.n = 1; a.k = d->he; a.post = acts + L.a0; a.out0 = ws + W.dzb0; a.out1 = g->g_base_b0;
+        SmallTArgs a; a.n = 1; a.k = d_mid(d); a.post = acts + L.a0; a.out0 = ws + W.dzb0; a.out1 = g->g_base_b0;
         a.j[0].W = d->base_w2; a.j[0].d = ws + W.dzb2; a.j[0].rows = d->he;
-        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d_mid(d) + 63) / 64), dim3(1024), 0, s, a);
     }
     if (g->g_x) {   // dx = Wb0^T dzb0
-        SmallTArgs a; a.n = 1; a.k = d->he; a.post = nullptr; a.out0 = g->g_x; a.out1 = nullptr;
-        a.j[0].W = d->base_w0; a.j[0].d = ws + W.dzb0; a.j[0].rows = d->he;
-        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(1024), 0, s, a);
+        SmallTArgs a; a.n = 1; a.k = d_in(d); a.post = nullptr; a.out0 = g->g_x; a.out1 = nullptr;
+        a.j[0].W = d->base_w0; a.j[0].d = ws + W.dzb0; a.j[0].rows = d_mid(d);
+        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d_in(d) + 63) / 64), dim3(1024), 0, s, a);
     }
     {   // dense weight grads (rank-1 outer products)
         OuterJobs oj; oj.n = 0; long b0 = 0;
@@ -458,8 +460,8 @@ extern "C" int caphn_hyper_backward(const caphn_hyper_desc* d, const float* dthe
             J.g = gv; J.a = av; J.out = out; J.rows = rows; J.k = k; J.block0 = b0;
             b0 += ((long)rows * k + 1023) / 1024;
         };
-        add(ws + W.dzb0, acts + L.x, g->g_base_w0, d->he, d->he);
-        add(ws + W.dzb2, acts + L.a0, g->g_base_w2, d->he, d->he);
+        add(ws + W.dzb0, acts + L.x, g->g_base_w0, d_mid(d), d_in(d));
+        add(ws + W.dzb2, acts + L.a0, g->g_base_w2, d->he, d_mid(d));
         for (int i = 0; i < nh; ++i) add(ws + W.dz[i], acts + L.base, g->g_w1[i], d->k[i], d->he);
         if (oj.n) hipLaunchKernelGGL(outer_kernel, dim3((unsigned)b0), dim3(256), 0, s, oj);
         // second-layer weight grads only when asked for (dense 576 MB at the canonical size)

@@ -202,5 +202,65 @@ class AttentionLstm(nn.Module):
 
 
 # names hypernet.py:11 imports from models.decoderlstm (they only exist in the import-less later.py)
-DecoderGRU = GruNet
-DecoderRNN = GruNet
+class _PlainDecoder(nn.Module):
+    """Shared body of DecoderGRU / DecoderRNN (later.py:227-457; hypernet.py:11 imports them from this module):
+    sub-modules `lstm_cell`, `layers`, `fc_out`, `embed`, `softmax`; forward(features[B,E], captions[B,T],
+    teacher_forcing=True) -> outputs [B,T,V]."""
+    _cell = "gru"
+
+    def __init__(self, embed_size, hidden_size, vocab_size, num_layers=1, dropout=False, vocab=None):
+        super().__init__()
+        self.embed_size = embed_size
+        self.hidden_size = hidden_size
+        self.vocab_size = vocab_size
+        self.dropout = dropout
+        self.num_layers = num_layers
+        self.vocab = vocab            # the reference unpickles data/vocab.pkl here (later.py:372-373); only used for text dumps
+        Cell = nn.GRUCell if self._cell == "gru" else nn.LSTMCell
+        self.lstm_cell = Cell(input_size=embed_size, hidden_size=hidden_size)          # named lstm_cell in both classes
+        self.layers = None
+        if num_layers > 1:
+            self.layers = nn.ModuleList([Cell(input_size=hidden_size, hidden_size=hidden_size) for _ in range(num_layers - 1)])
+        self.fc_out = nn.Linear(in_features=hidden_size, out_features=vocab_size)
+        self.embed = nn.Embedding(num_embeddings=vocab_size, embedding_dim=embed_size)
+        self.softmax = nn.Softmax(dim=1)
+
+    def _named_tensors(self):
+        t = {"fc_out.weight": self.fc_out.weight, "fc_out.bias": self.fc_out.bias, "embed.weight": self.embed.weight}
+        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            t["lstm_cell." + n] = getattr(self.lstm_cell, n)
+            for l in range(self.num_layers - 1):
+                t[f"layers.{l}.{n}"] = getattr(self.layers[l], n)
+        return t
+
+    def _initial_state(self, batch_size, like):
+        raise NotImplementedError
+
+    def forward(self, features, captions, teacher_forcing=True):
+        if not teacher_forcing:
+            raise NotImplementedError("the sampled branch draws torch.multinomial per step (later.py:424-426); only teacher "
+                                      "forcing is fused")
+        if self.dropout:
+            raise NotImplementedError("dropout=True is not supported by the fused HIP path (hypernet.py:51 passes False)")
+        B, T = captions.shape
+        dims = ops.PlainDims(B, T, self.embed_size, self.hidden_size, self.vocab_size, self.num_layers, self._cell)
+        h0, c0 = self._initial_state(B, features)
+        return CF.plain_decoder_forward(dims, features, captions, h0, c0, self._named_tensors())
+
+
+class DecoderGRU(_PlainDecoder):
+    """later.py:362-457.  The initial hidden state is torch.rand on the CPU generator, as in the reference (:397-398)."""
+    _cell = "gru"
+
+    def _initial_state(self, batch_size, like):
+        h0 = torch.rand(size=(batch_size, self.hidden_size)).to(device=like.device, dtype=torch.float32)
+        return h0, None
+
+
+class DecoderRNN(_PlainDecoder):
+    """later.py:227-330 (LSTM cells, zero initial states :259-262)."""
+    _cell = "lstm"
+
+    def _initial_state(self, batch_size, like):
+        z = torch.zeros(batch_size, self.hidden_size, device=like.device, dtype=torch.float32)
+        return z, z.clone()

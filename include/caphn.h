@@ -73,18 +73,21 @@ int caphn_colsum_f32(int M, int N, const float* A, int lda, float* out, void* ws
  */
 #define CAPHN_MAX_HEADS 8
 typedef struct caphn_hyper_desc {
-    int he;                       /* hypernet input width                        */
-    int n_heads;                  /* 4 for GRUCell / LSTMCell                    */
+    int he;                       /* width of the base output = input width of every head (also of x and of the base's
+                                     hidden layer unless d_in / d_mid say otherwise)                                     */
+    int n_heads;                  /* 4 for GRUCell / LSTMCell, 8 for hypernet.py's two-layer decoder                     */
     int k[CAPHN_MAX_HEADS];       /* hidden width of head i                      */
     int w[CAPHN_MAX_HEADS];       /* output size of head i (= numel of the generated parameter) */
     const float* base_w0; const float* base_b0;   /* hn_base.0  [he,he],[he] */
     const float* base_w2; const float* base_b2;   /* hn_base.2  [he,he],[he] */
     const float* w1[CAPHN_MAX_HEADS]; const float* b1[CAPHN_MAX_HEADS]; /* hn_heads.i.0 [k_i,he],[k_i] */
     const float* w2[CAPHN_MAX_HEADS]; const float* b2[CAPHN_MAX_HEADS]; /* hn_heads.i.2 [w_i,k_i],[w_i] */
+    int d_in, d_mid;              /* 0 = he.  hypernet.py:55-60 builds hn_base = Linear(E,4E), LeakyReLU, Linear(4E,8E),
+                                     LeakyReLU: d_in = E, d_mid = 4E, he = 8E; base_w0 [d_mid,d_in], base_w2 [he,d_mid]  */
 } caphn_hyper_desc;
 
 /* acts layout (floats), every segment padded to a multiple of 4 floats:
- * [x (he) | a0 (he) | base (he) | a_0 (k_0) | ... | a_{n-1}] ; size = caphn_hyper_acts_floats; acts must be 16-byte aligned */
+ * [x (d_in) | a0 (d_mid) | base (he) | a_0 (k_0) | ... | a_{n-1}] ; size = caphn_hyper_acts_floats; acts must be 16-byte aligned */
 int caphn_hyper_acts_floats(const caphn_hyper_desc* d);
 /* theta[sum w_i] = cat_i head_i(hn_base(x)); acts receives the post-LeakyReLU activations
  * needed by the backward (and, data-parallel, exchanged as rank-1 factors). */
@@ -103,7 +106,7 @@ typedef struct caphn_hyper_grads {
     float* g_base_w0; float* g_base_b0; float* g_base_w2; float* g_base_b2;
     float* g_w1[CAPHN_MAX_HEADS]; float* g_b1[CAPHN_MAX_HEADS];
     float* g_w2[CAPHN_MAX_HEADS]; float* g_b2[CAPHN_MAX_HEADS];
-    float* g_x;                   /* [he] gradient w.r.t. the style/domain embedding row */
+    float* g_x;                   /* [d_in] gradient w.r.t. the style/domain embedding row */
 } caphn_hyper_grads;
 size_t caphn_hyper_backward_workspace_bytes(const caphn_hyper_desc* d);
 /* VJP of caphn_hyper_forward with dtheta (what autograd would give the reference had utils.py:57
@@ -225,6 +228,36 @@ int caphn_decoder_search_steps(const caphn_decoder_dims* d, const caphn_decoder_
 int caphn_decoder_search_result(const caphn_decoder_dims* d, const caphn_search_cfg* c, int steps_done, void* ws, void* search_ws,
                                 int64_t* seqs, int* lengths, float* scores, int* finished, int* n_active,
                                 caphn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Non-attention decoders of the older hypernet path: DecoderGRU [later.py:362-457] and DecoderRNN
+ * [later.py:227-330] as constructed by hypernet.py:50-53, teacher forced:
+ *   x_0 = features[B,E] (image embedding), x_t = embed[caps[:,t-1]];  h = cell(x_t, h);
+ *   for each extra layer: h = layer(h, h)  (LSTM: (h,c) = layer(h,(h,c)));  logits[:,t] = fc_out(h).
+ * h0 (and c0 for the LSTM) come from the caller: DecoderGRU draws torch.rand (later.py:397), DecoderRNN zeros (:259).
+ * Layer 0 has w_ih [NG*H, E]; layers >= 1 have w_ih [NG*H, H]; w_hh [NG*H, H]; gate order as torch's cells.
+ * Every pointer may alias another layer's (hypernet.py injects overlapping views of theta, utils.py:68).
+ */
+#define CAPHN_MAX_LAYERS 4
+typedef struct caphn_plain_dims { int B, T, E, H, V, L, cell; } caphn_plain_dims;
+typedef struct caphn_plain_params {
+    const float* embed_w; const float* out_w; const float* out_b;      /* embed.weight [V,E], fc_out.weight [V,H], .bias [V] */
+    const float* w_ih[CAPHN_MAX_LAYERS]; const float* w_hh[CAPHN_MAX_LAYERS];
+    const float* b_ih[CAPHN_MAX_LAYERS]; const float* b_hh[CAPHN_MAX_LAYERS];
+} caphn_plain_params;
+typedef struct caphn_plain_grads {
+    float* embed_w; float* out_w; float* out_b;
+    float* w_ih[CAPHN_MAX_LAYERS]; float* w_hh[CAPHN_MAX_LAYERS]; float* b_ih[CAPHN_MAX_LAYERS]; float* b_hh[CAPHN_MAX_LAYERS];
+    float* features;               /* [B,E] gradient w.r.t. the image embedding (optional) */
+} caphn_plain_grads;
+size_t caphn_plain_workspace_bytes(const caphn_plain_dims* d);
+int caphn_plain_forward(const caphn_plain_dims* d, const caphn_plain_params* p, const float* features,
+                        const int64_t* captions, const float* h0, const float* c0, float* logits, void* ws,
+                        caphn_stream_t stream);
+/* Needs the workspace as the forward left it.  Gradient buffers are distinct (non-aliasing) arrays. */
+int caphn_plain_backward(const caphn_plain_dims* d, const caphn_plain_params* p, const float* features,
+                         const int64_t* captions, const float* h0, const float* c0, const float* dlogits,
+                         const caphn_plain_grads* g, void* ws, caphn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Loss: F.cross_entropy(logits.view(-1,V), caps.view(-1), ignore_index)   [hypernet_attention.py:183,

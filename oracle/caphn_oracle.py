@@ -370,6 +370,138 @@ def beam_search(p: Dict[str, Tensor], cellw: Dict[str, Tensor], features: Tensor
     return best, best_score, complete, complete_scores, margin
 
 
+# --------------------------------------------------------------------------
+# N3: hypernet.py + later.py (non-attention multi-layer decoders)
+# --------------------------------------------------------------------------
+@dataclass
+class PlainDims:
+    """hypernet.py:27 HyperNet(embed_size, hidden_size, vocab_size, vocab, num_layers, type)."""
+    E: int = 200
+    H: int = 150
+    V: int = 9684
+    L: int = 2
+    cell: str = "gru"
+
+    @property
+    def gates(self) -> int:
+        return 4 if self.cell == "lstm" else 3
+
+    def cell_param_shapes(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        """captioner.named_parameters() minus embed / fc_out, in order (later.py:376-379: lstm_cell, then layers)."""
+        G, E, H = self.gates * self.H, self.E, self.H
+        s = [("lstm_cell.weight_ih", (G, E)), ("lstm_cell.weight_hh", (G, H)), ("lstm_cell.bias_ih", (G,)),
+             ("lstm_cell.bias_hh", (G,))]
+        for l in range(self.L - 1):
+            s += [(f"layers.{l}.weight_ih", (G, H)), (f"layers.{l}.weight_hh", (G, H)), (f"layers.{l}.bias_ih", (G,)),
+                  (f"layers.{l}.bias_hh", (G,))]
+        return s
+
+    def theta_size(self) -> int:
+        return sum(int(np.prod(sh)) for _, sh in self.cell_param_shapes())
+
+
+def plain_head_layout(d: PlainDims) -> List[Tuple[int, int]]:
+    """(k_i, w_i) of every head by the M = 8 rule of hypernet.py:69-91 (head input is 8E wide)."""
+    out = []
+    for _, shape in d.cell_param_shapes():
+        w = int(np.prod(shape))
+        if w < 8 * d.E:
+            k = w                      # Linear(8E, w), LeakyReLU, Linear(w, w)
+        elif w // 8 < 8 * d.E:
+            k = 8 * d.E
+        else:
+            k = w // 8
+        out.append((k, w))
+    return out
+
+
+def plain_param_shapes(d: PlainDims) -> List[Tuple[str, Tuple[int, ...]]]:
+    E = d.E
+    s = [("hn_base.0.weight", (4 * E, E)), ("hn_base.0.bias", (4 * E,)), ("hn_base.2.weight", (8 * E, 4 * E)),
+         ("hn_base.2.bias", (8 * E,))]
+    for i, (k, w) in enumerate(plain_head_layout(d)):
+        s += [(f"hn_heads.{i}.0.weight", (k, 8 * E)), (f"hn_heads.{i}.0.bias", (k,)),
+              (f"hn_heads.{i}.2.weight", (w, k)), (f"hn_heads.{i}.2.bias", (w,))]
+    s += [("captioner.embed.weight", (d.V, E)), ("captioner.fc_out.weight", (d.V, d.H)), ("captioner.fc_out.bias", (d.V,))]
+    return s
+
+
+def init_plain_params(d: PlainDims, seed: int = 0) -> Dict[str, Tensor]:
+    """Seeded numpy-PCG64 initialisation (torch-default distributions), as init_params."""
+    rng = np.random.default_rng(seed)
+    shapes = dict(plain_param_shapes(d))
+    p: Dict[str, Tensor] = {}
+    for name, shape in plain_param_shapes(d):
+        if name == "captioner.embed.weight":
+            a = rng.standard_normal(shape, dtype=np.float32)
+        else:
+            fan_in = shapes[name[:-5] + ".weight"][1] if name.endswith(".bias") else shape[1]
+            b = 1.0 / math.sqrt(fan_in)
+            a = rng.uniform(-b, b, size=shape).astype(np.float32)
+        p[name] = torch.from_numpy(a)
+    return p
+
+
+def plain_inject(d: PlainDims, theta: Tensor) -> List[Dict[str, Tensor]]:
+    """flip_parameters_to_tensors / set_all_parameters on the WHOLE captioner (hypernet.py:112-113).  The
+    captioner itself holds no parameters; each child restarts at offset 0 (utils.py:62-68, `count` is only summed
+    on return), so lstm_cell reads theta[0:n0] and every extra layer reads theta[0:n_l] again -- overlapping
+    views; the slices produced by the layers' own heads are never used.  Returns one dict per layer."""
+    theta = theta.reshape(-1)
+    G, E, H = d.gates * d.H, d.E, d.H
+    out = []
+    for l in range(d.L):
+        off, cur = 0, {}
+        for name, shape in [("weight_ih", (G, E if l == 0 else H)), ("weight_hh", (G, H)), ("bias_ih", (G,)), ("bias_hh", (G,))]:
+            n = int(np.prod(shape))
+            cur[name] = theta[off:off + n].reshape(shape)
+            off += n
+        out.append(cur)
+    return out
+
+
+def plain_decoder_forward(d: PlainDims, p: Dict[str, Tensor], cells: List[Dict[str, Tensor]], features: Tensor,
+                          captions: Tensor, h0: Tensor, c0: Optional[Tensor] = None) -> Tensor:
+    """DecoderGRU.forward (later.py:394-447) / DecoderRNN.forward (:254-317), teacher forcing.  h0: the reference
+    draws torch.rand (GRU, :397) or zeros (LSTM, :259-262); passed in so both sides use the same values."""
+    B, T = captions.shape
+    emb = F_.embedding(captions, p["captioner.embed.weight"])
+    h, c = h0, c0
+    outs = []
+    for t in range(T):
+        x = features if t == 0 else emb[:, t - 1, :]
+        if d.cell == "gru":
+            h = gru_cell(x, h, cells[0])
+            for l in range(1, d.L):
+                h = gru_cell(h, h, cells[l])
+        else:
+            h, c = lstm_cell(x, h, c, cells[0])
+            for l in range(1, d.L):
+                h, c = lstm_cell(h, h, c, cells[l])
+        outs.append(F_.linear(h, p["captioner.fc_out.weight"], p["captioner.fc_out.bias"]))
+    return torch.stack(outs, dim=1)
+
+
+def plain_forward_backward(d: PlainDims, p: Dict[str, Tensor], features: Tensor, captions: Tensor, h0: Tensor,
+                           c0: Optional[Tensor] = None, style_token: int = 4):
+    """One step of hypernet.py:126-146 (Flickr protocol: x = embed(style), loss WITHOUT ignore_index) with the
+    generated weights left attached, so the hypernet receives the VJP ("intended" gradients, as for the attention
+    path).  Returns (loss, logits, theta, grads incl. 'features', dtheta)."""
+    names = [n for n, _ in plain_param_shapes(d)]
+    q = {n: p[n].clone().requires_grad_(True) for n in names}
+    feats = features.clone().requires_grad_(True)
+    x = q["captioner.embed.weight"][torch.tensor([style_token])]
+    theta = hyper_forward(q, x, n_heads=len(plain_head_layout(d)))
+    theta.retain_grad()
+    cells = plain_inject(d, theta)
+    logits = plain_decoder_forward(d, q, cells, feats, captions, h0, c0)
+    loss = F_.cross_entropy(logits.reshape(-1, d.V), captions.reshape(-1))
+    loss.backward()
+    grads = {n: (q[n].grad if q[n].grad is not None else torch.zeros_like(q[n])) for n in names}
+    grads["features"] = feats.grad
+    return loss.detach(), logits.detach(), theta.detach(), grads, theta.grad.detach()
+
+
 def caption_loss(logits: Tensor, captions: Tensor, pad: int = 0) -> Tensor:
     """hypernet_attention.py:183 / cc_train_hypernet.py:153: target at step t is
     caps[:,t]; mean over non-<pad> targets."""

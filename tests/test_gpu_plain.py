@@ -1,0 +1,176 @@
+"""GPU parity of the N3 row: hypernet.py's wider hypernet + later.py's non-attention DecoderGRU / DecoderRNN
+(caphn_plain_forward / _backward, caphn_hyper_* with d_in / d_mid) against vectors produced by the reference's
+own later.py classes and utils.py injection (child-offset restart included), through the C ABI and through the
+drop-in modules.  fp32 tolerance 2e-6 absolute on O(1) values (5e-6 where split-K atomics reorder long sums)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import caphn_oracle as O
+from helpers import GOLDEN, load_case, maxdiff
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ATOL = 2e-6
+CASES = ["plain_gru_l2", "plain_gru_b3", "plain_lstm_l2"]
+
+
+def _dims(name):
+    with open(os.path.join(GOLDEN, "meta.json")) as f:
+        m = json.load(f)[name]
+    return O.PlainDims(**m["dims"]), m
+
+
+def _check_common(g, d, logits, loss):
+    cols = g["cols"].long()
+    assert maxdiff(logits.cpu()[:, :, cols], g["logits_cols"]) < ATOL
+    assert torch.equal(logits.argmax(-1).cpu(), g["tokens"])
+    assert abs(float(loss) - float(g["loss"])) < ATOL
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_c_abi_forward_backward(name):
+    from caphn import ops
+    d, m = _dims(name)
+    g, _ = load_case(name)
+    p = {k: v.to(DEV) for k, v in O.init_plain_params(d, int(g["seed"])).items()}
+    shape = ops.HyperShape(8 * d.E, [tuple(x) for x in O.plain_head_layout(d)], d_in=d.E, d_mid=4 * d.E)
+    hp = {k: v for k, v in p.items() if k.startswith("hn_")}
+    x = p["captioner.embed.weight"][int(g["style_token"])].clone()
+    theta, acts = ops.hyper_forward(shape, hp, x)
+    assert maxdiff(theta.cpu(), g["theta"]) < ATOL
+    # utils.py:62-68 -- every layer reads theta from offset 0
+    cells = O.plain_inject(d, theta)
+    params = {"embed.weight": p["captioner.embed.weight"], "fc_out.weight": p["captioner.fc_out.weight"],
+              "fc_out.bias": p["captioner.fc_out.bias"]}
+    for li, cw in enumerate(cells):
+        for n, t in cw.items():
+            params[("lstm_cell." if li == 0 else f"layers.{li - 1}.") + n] = t.contiguous()
+    B, T = g["captions"].shape
+    pd = ops.PlainDims(B, T, d.E, d.H, d.V, d.L, d.cell)
+    feats, caps, h0 = g["features"].to(DEV), g["captions"].to(DEV), g["h0"].to(DEV)
+    c0 = torch.zeros_like(h0) if d.cell == "lstm" else None
+    ws = ops.plain_workspace(pd, DEV)
+    logits = ops.plain_forward(pd, params, feats, caps, h0, c0, ws)
+    out, dlogits = ops.cross_entropy_fwd_bwd(logits.view(B * T, d.V), caps.view(-1), ignore_index=-100)
+    _check_common(g, d, logits, out[0])
+    grads = {n: torch.empty(s, device=DEV) for n, s in pd.param_shapes().items()}
+    dfeat = torch.empty_like(feats)
+    ops.plain_backward(pd, params, feats, caps, h0, c0, dlogits.view(B, T, d.V), grads, ws, dfeat)
+    assert maxdiff(dfeat.cpu(), g["dfeatures"]) < ATOL
+    rows = g["rows"].long()
+    for key, nm in (("gfc_w", "fc_out.weight"), ("gfc_b", "fc_out.bias")):
+        assert maxdiff(grads[nm].cpu()[rows], g[key + "_rows"]) < ATOL, key
+        assert abs(float(grads[nm].double().norm()) - float(g[key + "_norm"])) < 1e-5, key
+    dtheta = torch.zeros_like(theta)
+    for li in range(d.L):
+        off = 0
+        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            full = ("lstm_cell." if li == 0 else f"layers.{li - 1}.") + n
+            assert maxdiff(grads[full].cpu(), g["glit/" + full]) < ATOL, full
+            dtheta[off:off + grads[full].numel()] += grads[full].flatten()
+            off += grads[full].numel()
+    assert maxdiff(dtheta.cpu(), g["dtheta"]) < ATOL
+    hg = {n: torch.empty(s, device=DEV) for n, s in shape.param_shapes().items()}
+    gx = ops.hyper_backward(shape, hp, dtheta, acts, hg, want_x=True)
+    for k, v in g.items():
+        if k.startswith("gint/hn_"):
+            assert maxdiff(hg[k[5:]].cpu(), v) < ATOL, k
+        elif k.startswith("gint_rows/"):
+            assert maxdiff(hg[k[10:]].cpu()[:32], v) < ATOL, k
+            assert abs(float(hg[k[10:]].double().norm()) - float(g["gint_norm/" + k[10:]])) < 1e-5, k
+    # the style row of embed receives gx on top of the decoder's gradient (hypernet.py:127-131)
+    tok = int(g["style_token"])
+    ge = grads["embed.weight"].clone(); ge[tok] += gx
+    assert maxdiff(ge.cpu()[rows], g["gembed_rows"]) < ATOL
+    assert abs(float(ge.double().norm()) - float(g["gembed_norm"])) < 1e-5
+
+
+class _Vocab:
+    w2i = {"<pad>": 0, "<s>": 1, "</s>": 2, "<unk>": 3, "factual": 4}
+
+    def __call__(self, w):
+        return self.w2i.get(w, 3)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_module_api_hypernet_py(name):
+    """hypernet.HyperNet(embed, hidden, vocab_size, vocab, num_layers, type) -> training_step protocol."""
+    from hypernet import HyperNet
+    d, m = _dims(name)
+    g, _ = load_case(name)
+    p = O.init_plain_params(d, int(g["seed"]))
+    net = HyperNet(d.E, d.H, d.V, _Vocab(), num_layers=d.L, type=d.cell if d.cell == "gru" else "lstm")
+    res = net.load_state_dict(p, strict=False)
+    assert not res.unexpected_keys
+    assert all(k.startswith(("captioner.lstm_cell.", "captioner.layers.", "image_encoder.")) for k in res.missing_keys), res
+    assert [(h[0].out_features, h[2].out_features) for h in net.hn_heads] == [tuple(x) for x in m["heads"]]
+    net = net.to(DEV)
+    feats = g["features"].to(DEV).requires_grad_(True)
+    caps = g["captions"].to(DEV)
+    style = torch.tensor([int(g["style_token"])], device=DEV)
+    cap = net(net.captioner.embed(style))
+    assert cap.lstm_cell.registered_parameters_name == ["weight_ih", "weight_hh", "bias_ih", "bias_hh"]
+    torch.manual_seed(int(g["seed"]))                  # DecoderGRU draws torch.rand for h0 (later.py:397)
+    logits = cap(feats, caps, True)
+    loss = F.cross_entropy(logits.view(-1, d.V), caps.view(-1))
+    _check_common(g, d, logits.detach(), loss.detach())
+    loss.backward()
+    assert maxdiff(feats.grad.cpu(), g["dfeatures"]) < ATOL
+    rows = g["rows"].long()
+    assert maxdiff(net.captioner.embed.weight.grad.cpu()[rows], g["gembed_rows"]) < ATOL
+    assert maxdiff(net.captioner.fc_out.weight.grad.cpu()[rows], g["gfc_w_rows"]) < ATOL
+    assert maxdiff(net.captioner.fc_out.bias.grad.cpu()[rows], g["gfc_b_rows"]) < ATOL
+    sd = dict(net.named_parameters())
+    for k, v in g.items():
+        if k.startswith("gint/hn_"):
+            assert maxdiff(sd[k[5:]].grad.cpu(), v) < ATOL, k
+        elif k.startswith("gint_rows/"):
+            assert maxdiff(sd[k[10:]].grad.cpu()[:32], v) < ATOL, k
+    with pytest.raises(NotImplementedError):
+        cap(feats, caps, False)
+
+
+@pytest.mark.parametrize("cell,L", [("gru", 1), ("gru", 3), ("lstm", 2)])
+def test_medium_size_vs_oracle(cell, L):
+    """B=32, T=12, E=64, H=48 (odd multiples, H not a multiple of 32), V=777: C ABI vs the oracle."""
+    from caphn import ops
+    d = O.PlainDims(E=64, H=48, V=777, L=L, cell=cell)
+    p = O.init_plain_params(d, 5)
+    rng = np.random.default_rng(11)
+    B, T = 32, 12
+    feats = torch.from_numpy(rng.standard_normal((B, d.E), dtype=np.float32))
+    caps = torch.from_numpy(rng.integers(0, d.V, size=(B, T)))
+    h0 = torch.from_numpy(rng.random((B, d.H), dtype=np.float32))
+    c0 = torch.zeros(B, d.H) if cell == "lstm" else None
+    loss, logits, theta, grads, dtheta = O.plain_forward_backward(d, p, feats, caps, h0, c0, 4)
+    cells = O.plain_inject(d, theta.to(DEV))
+    params = {"embed.weight": p["captioner.embed.weight"].to(DEV), "fc_out.weight": p["captioner.fc_out.weight"].to(DEV),
+              "fc_out.bias": p["captioner.fc_out.bias"].to(DEV)}
+    for li, cw in enumerate(cells):
+        for n, t in cw.items():
+            params[("lstm_cell." if li == 0 else f"layers.{li - 1}.") + n] = t.contiguous()
+    pd = ops.PlainDims(B, T, d.E, d.H, d.V, L, cell)
+    ws = ops.plain_workspace(pd, DEV)
+    f, c, h = feats.to(DEV), caps.to(DEV), h0.to(DEV)
+    cz = c0.to(DEV) if c0 is not None else None
+    lg = ops.plain_forward(pd, params, f, c, h, cz, ws)
+    assert maxdiff(lg.cpu(), logits) < 5e-6
+    l2, dl = ops.cross_entropy_fwd_bwd(lg.view(B * T, d.V), c.view(-1), ignore_index=-100)
+    assert abs(float(l2[0]) - float(loss)) < 5e-6
+    gr = {n: torch.empty(s, device=DEV) for n, s in pd.param_shapes().items()}
+    df = torch.empty_like(f)
+    ops.plain_backward(pd, params, f, c, h, cz, dl.view(B, T, d.V), gr, ws, df)
+    assert maxdiff(df.cpu(), grads["features"]) < 5e-6
+    assert maxdiff(gr["fc_out.weight"].cpu(), grads["captioner.fc_out.weight"]) < 5e-6
+    dth = torch.zeros(d.theta_size(), device=DEV)
+    for li in range(L):
+        off = 0
+        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            t = gr[("lstm_cell." if li == 0 else f"layers.{li - 1}.") + n]
+            dth[off:off + t.numel()] += t.flatten(); off += t.numel()
+    assert maxdiff(dth.cpu(), dtheta) < 5e-6

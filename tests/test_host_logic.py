@@ -107,7 +107,11 @@ def test_module_names_match_reference_state_dict():
               "attention.W_a.weight", "attention.U_a.bias", "attention.v_a.weight", "init_h.bias"]:
         assert k in keys
     assert sum(p.numel() for p in AttentionGru(2048, 200, 200, 200, 9684).parameters()) == 4815285
-    assert issubclass(GruNet, AttentionGru) and DecoderGRU is GruNet and DecoderRNN is GruNet
+    assert issubclass(GruNet, AttentionGru)
+    assert set(DecoderGRU(8, 6, 30, num_layers=2).state_dict()) == {
+        'lstm_cell.weight_ih', 'lstm_cell.weight_hh', 'lstm_cell.bias_ih', 'lstm_cell.bias_hh', 'layers.0.weight_ih',
+        'layers.0.weight_hh', 'layers.0.bias_ih', 'layers.0.bias_hh', 'fc_out.weight', 'fc_out.bias', 'embed.weight'}
+    assert isinstance(DecoderRNN(8, 6, 30).lstm_cell, nn.LSTMCell)
 
 
 def test_no_cpu_fallback():

@@ -231,3 +231,55 @@ def test_greedy_and_beam_search():
     with open(os.path.join(GOLDEN, "meta.json")) as f:
         meta = json.load(f)["gru_search"]
     assert len(set(meta["greedy_len"])) >= 3 and len(set(meta["beam_len"])) >= 3
+
+
+PLAIN_CASES = ["plain_gru_l2", "plain_gru_b3", "plain_lstm_l2"]
+
+
+def plain_dims(name):
+    with open(os.path.join(GOLDEN, "meta.json")) as f:
+        m = json.load(f)[name]
+    return O.PlainDims(**m["dims"]), m
+
+
+@pytest.mark.parametrize("name", PLAIN_CASES)
+def test_plain_decoder_hypernet_py(name):
+    """N3: oracle restatement of hypernet.py + later.py vs the reference's own DecoderGRU / DecoderRNN classes
+    (later.py source executed by tools/make_golden.py) and its flip/set_all_parameters incl. the child-offset
+    restart: theta, logits (sampled columns, lse, argmax), loss, every gradient."""
+    d, m = plain_dims(name)
+    g, _ = load_case(name)
+    p = O.init_plain_params(d, int(g["seed"]))
+    assert m["heads"] == [list(x) for x in O.plain_head_layout(d)] and m["n_set"] == m["theta_size"] == d.theta_size()
+    c0 = torch.zeros_like(g["h0"]) if d.cell == "lstm" else None
+    loss, logits, theta, grads, dtheta = O.plain_forward_backward(d, p, g["features"], g["captions"], g["h0"], c0,
+                                                                  int(g["style_token"]))
+    assert maxdiff(theta, g["theta"]) < ATOL
+    cols = g["cols"].long()
+    assert maxdiff(logits[:, :, cols], g["logits_cols"]) < ATOL
+    assert maxdiff(torch.logsumexp(logits, -1), g["logits_lse"]) < 2e-5
+    assert torch.equal(logits.argmax(-1), g["tokens"])
+    assert abs(float(loss) - float(g["loss"])) < ATOL
+    assert maxdiff(dtheta, g["dtheta"]) < ATOL
+    n0 = sum(int(np.prod(sh)) for _, sh in d.cell_param_shapes()[:4])
+    assert float(dtheta[n0:].abs().sum()) == 0.0          # the extra layers' own slices are never used (utils.py:68)
+    assert maxdiff(grads["features"], g["dfeatures"]) < ATOL
+    rows = g["rows"].long()
+    for key, nm in (("gembed", "captioner.embed.weight"), ("gfc_w", "captioner.fc_out.weight"), ("gfc_b", "captioner.fc_out.bias")):
+        assert maxdiff(grads[nm][rows], g[key + "_rows"]) < ATOL, key
+        assert abs(float(grads[nm].double().norm()) - float(g[key + "_norm"])) < 1e-5, key
+    for k, v in g.items():
+        if k.startswith("gint/"):
+            assert maxdiff(grads[k[5:]], v) < ATOL, k
+        elif k.startswith("gint_rows/"):
+            assert maxdiff(grads[k[10:]][:32], v) < ATOL, k
+            assert abs(float(grads[k[10:]].double().norm()) - float(g["gint_norm/" + k[10:]])) < 1e-5, k
+    # literal leaf gradients of the overlapping views, layer by layer
+    theta_l = theta.clone().requires_grad_(True)
+    cells = O.plain_inject(d, theta_l)
+    leaves = [{n: t.detach().clone().requires_grad_(True) for n, t in cw.items()} for cw in cells]
+    lg = O.plain_decoder_forward(d, p, leaves, g["features"], g["captions"], g["h0"], c0)
+    torch.nn.functional.cross_entropy(lg.reshape(-1, d.V), g["captions"].reshape(-1)).backward()
+    for li, cw in enumerate(leaves):
+        for n, t in cw.items():
+            assert maxdiff(t.grad, g["glit/" + ("lstm_cell." if li == 0 else f"layers.{li - 1}.") + n]) < ATOL

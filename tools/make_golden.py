@@ -411,10 +411,128 @@ def search_case(name, dims, n_images, P, seed, end_bump, k=3, max_sentence=12, s
             "beam_margin": b_margin.tolist(), "beam_steps": b_steps.tolist(), "complete": comp}
 
 
+
+def _load_later_classes():
+    """later.py holds DecoderGRU / DecoderRNN but has no import statements (it cannot be imported as a module).
+    Its source is executed here in a namespace that supplies the names its authors had in scope.  Inert stand-ins:
+    `open` / `pickle.load` (the constructors read data/vocab.pkl only to keep a vocabulary for text dumps; nothing is
+    unpickled here) and `cap_to_text_gt` (id -> text, result unused by forward, later.py:449-450)."""
+    import io
+    ns = {"torch": torch, "nn": nn, "F": F, "np": np,
+          "pickle": types.SimpleNamespace(load=lambda f: None),
+          "open": lambda *a, **k: io.BytesIO(b""),
+          "cap_to_text_gt": lambda *a, **k: ""}
+    with open(os.path.join(REF, "later.py")) as f:
+        src = f.read()
+    exec(compile(src, os.path.join(REF, "later.py"), "exec"), ns)
+    return ns["DecoderGRU"], ns["DecoderRNN"]
+
+
+def plain_case(name, d, B, T, seed, style_token=4):
+    """hypernet.py's step with the reference's own DecoderGRU / DecoderRNN (later.py) and its own
+    flip_parameters_to_tensors / set_all_parameters (utils.py) on the whole captioner -- child-offset restart
+    included; HyperNet.__init__ (hypernet.py:55-93) is restated (the class needs downloads).  V must be 9684:
+    later.py:445 hard-codes it."""
+    assert d.V == 9684
+    DecoderGRU, DecoderRNN = _load_later_classes()
+    p = O.init_plain_params(d, seed)
+    Cls = DecoderGRU if d.cell == "gru" else DecoderRNN
+    cap = Cls(d.E, d.H, d.V, num_layers=d.L, dropout=False)
+    E = d.E
+    hn_base = nn.Sequential(nn.Linear(E, 4 * E), nn.LeakyReLU(), nn.Linear(4 * E, 8 * E), nn.LeakyReLU())
+    heads, order = [], []
+    for pname, W in cap.named_parameters():
+        if pname in ('embed.weight', 'fc_out.weight', 'fc_out.bias'):
+            continue
+        order.append(pname)
+        w_size = len(W.flatten())
+        if w_size < 8 * E:
+            heads.append(nn.Sequential(nn.Linear(8 * E, w_size), nn.LeakyReLU(), nn.Linear(w_size, w_size)))
+        elif w_size // 8 < 8 * E:
+            heads.append(nn.Sequential(nn.Linear(8 * E, 8 * E), nn.LeakyReLU(), nn.Linear(8 * E, w_size)))
+        else:
+            heads.append(nn.Sequential(nn.Linear(8 * E, w_size // 8), nn.LeakyReLU(), nn.Linear(w_size // 8, w_size)))
+    hn_heads = nn.ModuleList(heads)
+    assert order == [n for n, _ in d.cell_param_shapes()], order
+    assert [(h[0].out_features, h[2].out_features) for h in hn_heads] == O.plain_head_layout(d)
+    hn_base.load_state_dict({k[len("hn_base."):]: v.clone() for k, v in p.items() if k.startswith("hn_base.")})
+    hn_heads.load_state_dict({k[len("hn_heads."):]: v.clone() for k, v in p.items() if k.startswith("hn_heads.")})
+    res = cap.load_state_dict({k[len("captioner."):]: v.clone() for k, v in p.items() if k.startswith("captioner.")}, strict=False)
+    assert not res.unexpected_keys and all(k.startswith(("lstm_cell.", "layers.")) for k in res.missing_keys), res
+    rng = np.random.default_rng(seed + 1)
+    feats = torch.from_numpy(rng.standard_normal((B, E), dtype=np.float32)).requires_grad_(True)
+    caps = torch.from_numpy(rng.integers(0, d.V, size=(B, T)))
+    caps[:, 0] = 1
+    caps[0, T - 1] = 0                                  # a <pad> target: this loss has no ignore_index (hypernet.py:146)
+    x = cap.embed(torch.tensor([style_token]))          # hypernet.py:127-131
+    base_feat = hn_base(x)
+    theta = torch.cat([h(base_feat).flatten() for h in hn_heads], dim=0)
+    flip_parameters_to_tensors(cap)
+    n_set = set_all_parameters(cap, theta.reshape(1, -1))
+    torch.manual_seed(seed)
+    h0 = torch.rand(size=(B, d.H)) if d.cell == "gru" else torch.zeros(B, d.H)
+    torch.manual_seed(seed)                             # DecoderGRU.forward draws the same torch.rand (later.py:397)
+    logits = cap(feats, caps, True)
+    loss = F.cross_entropy(logits.view(-1, d.V), caps.view(-1).long())
+    loss.backward()
+    # literal leaf grads of the injected Parameters, then dtheta by the same overlapping slicing, then the hypernet VJP
+    cells = [cap.lstm_cell] + (list(cap.layers) if cap.layers else [])
+    dtheta = torch.zeros_like(theta)
+    lit = {}
+    for li, cell in enumerate(cells):
+        off = 0
+        for nm in cell.registered_parameters_name:
+            gq = getattr(cell, nm).grad
+            lit[("lstm_cell." if li == 0 else f"layers.{li - 1}.") + nm] = gq.detach().clone()
+            dtheta[off:off + gq.numel()] += gq.flatten()
+            off += gq.numel()
+    theta.backward(dtheta)
+    cols = np.sort(rng.choice(d.V, size=192, replace=False)); cols[:3] = [0, 1, 2]; cols = np.sort(np.unique(cols))
+    rows = np.unique(np.concatenate([caps.numpy().reshape(-1), [style_token]]))
+    arrs = {"features": feats.detach(), "captions": caps, "h0": h0, "style_token": np.int64(style_token),
+            "seed": np.int64(seed), "theta": theta.detach(), "dtheta": dtheta, "loss": loss.detach(),
+            "cols": cols, "logits_cols": logits.detach()[:, :, cols], "tokens": logits.detach().argmax(-1),
+            "logits_lse": torch.logsumexp(logits.detach(), -1), "logits_sum": np.float64(logits.detach().double().sum()),
+            "dfeatures": feats.grad.detach(), "rows": rows,
+            "gembed_rows": cap.embed.weight.grad.detach()[rows], "gembed_norm": np.float64(cap.embed.weight.grad.double().norm()),
+            "gfc_w_rows": cap.fc_out.weight.grad.detach()[rows], "gfc_w_norm": np.float64(cap.fc_out.weight.grad.double().norm()),
+            "gfc_b_rows": cap.fc_out.bias.grad.detach()[rows], "gfc_b_norm": np.float64(cap.fc_out.bias.grad.double().norm())}
+    for k, v in lit.items():
+        arrs["glit/" + k] = v
+    for n, q in hn_base.named_parameters():
+        arrs["gint/hn_base." + n] = q.grad.detach()
+    for n, q in hn_heads.named_parameters():
+        if q.grad.numel() > 20000:       # rank-1 (dtheta slice x hidden activations): keep 32 rows and the norm
+            arrs["gint_rows/hn_heads." + n] = q.grad.detach()[:32]
+            arrs["gint_norm/hn_heads." + n] = np.float64(q.grad.double().norm())
+        else:
+            arrs["gint/hn_heads." + n] = q.grad.detach()
+    save_npz(os.path.join(OUT, name + ".npz"), **arrs)
+    return {"order": order, "n_set": int(n_set), "heads": O.plain_head_layout(d), "theta_size": int(theta.numel()),
+            "dims": {"E": d.E, "H": d.H, "V": d.V, "L": d.L, "cell": d.cell}, "B": B, "T": T,
+            "dtheta_tail_abs_sum": float(dtheta[sum(int(np.prod(sh)) for _, sh in d.cell_param_shapes()[:4]):].abs().sum())}
+
+
+PLAIN_CASES = {   # name: (dims, B, T, seed); E=12,H=10 -> head branches 2 and 1; E=4,H=24 -> branches 3 and 2
+    "plain_gru_l2": (dict(E=12, H=10, V=9684, L=2, cell="gru"), 3, 5, 71),
+    "plain_gru_b3": (dict(E=4, H=24, V=9684, L=1, cell="gru"), 2, 4, 72),
+    "plain_lstm_l2": (dict(E=12, H=10, V=9684, L=2, cell="lstm"), 3, 5, 73),
+}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     meta = {"torch": torch.__version__, "reference": "zacharie12/Hypernet-image-captioning @ /root/reference"}
+    if "--only-plain" in sys.argv:             # refresh the hypernet.py / later.py vectors only
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        for nm, (dd, B, T, sd) in PLAIN_CASES.items():
+            meta[nm] = plain_case(nm, O.PlainDims(**dd), B, T, sd)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        print(json.dumps({k: meta[k] for k in PLAIN_CASES}, indent=1)[:3000])
+        return
     if "--only-search" in sys.argv:            # refresh the search vectors, keep everything else as committed
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -435,6 +553,8 @@ def main():
     meta["gru_odd_cc"] = tiny_case("gru_odd_cc", odd, B=5, T=9, P=10, seed=31, flickr=False, max_norm=5.0)
     meta["lstm_tiny"] = lstm_case("lstm_tiny", seed=41)
     meta["gru_search"] = search_case("gru_search", tiny, n_images=6, P=7, seed=462, end_bump=SEARCH_END_BUMP, sharpen=SEARCH_SHARPEN)
+    for nm, (dd, B, T, sd) in PLAIN_CASES.items():
+        meta[nm] = plain_case(nm, O.PlainDims(**dd), B, T, sd)
     if os.environ.get("CAPHN_GOLDEN_FULL", "1") == "1":
         meta["gru_full"] = full_case("gru_full", seed=2024)
     with open(os.path.join(OUT, "meta.json"), "w") as f:
