@@ -119,6 +119,8 @@ def main():
                          "GPU-bound either way (measured 2.958 vs 2.977 ms) and host launches let the HIP events around "
                          "the dominant kernel sit inside the timed region")
     ap.add_argument("--eager", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-overlap", action="store_true", help="do not issue the next batch's caption-independent "
+                    "precompute beside the optimiser")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,6 +146,8 @@ def main():
     torch.manual_seed(1234)                       # identical replicas on every rank
     net = HyperNet(F, E, H, V, _Vocab()).to(dev)
     tr = FusedTrainer(net, lr=1e-3, max_norm=5.0)
+    if os.environ.get("CAPHN_OVERLAP_AFTER_HEAD"):
+        tr.overlap_after_head = int(os.environ["CAPHN_OVERLAP_AFTER_HEAD"])
     batches = synth_batches(4, B, T, P, D, V, dev, seed=1234 + rank)
     style = 4 + (rank % 3)                        # one style domain per rank-batch
 
@@ -157,8 +161,11 @@ def main():
         do_step = tr.step_graphed if use_graph else tr.step
     else:
         # the loader is one batch ahead, so the next batch's style is known when the optimiser runs
+        nxt = {batches[i][0].data_ptr(): batches[(i + 1) % len(batches)][0] for i in range(len(batches))}
+
         def do_step(f, c, style_token):
-            return tr.step(f, c, style_token=style_token, next_style_token=style_token)
+            return tr.step(f, c, style_token=style_token, next_style_token=style_token,
+                           next_features=None if args.no_overlap else nxt[f.data_ptr()])
     if use_graph:                                  # two passes over the batch buffers: eager, then capture
         for _ in range(2):
             for f, c in batches:
@@ -224,6 +231,7 @@ def main():
                                                       sum(q.numel() for q in net.hn_heads.parameters())),
                        "parallelism": f"dp{world}", "launch": "hipGraph" if use_graph else "eager",
                        "next_theta_in_adam_pass": not (use_graph or args.no_prefetch),
+                       "next_precompute_beside_adam": not (use_graph or args.no_prefetch or args.no_overlap),
                        "final_loss": float(loss[0])},
             "roofline": {"bound": "hbm", "kernel": "adam_rank_kernel(hn_heads.0.2.weight)",
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

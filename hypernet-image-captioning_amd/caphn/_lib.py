@@ -33,7 +33,8 @@ class HyperGrads(C.Structure):
 
 
 class DecoderDims(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("B", "T", "P", "D", "F", "E", "H", "V", "cell", "raw_features", "row_subset")]
+    _fields_ = [(n, C.c_int) for n in ("B", "T", "P", "D", "F", "E", "H", "V", "cell", "raw_features", "row_subset",
+                                         "precomputed")]
 
 
 _DEC_FIELDS = ("fc0_w", "fc0_b", "fc2_w", "fc2_b", "embed_w", "out_w", "out_b", "Wa_w", "Wa_b",
@@ -92,6 +93,7 @@ SIGNATURES = {
     "caphn_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDims)]),
     "caphn_decoder_forward": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
                                         c_fp, c_fp, c_fp, c_fp]),
+    "caphn_decoder_precompute": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp, c_fp]),
     "caphn_decoder_prepare_rows": (C.c_int, [C.POINTER(DecoderDims), c_fp, C.c_int64, c_fp, c_fp]),
     "caphn_decoder_forward_sampled": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
                                                 C.c_char_p, c_fp, c_fp, c_fp, c_fp]),

@@ -70,6 +70,11 @@ class FusedTrainer:
         self._theta_next = None
         self._acts_next = torch.zeros_like(self._acts)
         self._next_key = None
+        # next-step feature_fc / init_hidden / W_a f issued on a side stream beside the small Adam passes
+        self._pre_stream = torch.cuda.Stream(device=dev)
+        self._pre_key = None
+        self._pre_done = torch.cuda.Event()
+        self.overlap_after_head = 0      # the side stream forks after this head's Adam pass (-1: before the first)
 
     # ------------------------------------------------------------------ parameter arenas
     def _build_arena(self):
@@ -215,7 +220,16 @@ class FusedTrainer:
         params = self._dec_tensors(theta, grads=False)
         if dims.rows:
             ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
-        ops.decoder_forward(dims, params, features, captions, buf["ws"], logits=buf["logits"], alphas=buf["alphas"],
+        fdims = dims
+        if self._pre_key is not None:
+            if self._pre_key == (features.data_ptr(), B, T, P) and not self._readopted:
+                import dataclasses
+                torch.cuda.current_stream().wait_event(self._pre_done)
+                fdims = dataclasses.replace(dims, pre=True)
+            else:       # the announced features did not come: the side-stream work is wasted but must finish first
+                torch.cuda.current_stream().wait_event(self._pre_done)
+            self._pre_key = None
+        ops.decoder_forward(fdims, params, features, captions, buf["ws"], logits=buf["logits"], alphas=buf["alphas"],
                             validate=validate)
         lib_loss, dlogits = ops.cross_entropy_fwd_bwd(buf["logits"], captions, 0, dlogits=buf["logits"])
         buf["loss"].copy_(lib_loss)
@@ -268,7 +282,7 @@ class FusedTrainer:
         self._adam_host[1] = b
         self._adam_dev.copy_(self._adam_host, non_blocking=True)
 
-    def _optimizer_impl(self, next_x_style=None, next_style_token=None):
+    def _optimizer_impl(self, next_x_style=None, next_style_token=None, next_batch=None):
         R = dp.world(self.group)
         gfac, acts_all = self._exchange()
         part = ops.sumsq_partials(self.flat_g, self._part)
@@ -301,6 +315,8 @@ class FusedTrainer:
             ops.hyper_forward_acts(self.shape, hp, xn, self._acts_next)
             if self._theta_next is None:
                 self._theta_next = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)
+        if next_batch is not None and self.overlap_after_head < 0:
+            self._precompute_next(*next_batch)
         for i, (gi, ai, o, w, ao, an) in enumerate(segs):
             kw = {}
             if prefetch:
@@ -308,19 +324,45 @@ class FusedTrainer:
                           next_theta=self._theta_next[o:o + w])
             ops.adam_rank(self.W2[i].data, self.W2_m[i], self.W2_v[i], gi, ai, self._coef, self.lr, step,
                           self.betas, self.eps, dev_scalars=self._adam_dev, **kw)
+            if i == self.overlap_after_head and next_batch is not None:
+                self._precompute_next(*next_batch)
         return self._coef
 
-    def optimizer_step(self, next_x_style=None, next_style_token=None):
+    def _precompute_next(self, features, T):
+        """The decoder's dense parameters are final (adam_dense ran) and the workspace is free (backward is done):
+        run the next minibatch's feature_fc / init_hidden / W_a f (MFMA-bound, 51 MB of reads) on a side stream
+        while the remaining Adam passes stream the hypernet (HBM-bound).  It starts after the head-0 pass, the
+        kernel the roofline figure is quoted on, so that one is measured undisturbed."""
+        B, P, _ = features.shape
+        buf = self._buffers(B, T, P)
+        params = {n: self._view(self.flat_p, "captioner." + n) for n in self._dec_names}
+        # the cell entries are not read by this part; hand over any correctly shaped tensors
+        theta = self._theta if getattr(self, "_theta", None) is not None else torch.empty(self.theta_size, device=self.dev)
+        params.update({n: t for n, t in self._dec_tensors(theta, grads=False).items() if n in self._cell_names})
+        main = torch.cuda.current_stream()
+        self._pre_stream.wait_stream(main)
+        with torch.cuda.stream(self._pre_stream):
+            ops.decoder_precompute(buf["dims"], params, features, buf["ws"])
+            self._pre_done.record(self._pre_stream)
+        self._pre_key = (features.data_ptr(), B, T, P)
+
+
+    def optimizer_step(self, next_x_style=None, next_style_token=None, next_batch=None):
         """clip_grad_norm_(max_norm) over ALL gradients + Adam, on device, no host sync.
         If the NEXT minibatch's style row is already known (the data loader is one batch ahead), pass it:
         the Adam pass over the big second-layer weights then also produces the next step's theta, saving that
         step's 576 MB forward read (the following forward_backward must be called with that same input)."""
         self._begin_step()
-        return self._optimizer_impl(next_x_style, next_style_token)
+        return self._optimizer_impl(next_x_style, next_style_token, next_batch)
 
-    def step(self, features, captions, x_style=None, style_token=None, next_x_style=None, next_style_token=None):
+    def step(self, features, captions, x_style=None, style_token=None, next_x_style=None, next_style_token=None,
+             next_features=None, next_T=None):
+        """next_features (+ next_T, default: this T): the NEXT minibatch's feature maps when the loader is one batch
+        ahead -- their caption-independent precompute then overlaps this step's optimiser (the next call must pass
+        that same tensor)."""
         loss = self.forward_backward(features, captions, x_style, style_token)
-        self.optimizer_step(next_x_style, next_style_token)
+        nb = None if next_features is None else (next_features, captions.shape[1] if next_T is None else next_T)
+        self.optimizer_step(next_x_style, next_style_token, nb)
         return loss
 
     def step_graphed(self, features, captions, x_style=None, style_token=None):

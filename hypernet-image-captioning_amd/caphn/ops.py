@@ -188,6 +188,7 @@ class DecDims:
     cell: str = "gru"        # "gru" (AttentionGru) or "lstm" (AttentionLstm)
     raw: bool = False        # True: no feature_fc, attention over the raw D-channel features (F == D)
     rows: bool = False       # True: vocab GEMMs only touch rows with a live target (decoder_prepare_rows first)
+    pre: bool = False        # True: decoder_precompute already ran on the workspace for these features
 
     @property
     def NG(self) -> int:
@@ -195,7 +196,7 @@ class DecDims:
 
     def c(self) -> L.DecoderDims:
         return L.DecoderDims(self.B, self.T, self.P, self.D, self.F, self.E, self.H, self.V,
-                             1 if self.cell == "lstm" else 0, int(self.raw), int(self.rows))
+                             1 if self.cell == "lstm" else 0, int(self.raw), int(self.rows), int(self.pre))
 
     def fields(self):
         """Ordered (C struct field, parameter name) pairs this configuration uses."""
@@ -254,6 +255,18 @@ def decoder_workspace(dims: DecDims, device) -> torch.Tensor:
     if n == 0:
         raise L.CaphnError("bad decoder dims")
     return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def decoder_precompute(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor, ws: torch.Tensor) -> None:
+    """feature_fc, init_hidden and W_a f of the forward for `features` (models/decoderlstm.py:61-63, attention.py:34),
+    issued ahead of the forward on the current stream; follow with decoder_forward(dims with pre=True)."""
+    lib = L.load()
+    if tuple(features.shape) != (dims.B, dims.P, dims.D):
+        raise L.CaphnError(f"features {tuple(features.shape)} do not match {dims}")
+    cd = dims.c()
+    ps = _dec_struct(L.DecoderParams, dims, params)
+    L.check(lib.caphn_decoder_precompute(C.byref(cd), C.byref(ps), L.ptr(features), C.c_void_p(ws.data_ptr()),
+                                         L.stream_ptr()), "caphn_decoder_precompute")
 
 
 def decoder_forward(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,

@@ -198,34 +198,38 @@ inline int gemm_auto(int ta, int tb, int M, int N, int K, const float* A, int ld
     return caphn_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, 0, flags, 1, s);
 }
 
-// feature_fc, init_hidden (+ init_c), W_a f, G = f W_ih[:,E:]^T  -- everything that does not depend on the captions
+// feature_fc, init_hidden (+ init_c), W_a f, G = f W_ih[:,E:]^T  -- everything that does not depend on the captions.
+// part 1 (theta-independent: feature_fc, init_hidden, W_a f) can be issued ahead of time by caphn_decoder_precompute
+// (dims.precomputed = 1 then skips it here); part 2 is the G GEMM, which needs the generated W_ih.
 static int decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_params* p, const Ws& w, float* ws,
-                              const float* features, const float** f_out, hipStream_t s) {
+                              const float* features, const float** f_out, hipStream_t s, int parts = 3) {
     const int B = d->B, P = d->P, D = d->D, F = d->F, E = d->E, H = d->H;
     const bool lstm = d->cell == CAPHN_CELL_LSTM, raw = d->raw_features != 0;
     const int BP = B * P, GH = w.NG * H, EF = E + F;
-    const float* f = features;
-    if (!raw) {
+    const float* f = raw ? features : ws + w.f;
+    *f_out = f;
+    if ((parts & 1) && !raw) {
         // feature_fc: Linear(D,F) + ReLU + Linear(F,F)      decoderlstm.py:22-26,61
         RUN(caphn_gemm_f32(0, 1, BP, F, D, features, D, p->fc0_w, D, ws + w.Y1, F, p->fc0_b, nullptr, 0,
                            CAPHN_GEMM_BIAS | CAPHN_GEMM_RELU, 1, s));
         RUN(caphn_gemm_f32(0, 1, BP, F, F, ws + w.Y1, F, p->fc2_w, F, ws + w.f, F, p->fc2_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
-        f = ws + w.f;
     }
     Side& sd = g_side;
-    RUN(sd.begin(s, g_tune_fork != 0));
-    RUN(sd.forkto(0)); RUN(sd.forkto(1));
-    // branch 0 -- init_hidden: mean over positions -> Linear(F,H) (and init_c for the LSTM)      :122-135 / :255-260
-    RUN(caphn_launch_mean_p(B, P, F, f, ws + w.meanf, sd.s(0)));
-    RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->inith_w, F, ws + w.h0, H, p->inith_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, sd.s(0)));
-    if (lstm)
-        RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->initc_w, F, ws + w.c0, H, p->initc_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, sd.s(0)));
-    // branch 1 -- t-invariant attention projection W_a f + b      attention.py:34
-    RUN(caphn_gemm_f32(0, 1, BP, H, F, f, F, p->Wa_w, F, ws + w.Waf, H, p->Wa_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, sd.s(1)));
+    RUN(sd.begin(s, g_tune_fork != 0 && (parts & 1)));
+    if (parts & 1) {
+        RUN(sd.forkto(0)); RUN(sd.forkto(1));
+        // branch 0 -- init_hidden: mean over positions -> Linear(F,H) (and init_c for the LSTM)      :122-135 / :255-260
+        RUN(caphn_launch_mean_p(B, P, F, f, ws + w.meanf, sd.s(0)));
+        RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->inith_w, F, ws + w.h0, H, p->inith_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, sd.s(0)));
+        if (lstm)
+            RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->initc_w, F, ws + w.c0, H, p->initc_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, sd.s(0)));
+        // branch 1 -- t-invariant attention projection W_a f + b      attention.py:34
+        RUN(caphn_gemm_f32(0, 1, BP, H, F, f, F, p->Wa_w, F, ws + w.Waf, H, p->Wa_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, sd.s(1)));
+    }
     // main -- G = f W_ih[:, E:]^T  (context side of the gate pre-activations, hoisted)
-    RUN(caphn_gemm_f32(0, 1, BP, GH, F, f, F, p->w_ih + E, EF, ws + w.G, GH, nullptr, nullptr, 0, 0, 1, s));
-    RUN(sd.jointo(0)); RUN(sd.jointo(1));
-    *f_out = f;
+    if (parts & 2)
+        RUN(caphn_gemm_f32(0, 1, BP, GH, F, f, F, p->w_ih + E, EF, ws + w.G, GH, nullptr, nullptr, 0, 0, 1, s));
+    if (parts & 1) { RUN(sd.jointo(0)); RUN(sd.jointo(1)); }
     return CAPHN_OK;
 }
 
@@ -271,6 +275,18 @@ extern "C" int caphn_decoder_prepare_rows(const caphn_decoder_dims* d, const int
     return caphn_launch_status();
 }
 
+extern "C" int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_params* p, const float* features,
+                                        void* ws_, caphn_stream_t stream) {
+    if (!dims_ok(d) || !p || !features || !ws_) return CAPHN_EINVAL;
+    const bool raw = d->raw_features != 0;
+    if (!raw && (!p->fc0_w || !p->fc0_b || !p->fc2_w || !p->fc2_b)) return CAPHN_EINVAL;
+    if (d->cell == CAPHN_CELL_LSTM && (!p->initc_w || !p->initc_b)) return CAPHN_EINVAL;
+    const Ws w = layout(d);
+    const float* f = nullptr;
+    RUN(decoder_precompute(d, p, w, static_cast<float*>(ws_), features, &f, static_cast<hipStream_t>(stream), 1));
+    return caphn_launch_status();
+}
+
 extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_decoder_params* p,
                                      const float* features, const int64_t* captions,
                                      float* logits, float* alphas, void* ws_, caphn_stream_t stream) {
@@ -287,7 +303,7 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     if (!raw && (!p->fc0_w || !p->fc0_b || !p->fc2_w || !p->fc2_b)) return CAPHN_EINVAL;
 
     const float* f = nullptr;
-    RUN(decoder_precompute(d, p, w, ws, features, &f, s));
+    RUN(decoder_precompute(d, p, w, ws, features, &f, s, d->precomputed ? 2 : 3));
     // embedding lookup with the reference's zeroed first two inputs, then the x side of the gates
     int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
     hipLaunchKernelGGL(build_idx_kernel, dim3((BT + 255) / 256), dim3(256), 0, s, B, T, captions, idx);

@@ -132,6 +132,8 @@ typedef struct caphn_decoder_dims {
                            its two backward GEMMs touch only rows whose target is not ignored by the loss (logits rows
                            of ignored targets are left unwritten, their d logits must be zero).  For fused training;
                            the module API, which must return every logits row, uses 0. */
+    int precomputed;    /* 1: caphn_decoder_precompute has already filled this workspace for these features with the
+                           current feature_fc / attention.W_a / init_h parameters; caphn_decoder_forward skips that part */
 } caphn_decoder_dims;
 
 typedef struct caphn_decoder_params {   /* reference state_dict names in comments */
@@ -166,6 +168,11 @@ size_t caphn_decoder_workspace_bytes(const caphn_decoder_dims* d);
 int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_decoder_params* p,
                           const float* features, const int64_t* captions,
                           float* logits, float* alphas, void* ws, caphn_stream_t stream);
+/* The part of the forward that depends neither on the captions nor on the generated cell weights: feature_fc,
+ * init_hidden (init_c) and the hoisted W_a f.  A trainer that knows the next minibatch's features can issue it on
+ * another stream while the optimiser streams the hypernet (then set dims.precomputed = 1 for that forward). */
+int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_params* p, const float* features,
+                             void* ws, caphn_stream_t stream);
 /* Compacts the (b,t) rows whose target differs from ignore_index into a row map kept in the workspace (count stays on
  * the device: no host synchronisation).  Call before caphn_decoder_forward / _backward with dims.row_subset = 1. */
 int caphn_decoder_prepare_rows(const caphn_decoder_dims* d, const int64_t* targets, int64_t ignore_index,

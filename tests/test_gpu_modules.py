@@ -352,3 +352,30 @@ def test_next_theta_fused_into_adam_pass(name):
     l_new = tb.forward_backward(feats, caps, x_style=xo, style_token=other)
     l_ref = ta.forward_backward(feats, caps, x_style=xo, style_token=other)
     assert abs(float(l_new[0]) - float(l_ref[0])) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["gru_tiny_cc", "gru_tiny_flickr"])
+def test_next_precompute_overlaps_optimizer(name):
+    """step(next_features=...) runs the next minibatch's feature_fc / init_hidden / W_a f on a side stream beside
+    the Adam passes (caphn_decoder_precompute + dims.precomputed): same trajectory as the plain step, also when
+    the announced features do not arrive."""
+    from caphn.engine import FusedTrainer
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    x, tok = style_args(g)
+    caps = g["captions"].to(DEV)
+    f0 = g["features"].to(DEV)
+    f1 = (f0 * 0.5 + 0.1).contiguous()
+    seq = [f0, f1, f0, f1, f1]                  # the last announcement (f0 after step 3) is wrong on purpose
+    ann = [f1, f0, f1, f0, None]
+    xs = None if tok is not None else x.to(DEV)
+    ta = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
+    tb = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
+    la, lb = [], []
+    for i, f in enumerate(seq):
+        la.append(float(ta.step(f, caps, x_style=xs, style_token=tok)[0]))
+        lb.append(float(tb.step(f, caps, x_style=xs, style_token=tok, next_features=ann[i])[0]))
+        if ann[i] is not None:
+            assert tb._pre_key is not None
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
+    assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 2e-5
