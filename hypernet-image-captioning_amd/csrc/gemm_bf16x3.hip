@@ -13,6 +13,7 @@
 // operand (80-byte row pitch: conflict-free ds_read_b128 fragments).
 #include "common.h"
 #include "gemm_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -22,14 +23,35 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BK = 32;
 constexpr int PITCH = 40;          // bf16 elements per LDS row (32 + 8 pad): 80 B = 5 x 16 B
 
+// The three planes by TRUNCATION on the bit pattern (exact: 24 significand bits = 8 + 8 + 8, so hi + mid + lo == x
+// with no rounding anywhere): hi = x & 0xffff0000, mid = (x - hi) & 0xffff0000, lo = x - hi - mid.  Per element pair
+// that is 4 v_and, 2 v_pk_add_f32 and 3 v_perm_b32 (packing the upper halves of two dwords) -- 4.5 vector
+// instructions per element instead of the 7.5 of the convert / convert-back / subtract formulation, in a kernel
+// whose main loop is bound by vector-instruction issue, not by the MFMA pipe (rocprofv3 SQ counters).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 struct Split4 { bf16x4 hi, mid, lo; };
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) {      // {a[31:16], b[31:16]} -> one dword, a low
+    return __builtin_amdgcn_perm(b, a, 0x07060302u);
+}
 __device__ __forceinline__ Split4 split3(f32x4 v) {
+    union U2 { f32x2 f; u32x2 u; };
+    union Out { unsigned u[2]; bf16x4 b; };
+    Out hi, mid, lo;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        U2 x, a, r1, m, r2;
+        x.f = f32x2{v[2 * h], v[2 * h + 1]};
+        a.u = x.u & 0xffff0000u;
+        r1.f = x.f - a.f;
+        m.u = r1.u & 0xffff0000u;
+        r2.f = r1.f - m.f;
+        hi.u[h] = pack_hi16(x.u[0], x.u[1]);
+        mid.u[h] = pack_hi16(r1.u[0], r1.u[1]);
+        lo.u[h] = pack_hi16(r2.u[0], r2.u[1]);
+    }
     Split4 s;
-    s.hi = __builtin_convertvector(v, bf16x4);
-    const f32x4 r1 = v - __builtin_convertvector(s.hi, f32x4);
-    s.mid = __builtin_convertvector(r1, bf16x4);
-    const f32x4 r2 = r1 - __builtin_convertvector(s.mid, f32x4);
-    s.lo = __builtin_convertvector(r2, bf16x4);
+    s.hi = hi.b; s.mid = mid.b; s.lo = lo.b;
     return s;
 }
 
@@ -48,10 +70,12 @@ struct TileS {
 
     // pr: physical rows (KC) ; kmap: physical row of a logical k (!KC), may be null
     // physical rows of this thread's NV logical rows (KC operands); looked up once, not per K-slab
-    __device__ static __forceinline__ void phys_rows(int (&pr)[NV], int rows, int r0, int tid, const int* __restrict__ rmap) {
+    __device__ static __forceinline__ void phys_rows(int (&pr)[NV], int rows, int r0, int tid, const int* __restrict__ rmap,
+                                                     bool clamp) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int row = r0 + ((tid + 256 * i) >> 3);
+            int row = r0 + ((tid + 256 * i) >> 3);
+            if (clamp) row = min(row, rows - 1);
             pr[i] = (rmap && row < rows) ? rmap[row] : row;
         }
     }
@@ -88,6 +112,29 @@ struct TileS {
             r[i] = v;
         }
     }
+    // Branch-free variant for 16-byte aligned operands (ld % 4 == 0, K % 4 == 0, extents >= 4): every thread always
+    // issues exactly NV dwordx4 loads, from CLAMPED coordinates -- rows past the edge re-read the last valid row (their
+    // products land in accumulator rows/columns the epilogue never stores); a K tail is zeroed later, in store_tail, NOT here:
+    // a select at the load site makes the compiler wait for the data right after requesting it.  A
+    // static load count lets the compiler wait with s_waitcnt vmcnt(n > 0) for the OLDER register set only; with
+    // the bounds checks as branches it had to drain everything (vmcnt(0)), which cancelled the look-ahead.
+    __device__ static __forceinline__ void load_fast(f32x4 (&r)[NV], const float* __restrict__ G, int ld,
+                                                     int rows, int K, int r0, int k0, int tid, const int (&pr)[NV]) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            if (KC) {               // memory [rows, K]; pr[] is already clamped
+                const int k = k0 + (idx & 7) * 4;
+                const int kc = min(k, K - 4);
+                r[i] = *reinterpret_cast<const f32x4*>(G + (size_t)pr[i] * ld + kc);
+            } else {                // memory [K, rows]
+                const int m = min(r0 + (idx % (BMN / 4)) * 4, rows - 4);
+                const int k = k0 + idx / (BMN / 4);
+                const int kc = min(k, K - 1);
+                r[i] = *reinterpret_cast<const f32x4*>(G + (size_t)kc * ld + m);
+            }
+        }
+    }
     __device__ static __forceinline__ void store(const f32x4 (&r)[NV], __bf16* __restrict__ S, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -99,6 +146,18 @@ struct TileS {
             *reinterpret_cast<bf16x4*>(p + PLANE) = s.mid;
             *reinterpret_cast<bf16x4*>(p + 2 * PLANE) = s.lo;
         }
+    }
+    // K-tail slab of the branch-free path: zero the elements whose k >= K, then stage
+    __device__ static __forceinline__ void store_tail(f32x4 (&r)[NV], __bf16* __restrict__ S, int tid, int k0, int K) {
+        if (k0 + BK > K) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int idx = tid + 256 * i;
+                const int k = KC ? k0 + (idx & 7) * 4 : k0 + idx / (BMN / 4);
+                if (k >= K) r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        store(r, S, tid);
     }
     // MFMA operand of lane l (r = l&31, h = l>>5) for k-step ks: elements k = 16 ks + 8 h + (0..7) of row `row0 + r`
     __device__ static __forceinline__ bf16x8 frag(const __bf16* __restrict__ S, int plane, int row0, int ks, int lane) {
@@ -124,14 +183,26 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     using TileA = TileS<BM, !TA>;
     using TileB = TileS<BN, TB>;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    __shared__ __attribute__((aligned(16))) __bf16 lds[TileA::ELEMS + TileB::ELEMS];
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];      // TileA::ELEMS + TileB::ELEMS (up to 77 KB)
     __bf16* As = lds;
     __bf16* Bs = lds + TileA::ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, kh = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so neighbouring tiles
+    // -- which share an operand panel -- would land on eight different L2s and each fetch the panel from HBM.  Give
+    // every XCD a contiguous run of the (n fastest, then m, then k-split) tile order instead (bijective remap for
+    // any grid size).  Placement is a speed matter only.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.flags & (1 << 20)) {
+        const int nx = gridDim.x, ny = gridDim.y, nwg = nx * ny * (int)gridDim.z;
+        const int orig = bx + nx * (by + ny * bz);
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = wgid % nx; by = (wgid / nx) % ny; bz = wgid / (nx * ny);
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     // row subset: effective extents come from device memory (no host round trip)
     const int* rmapA = nullptr; const int* kmap = nullptr;
     if (g.map_mode == 1) { g.M = min(g.M, g.dev_count[0]); rmapA = g.row_map; if (m0 >= g.M) return; }
@@ -141,7 +212,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     int slab0 = 0, slab1 = nslab_total;
     if (g.splitk > 1) {
         const int sps = g.map_mode == 2 ? (nslab_total + g.splitk - 1) / g.splitk : g.slabs_per_split;
-        slab0 = blockIdx.z * sps;
+        slab0 = bz * sps;
         slab1 = min(nslab_total, slab0 + sps);
         if (slab0 >= slab1) return;
     }
@@ -154,22 +225,26 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    f32x4 ra[TileA::NV], rb[TileB::NV];
+    // Software pipeline, two K-slabs of global loads in flight: while slab s is multiplied out of LDS, slab s+1 sits
+    // in one register set (issued an iteration ago) and slab s+2 is being requested into the other.  With one slab
+    // of look-ahead every workgroup stalled on HBM latency each slab (the loads' L2 hit rate is ~80-85 %, so nearly
+    // every 1 KB wave-load waits for at least one miss): SQ_WAIT_ANY was 27-47 % of wave time.
+    f32x4 ra0[TileA::NV], rb0[TileB::NV], ra1[TileA::NV], rb1[TileB::NV];
     int pra[TileA::NV], prb[TileB::NV];
-    TileA::phys_rows(pra, g.M, m0, tid, rmapA);
-    TileB::phys_rows(prb, g.N, n0, tid, nullptr);
-    TileA::load(ra, g.A, g.lda, g.M, g.K, m0, slab0 * BK, g.vecA, tid, pra, kmap);
-    TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, slab0 * BK, g.vecB, tid, prb, kmap);
-    TileA::store(ra, As, tid);
-    TileB::store(rb, Bs, tid);
-    __syncthreads();
-
-    for (int slab = slab0; slab < slab1; ++slab) {
-        const bool more = slab + 1 < slab1;
-        if (more && !(g.flags & (1 << 19))) {
-            TileA::load(ra, g.A, g.lda, g.M, g.K, m0, (slab + 1) * BK, g.vecA, tid, pra, kmap);
-            TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, (slab + 1) * BK, g.vecB, tid, prb, kmap);
+    const bool fast = !(g.flags & (1 << 21)) && g.vecA && g.vecB && !kmap && g.M >= 4 && g.N >= 4 && g.K >= 4 && (g.K & 3) == 0 &&
+                      (!TA || (g.M & 3) == 0) && (TB || (g.N & 3) == 0);
+    TileA::phys_rows(pra, g.M, m0, tid, rmapA, fast);
+    TileB::phys_rows(prb, g.N, n0, tid, nullptr, fast);
+    auto gload = [&](f32x4 (&ra)[TileA::NV], f32x4 (&rb)[TileB::NV], int slab, auto fast_c) {
+        if constexpr (decltype(fast_c)::value) {
+            TileA::load_fast(ra, g.A, g.lda, g.M, g.K, m0, slab * BK, tid, pra);
+            TileB::load_fast(rb, g.B, g.ldb, g.N, g.K, n0, slab * BK, tid, prb);
+        } else {
+            TileA::load(ra, g.A, g.lda, g.M, g.K, m0, slab * BK, g.vecA, tid, pra, kmap);
+            TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, slab * BK, g.vecB, tid, prb, kmap);
         }
+    };
+    auto multiply = [&](int slab) {
         const int nks = (g.K - slab * BK) > 16 ? 2 : 1;      // skip the all-zero second k-step of a short tail
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -188,10 +263,6 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
                     for (int b = 0; b < TN; ++b) {
                         f32x16 c = acc[a][b];            // smallest terms first
-                        if (g.flags & (1 << 16)) {       // ablation: keep the fragments alive, skip the MFMAs
-                            asm volatile("" :: "v"(fa[a][0]), "v"(fa[a][1]), "v"(fa[a][2]), "v"(fb[b][0]), "v"(fb[b][1]), "v"(fb[b][2]));
-                            continue;
-                        }
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], c, 0, 0, 0);   // lo  . hi
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], c, 0, 0, 0);   // hi  . lo
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], c, 0, 0, 0);   // mid . mid
@@ -202,19 +273,51 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                     }
             }
         }
-        __syncthreads();
-        if (more) {
-            if (!(g.flags & (1 << 18))) {
-                TileA::store(ra, As, tid);
-                TileB::store(rb, Bs, tid);
-            }
-            __syncthreads();
+    };
+    auto stage = [&](f32x4 (&ra)[TileA::NV], f32x4 (&rb)[TileB::NV], int slab, auto fast_c) {
+        if constexpr (decltype(fast_c)::value) {
+            TileA::store_tail(ra, As, tid, slab * BK, g.K);
+            TileB::store_tail(rb, Bs, tid, slab * BK, g.K);
+        } else {
+            TileA::store(ra, As, tid);
+            TileB::store(rb, Bs, tid);
         }
-    }
+    };
+    auto mainloop = [&](auto fc) {
+        // In the branch-free path the look-ahead loads are issued UNCONDITIONALLY (slab index clamped to the last one,
+        // a redundant L2 hit at the tail): only then is the number of loads in flight static and the wait before
+        // staging set 1 becomes vmcnt(#loads of set 0) instead of vmcnt(0).
+        constexpr bool F = decltype(fc)::value;
+        const int last = slab1 - 1;
+        gload(ra0, rb0, slab0, fc);
+        if (F || slab0 + 1 < slab1) gload(ra1, rb1, min(slab0 + 1, last), fc);
+        stage(ra0, rb0, slab0, fc);
+        __syncthreads();
+        for (int slab = slab0; slab < slab1; slab += 2) {
+            // LDS: slab.  set 1: slab+1 (in flight).  set 0: free
+            if (F || slab + 2 < slab1) gload(ra0, rb0, min(slab + 2, last), fc);
+            multiply(slab);
+            __builtin_amdgcn_sched_barrier(0);      // keep the staging (and its vmcnt wait) behind the MFMAs
+            __syncthreads();
+            if (slab + 1 >= slab1) break;
+            stage(ra1, rb1, slab + 1, fc);
+            __syncthreads();
+            // LDS: slab+1.  set 0: slab+2 (in flight).  set 1: free
+            if (F || slab + 3 < slab1) gload(ra1, rb1, min(slab + 3, last), fc);
+            multiply(slab + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (slab + 2 < slab1) {
+                stage(ra0, rb0, slab + 2, fc);
+                __syncthreads();
+            }
+        }
+    };
+    if (fast) mainloop(std::true_type{}); else mainloop(std::false_type{});
 
     // epilogue: acc register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
     const bool atomic = g.splitk > 1;
-    const bool add_bias = (g.flags & CAPHN_GEMM_BIAS) && (!atomic || blockIdx.z == 0);
+    const bool add_bias = (g.flags & CAPHN_GEMM_BIAS) && (!atomic || bz == 0);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -228,7 +331,6 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                 if (row >= g.M) continue;
                 float v = acc[a][b][r] + bv;
                 float* c = g.C + (size_t)(rmapA ? rmapA[row] : row) * g.ldc + col;
-                if ((g.flags & (1 << 17)) && v != 12345.678f) continue;      // ablation: no epilogue stores
                 if (atomic) { atomicAdd(c, v); continue; }
                 if (g.flags & CAPHN_GEMM_ACCUM) v += *c;
                 if (g.flags & CAPHN_GEMM_RELU) v = fmaxf(v, 0.f);
@@ -238,22 +340,45 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         }
 }
 
+template <int BM, int BN, bool TA, bool TB>
+int launch_one(const GemmArgs& g, hipStream_t s) {
+    using TileA = TileS<BM, !TA>;
+    using TileB = TileS<BN, TB>;
+    constexpr size_t lds = sizeof(__bf16) * (TileA::ELEMS + TileB::ELEMS);
+    static bool attr_set = false;          // one flag per instantiation; one host thread drives one device
+    if (lds > 48 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<BM, BN, TA, TB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CAPHN_ELAUNCH;
+        attr_set = true;
+    }
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk > 1 ? g.splitk : 1);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB>), grid, dim3(256), lds, s, g);
+    return caphn_launch_status();
+}
 template <int BM, int BN>
 int launch_cfg(const GemmArgs& g, int ta, int tb, hipStream_t s) {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk > 1 ? g.splitk : 1);
-    dim3 block(256);
-    if (!ta && tb) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, false, true>), grid, block, 0, s, g);
-    else if (!ta && !tb) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, false, false>), grid, block, 0, s, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, true, false>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, true, true>), grid, block, 0, s, g);
-    return caphn_launch_status();
+    if (!ta && tb) return launch_one<BM, BN, false, true>(g, s);
+    if (!ta && !tb) return launch_one<BM, BN, false, false>(g, s);
+    if (ta && !tb) return launch_one<BM, BN, true, false>(g, s);
+    return launch_one<BM, BN, true, true>(g, s);
 }
 
 }  // namespace
 
-int g_tune_gemm_tile = 0;     // 0: 128x128 when >= 512 such tiles else 64x64; 1: also try 128x64 when >= 512 such tiles
+int g_tune_gemm_xcd = 1;      // 1 (default): XCD-aware tile order
+int g_tune_gemm_fast = 1;     // 1 (default): branch-free loads (static vmcnt) where alignment allows
+int g_tune_gemm_tile = 0;     // 0 (default): 128x128 when >= 512 such tiles else 64x64; 1: also 128x64; 2: skinny 64x256 / 256x64
+                              // tiles (measured slower: two workgroups per CU hide less latency than five)
+// Skinny problems (one extent in (128, 256], the other long): a 64-wide tile on the short side makes the LONG operand
+// travel from L2/HBM once per short-side tile (4x for N = 200).  A tile spanning the whole short side reads it once.
 int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
+    if (g_tune_gemm_xcd) g.flags |= 1 << 20;
+    if (!g_tune_gemm_fast) g.flags |= 1 << 21;
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.splitk;
+    if (g_tune_gemm_tile == 2) {
+        if (g.N > 128 && g.N <= 256 && g.M >= 1024) return launch_cfg<64, 256>(g, ta, tb, s);
+        if (g.M > 128 && g.M <= 256 && g.N >= 1024) return launch_cfg<256, 64>(g, ta, tb, s);
+    }
     if (tiles128 >= 512) return launch_cfg<128, 128>(g, ta, tb, s);
     if (g_tune_gemm_tile == 1) {
         const long t12864 = (long)((g.M + 127) / 128) * ((g.N + 63) / 64) * g.splitk;

@@ -10,11 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "hypernet-image-captioning_amd"))
 from caphn import _lib, ops  # noqa: E402
 
-SHAPES = [  # name, ta, tb, M, N, K, splitk
-    ("fc0 fwd", 0, 1, 6272, 200, 2048, 1), ("logits fwd", 0, 1, 2560, 9684, 200, 1),
-    ("dW_fc", 1, 0, 9684, 200, 2560, 2), ("dW_fc s4", 1, 0, 9684, 200, 2560, 4), ("dHs", 0, 0, 2560, 200, 9684, 7), ("dHs s14", 0, 0, 2560, 200, 9684, 14), ("dW_fc0", 1, 0, 200, 2048, 6272, 8), ("dW_fc0 s16", 1, 0, 200, 2048, 6272, 16), ("fc0 fwd big", 0, 1, 6272, 200, 2048, 1),
-    ("G", 0, 1, 6272, 600, 200, 1), ("Xg", 0, 1, 2560, 600, 200, 1), ("dW_hh", 1, 0, 600, 200, 2560, 10),
-    ("dY1", 0, 0, 6272, 200, 200, 1),
+SHAPES = [  # name, ta, tb, M, N, K, splitk candidates
+    ("fc0 fwd", 0, 1, 6272, 200, 2048, (1, 2, 4, 6)), ("logits fwd", 0, 1, 2560, 9684, 200, (1,)),
+    ("dW_fc", 1, 0, 9684, 200, 2560, (1, 2, 4)), ("dHs", 0, 0, 2560, 200, 9684, (7, 14, 20)),
+    ("dW_fc0", 1, 0, 200, 2048, 6272, (8, 16, 24)), ("G", 0, 1, 6272, 600, 200, (1,)), ("Waf", 0, 1, 6272, 200, 200, (1, 2)),
+    ("Xg", 0, 1, 2560, 600, 200, (1,)), ("dW_hh", 1, 0, 600, 200, 2560, (10,)), ("dY1", 0, 0, 6272, 200, 200, (1, 2)),
+    ("dW_fc2", 1, 0, 200, 200, 6272, (16, 32)), ("dctx->df", 0, 0, 2560, 200, 600, (1, 2, 4)),
 ]
 
 
@@ -22,14 +23,15 @@ def main():
     lib = _lib.load()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
-    for name, ta, tb, M, N, K, sk in SHAPES:
+    for name, ta, tb, M, N, K, sks in SHAPES:
+      for sk in sks:
         A = torch.randn((K, M) if ta else (M, K), generator=g, device=dev)
         B = torch.randn((N, K) if tb else (K, N), generator=g, device=dev) * 0.07
         ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
         out = torch.zeros(M, N, device=dev)
-        line = f"{name:11s} M={M:5d} N={N:5d} K={K:5d}"
-        for mode in (1, 2):
-            lib.caphn_tune(2, 1); lib.caphn_tune(5, mode - 1)
+        line = f"{name:11s} M={M:5d} N={N:5d} K={K:5d} sk={sk:2d}"
+        for mode in (0, 1):
+            lib.caphn_tune(2, 1); lib.caphn_tune(5, 0); lib.caphn_tune(6, 1); lib.caphn_tune(7, mode)
             ts = []
             for _ in range(6):
                 if sk > 1:
@@ -42,9 +44,9 @@ def main():
             err = float((out.double() - ref).abs().max())
             rel = err / float(ref.abs().max())
             t = float(np.median(ts[1:])) * 1e3
-            line += f" | {'64x64' if mode == 1 else '128x64'}: {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF err {err:.2e} (rel {rel:.1e})"
+            line += f" | {'generic' if mode == 0 else 'fast   '}: {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF err {err:.2e} (rel {rel:.1e})"
         print(line)
-    lib.caphn_tune(2, 1); lib.caphn_tune(5, 0)
+    lib.caphn_tune(2, 1); lib.caphn_tune(5, 0); lib.caphn_tune(6, 1); lib.caphn_tune(7, 1)
 
 
 if __name__ == "__main__":
