@@ -126,14 +126,21 @@ struct TileS {
             if (KC) {               // memory [rows, K]; pr[] is already clamped
                 const int k = k0 + (idx & 7) * 4;
                 const int kc = min(k, K - 4);
-                r[i] = *reinterpret_cast<const f32x4*>(G + (size_t)pr[i] * ld + kc);
+                issue(r[i], G + (size_t)pr[i] * ld + kc);
             } else {                // memory [K, rows]
                 const int m = min(r0 + (idx % (BMN / 4)) * 4, rows - 4);
                 const int k = k0 + idx / (BMN / 4);
                 const int kc = min(k, K - 1);
-                r[i] = *reinterpret_cast<const f32x4*>(G + (size_t)kc * ld + m);
+                issue(r[i], G + (size_t)kc * ld + m);
             }
         }
+    }
+    // The load is issued from inline assembly so that the compiler's wait-count pass does not see it: that pass
+    // inserted vmcnt(0/1) waits at the top of the loop (register re-use it could not prove safe across the back
+    // edge), i.e. waited for the newest look-ahead loads as well.  The kernel waits by hand (vm_wait below); every
+    // register set is an in/out operand of its wait, which keeps the registers reserved while the load is in flight.
+    __device__ static __forceinline__ void issue(f32x4& r, const float* p) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p));
     }
     __device__ static __forceinline__ void store(const f32x4 (&r)[NV], __bf16* __restrict__ S, int tid) {
 #pragma unroll
@@ -283,14 +290,38 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             TileB::store(rb, Bs, tid);
         }
     };
+    // s_waitcnt vmcnt(N): at most N of this wave's loads still in flight (they complete in issue order).  The
+    // operands tie the wait to the registers it releases.
+    auto vm_wait = [&](f32x4 (&ra)[TileA::NV], f32x4 (&rb)[TileB::NV], auto n_c) {
+        constexpr int N = decltype(n_c)::value;
+        if constexpr (TileA::NV == 2 && TileB::NV == 2)
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]) : "n"(N));
+        else if constexpr (TileA::NV == 4 && TileB::NV == 2)
+            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]) : "n"(N));
+        else if constexpr (TileA::NV == 2 && TileB::NV == 4)
+            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]) : "n"(N));
+        else if constexpr (TileA::NV == 4 && TileB::NV == 4)
+            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]),
+                         "+v"(rb[2]), "+v"(rb[3]) : "n"(N));
+        else {
+#pragma unroll
+            for (int i = 0; i < TileA::NV; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[i]));
+#pragma unroll
+            for (int i = 0; i < TileB::NV; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[i]));
+        }
+    };
+    constexpr int NLD = (TileA::NV == 8 || TileB::NV == 8) ? 0 : TileA::NV + TileB::NV;     // loads per register set
+    using NldC = std::integral_constant<int, NLD>;
+    using ZeroC = std::integral_constant<int, 0>;
     auto mainloop = [&](auto fc) {
         // In the branch-free path the look-ahead loads are issued UNCONDITIONALLY (slab index clamped to the last one,
-        // a redundant L2 hit at the tail): only then is the number of loads in flight static and the wait before
-        // staging set 1 becomes vmcnt(#loads of set 0) instead of vmcnt(0).
+        // a redundant L2 hit at the tail), so exactly two sets are in flight whenever one is staged: the wait is
+        // vmcnt(loads of the newer set).
         constexpr bool F = decltype(fc)::value;
         const int last = slab1 - 1;
         gload(ra0, rb0, slab0, fc);
         if (F || slab0 + 1 < slab1) gload(ra1, rb1, min(slab0 + 1, last), fc);
+        if constexpr (F) vm_wait(ra0, rb0, NldC{});
         stage(ra0, rb0, slab0, fc);
         __syncthreads();
         for (int slab = slab0; slab < slab1; slab += 2) {
@@ -300,6 +331,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);      // keep the staging (and its vmcnt wait) behind the MFMAs
             __syncthreads();
             if (slab + 1 >= slab1) break;
+            if constexpr (F) vm_wait(ra1, rb1, NldC{});
             stage(ra1, rb1, slab + 1, fc);
             __syncthreads();
             // LDS: slab+1.  set 0: slab+2 (in flight).  set 1: free
@@ -308,9 +340,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             if (slab + 2 < slab1) {
+                if constexpr (F) vm_wait(ra0, rb0, NldC{});
                 stage(ra0, rb0, slab + 2, fc);
                 __syncthreads();
             }
+        }
+        if constexpr (F) {      // nothing may stay in flight: the epilogue re-uses these registers
+            vm_wait(ra0, rb0, ZeroC{});
+            vm_wait(ra1, rb1, ZeroC{});
         }
     };
     if (fast) mainloop(std::true_type{}); else mainloop(std::false_type{});
