@@ -135,13 +135,11 @@ struct TileS {
             }
         }
     }
-    // The load is issued from inline assembly so that the compiler's wait-count pass does not see it: that pass
-    // inserted vmcnt(0/1) waits at the top of the loop (register re-use it could not prove safe across the back
-    // edge), i.e. waited for the newest look-ahead loads as well.  The kernel waits by hand (vm_wait below); every
-    // register set is an in/out operand of its wait, which keeps the registers reserved while the load is in flight.
-    __device__ static __forceinline__ void issue(f32x4& r, const float* p) {
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p));
-    }
+    // A plain load, tracked by the compiler's wait-count pass.  (Issuing it from inline assembly with hand-placed
+    // s_waitcnt vmcnt(n) removes two conservative waits at the top of the loop and measured 3 % faster, but it is
+    // unsound: the register allocator may COPY a register set between the load and the wait -- it did, at the loop's
+    // back edge -- reading registers whose loads are still in flight.  The failure is intermittent.)
+    __device__ static __forceinline__ void issue(f32x4& r, const float* p) { r = *reinterpret_cast<const f32x4*>(p); }
     __device__ static __forceinline__ void store(const f32x4 (&r)[NV], __bf16* __restrict__ S, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -224,13 +222,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         if (slab0 >= slab1) return;
     }
 
-    f32x16 acc[TM][TN];
+    constexpr bool DUAL = TM * TN == 1;
+    f32x16 acc[TM][TN], acc2[DUAL ? TM : 1][DUAL ? TN : 1];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.f; if (DUAL) acc2[a][b][r] = 0.f; }
 
     // Software pipeline, two K-slabs of global loads in flight: while slab s is multiplied out of LDS, slab s+1 sits
     // in one register set (issued an iteration ago) and slab s+2 is being requested into the other.  With one slab
@@ -269,14 +268,28 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b) {
-                        f32x16 c = acc[a][b];            // smallest terms first
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], c, 0, 0, 0);   // lo  . hi
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], c, 0, 0, 0);   // hi  . lo
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], c, 0, 0, 0);   // mid . mid
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], c, 0, 0, 0);   // mid . hi
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], c, 0, 0, 0);   // hi  . mid
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], c, 0, 0, 0);   // hi  . hi
-                        acc[a][b] = c;
+                        if constexpr (DUAL) {
+                            // one 32x32 tile per wave: twelve MFMAs in a row on one accumulator are a RAW chain
+                            // (SQ_WAIT_INST_ANY 47 % of wave time); keep the small cross terms in a second
+                            // accumulator -- two independent chains, and the small terms are summed among themselves
+                            f32x16 c = acc[a][b], e = acc2[a][b];
+                            e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], e, 0, 0, 0);   // lo  . hi
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], c, 0, 0, 0);   // mid . hi
+                            e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], e, 0, 0, 0);   // hi  . lo
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], c, 0, 0, 0);   // hi  . mid
+                            e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], e, 0, 0, 0);   // mid . mid
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], c, 0, 0, 0);   // hi  . hi
+                            acc[a][b] = c; acc2[a][b] = e;
+                        } else {
+                            f32x16 c = acc[a][b];            // smallest terms first
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], c, 0, 0, 0);   // lo  . hi
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], c, 0, 0, 0);   // hi  . lo
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], c, 0, 0, 0);   // mid . mid
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], c, 0, 0, 0);   // mid . hi
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], c, 0, 0, 0);   // hi  . mid
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], c, 0, 0, 0);   // hi  . hi
+                            acc[a][b] = c;
+                        }
                     }
             }
         }
@@ -290,38 +303,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             TileB::store(rb, Bs, tid);
         }
     };
-    // s_waitcnt vmcnt(N): at most N of this wave's loads still in flight (they complete in issue order).  The
-    // operands tie the wait to the registers it releases.
-    auto vm_wait = [&](f32x4 (&ra)[TileA::NV], f32x4 (&rb)[TileB::NV], auto n_c) {
-        constexpr int N = decltype(n_c)::value;
-        if constexpr (TileA::NV == 2 && TileB::NV == 2)
-            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]) : "n"(N));
-        else if constexpr (TileA::NV == 4 && TileB::NV == 2)
-            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]) : "n"(N));
-        else if constexpr (TileA::NV == 2 && TileB::NV == 4)
-            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]) : "n"(N));
-        else if constexpr (TileA::NV == 4 && TileB::NV == 4)
-            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]),
-                         "+v"(rb[2]), "+v"(rb[3]) : "n"(N));
-        else {
-#pragma unroll
-            for (int i = 0; i < TileA::NV; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[i]));
-#pragma unroll
-            for (int i = 0; i < TileB::NV; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[i]));
-        }
-    };
-    constexpr int NLD = (TileA::NV == 8 || TileB::NV == 8) ? 0 : TileA::NV + TileB::NV;     // loads per register set
-    using NldC = std::integral_constant<int, NLD>;
-    using ZeroC = std::integral_constant<int, 0>;
     auto mainloop = [&](auto fc) {
         // In the branch-free path the look-ahead loads are issued UNCONDITIONALLY (slab index clamped to the last one,
-        // a redundant L2 hit at the tail), so exactly two sets are in flight whenever one is staged: the wait is
-        // vmcnt(loads of the newer set).
+        // a redundant L2 hit at the tail): only then is the number of loads in flight static and the compiler's wait
+        // before staging a set becomes vmcnt(#loads of the newer set) instead of vmcnt(0).
         constexpr bool F = decltype(fc)::value;
         const int last = slab1 - 1;
         gload(ra0, rb0, slab0, fc);
         if (F || slab0 + 1 < slab1) gload(ra1, rb1, min(slab0 + 1, last), fc);
-        if constexpr (F) vm_wait(ra0, rb0, NldC{});
         stage(ra0, rb0, slab0, fc);
         __syncthreads();
         for (int slab = slab0; slab < slab1; slab += 2) {
@@ -331,7 +320,6 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);      // keep the staging (and its vmcnt wait) behind the MFMAs
             __syncthreads();
             if (slab + 1 >= slab1) break;
-            if constexpr (F) vm_wait(ra1, rb1, NldC{});
             stage(ra1, rb1, slab + 1, fc);
             __syncthreads();
             // LDS: slab+1.  set 0: slab+2 (in flight).  set 1: free
@@ -340,18 +328,17 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             if (slab + 2 < slab1) {
-                if constexpr (F) vm_wait(ra0, rb0, NldC{});
-                stage(ra0, rb0, slab + 2, fc);
+                        stage(ra0, rb0, slab + 2, fc);
                 __syncthreads();
             }
-        }
-        if constexpr (F) {      // nothing may stay in flight: the epilogue re-uses these registers
-            vm_wait(ra0, rb0, ZeroC{});
-            vm_wait(ra1, rb1, ZeroC{});
         }
     };
     if (fast) mainloop(std::true_type{}); else mainloop(std::false_type{});
 
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[0][0][r];
+    }
     // epilogue: acc register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
     const bool atomic = g.splitk > 1;
     const bool add_bias = (g.flags & CAPHN_GEMM_BIAS) && (!atomic || bz == 0);
