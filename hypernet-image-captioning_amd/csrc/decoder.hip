@@ -182,20 +182,26 @@ inline int gemm_auto(int ta, int tb, int M, int N, int K, const float* A, int ld
     int sk = pick_splitk(M, N, K);
     if (rowmap) {      // row subset: rowmap[0] = count (device), rowmap + 4 = indices
         if (sk > 1) {
-            if (ldc == N) { if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, s) != hipSuccess) return CAPHN_ELAUNCH; }
+            if (ldc == N) { RUN(caphn_zero_f32(C, (size_t)M * N, s)); }
             else if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, s) != hipSuccess) return CAPHN_ELAUNCH;
         }
         return caphn_gemm_mapped(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, sk, rowmap + 4, rowmap, map_mode, s);
     }
     if (sk > 1 && (flags & ~CAPHN_GEMM_BIAS) == 0) {
         if (ldc == N) {
-            if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, s) != hipSuccess) return CAPHN_ELAUNCH;
+            RUN(caphn_zero_f32(C, (size_t)M * N, s));
         } else {
             if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, s) != hipSuccess) return CAPHN_ELAUNCH;
         }
         return caphn_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, 0, flags, sk, s);
     }
     return caphn_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, 0, flags, 1, s);
+}
+
+// weight gradient dW = A^T B (A stored [K, M]) with its bias gradient db = column sums of A fused into the GEMM
+inline int wgrad_bias(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* dW, int ldc, float* db,
+                      const int* rowmap, void* cws, hipStream_t s) {
+    return caphn_gemm_tn_colsum(M, N, K, A, lda, B, ldb, dW, ldc, db, pick_splitk(M, N, K), rowmap, cws, s);
 }
 
 // feature_fc, init_hidden (+ init_c), W_a f, G = f W_ih[:,E:]^T  -- everything that does not depend on the captions.
@@ -388,11 +394,10 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     const bool late = g_tune_fork != 2;
     if (!late) {
         RUN(sd.forkto(0));
-        RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, sd.s(0), rmap, 2));
-        RUN(caphn_colsum_f32(BT, V, dlogits, V, g->out_b, cws, sd.s(0)));
+        RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, sd.s(0)));
     }
     if (rmap) {   // rows of ignored targets have d logits == 0: dHs of those rows is zero, the others are gathered
-        if (hipMemsetAsync(ws + w.dHs, 0, sizeof(float) * (size_t)BT * H, s) != hipSuccess) return CAPHN_ELAUNCH;
+        RUN(caphn_zero_f32(ws + w.dHs, (size_t)BT * H, s));
         RUN(caphn_gemm_mapped(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, pick_splitk(BT, H, V),
                               rmap + 4, rmap, 1, s));
     } else
@@ -419,8 +424,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     const bool hold_big = late && !raw && g_tune_fork == 3;   // 3: release the two big leaves only once df exists (measured: no gain)
     if (late) RUN(sd.forkto(0));
     if (late && !hold_big) {   // the optimiser-only vocab gradients
-        RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, b0, rmap, 2));
-        RUN(caphn_colsum_f32(BT, V, dlogits, V, g->out_b, cws, b0));
+        RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0));
     }
     if (!raw) {
         if (!g->fc0_w || !g->fc0_b || !g->fc2_w || !g->fc2_b) return CAPHN_EINVAL;
@@ -440,30 +444,25 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     RUN(sd.record(2, s));
     // b2 -- input weights dW_ih[:, :E] = dgi^T Xe, dW_ih[:, E:] = dgi^T ctx; embedding gradient
     RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, b2));
-    RUN(gemm_auto(1, 0, GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, nullptr, 0, b2));
+    if (lstm) RUN(gemm_auto(1, 0, GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, nullptr, 0, b2));
+    else RUN(wgrad_bias(GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, g->b_ih, nullptr, cw2, b2));      // + db_ih
     RUN(gemm_auto(1, 0, GH, F, BT, dgi, GH, ws + w.ctx, F, g->w_ih + E, EF, nullptr, 0, b2));
     RUN(sd.record(3, b2));
     RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, b2));
-    if (hipMemsetAsync(g->embed_w, 0, sizeof(float) * (size_t)V * E, b2) != hipSuccess) return CAPHN_ELAUNCH;
+    RUN(caphn_zero_f32(g->embed_w, (size_t)V * E, b2));
     RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, b2));
     // b1 -- recurrent weights dW_hh = dgh^T Hprev, dU_a = duah^T Hprev, biases by column sums; init_h / init_c
-    RUN(gemm_auto(1, 0, GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, nullptr, 0, b1));
-    RUN(caphn_colsum_f32(BT, GH, dgh, GH, g->b_hh, cw1, b1));
-    RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cw1, b1));
+    RUN(wgrad_bias(GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, g->b_hh, nullptr, cw1, b1));
+    if (lstm) RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cw1, b1));      // dgh aliases dgi: db_ih == db_hh
     if (hook && !hold_big) {
         // dL/dtheta = [dW_ih | dW_hh | db_ih | db_hh] is complete once E3 has fired: the hypernet VJP (HBM-bound
         // transposed GEMV over the 576 MB of second-layer weights) runs here, beside the main chain
         RUN(sd.wait(3, b1));
         RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, b1));
     }
-    RUN(gemm_auto(1, 0, H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, nullptr, 0, b1));
-    RUN(caphn_colsum_f32(BT, H, ws + w.duah, H, g->Ua_b, cw1, b1));
-    RUN(gemm_auto(1, 0, H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, nullptr, 0, b1));
-    RUN(caphn_colsum_f32(B, H, ws + w.dh0, H, g->inith_b, cw1, b1));
-    if (lstm) {
-        RUN(gemm_auto(1, 0, H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, nullptr, 0, b1));
-        RUN(caphn_colsum_f32(B, H, ws + w.dc0, H, g->initc_b, cw1, b1));
-    }
+    RUN(wgrad_bias(H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, g->Ua_b, nullptr, cw1, b1));
+    RUN(wgrad_bias(H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, g->inith_b, nullptr, cw1, b1));
+    if (lstm) RUN(wgrad_bias(H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, g->initc_b, nullptr, cw1, b1));
     // main -- df = alpha^T dctx + dmean/P + dWaf W_a, then feature_fc backward
     if (!raw) {
         RUN(caphn_launch_df(B, T, P, F, ws + w.alphas, ws + w.dctx, ws + w.dmeanf, ws + w.df, s));
@@ -474,28 +473,24 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
             // df_kernel in the kernel trace), so the latency-critical front of the chain runs first; the optimiser-only
             // vocab gradients (b0) and the hypernet VJP (b1) start here, beside the two remaining chain GEMMs.
             RUN(sd.wait(4, b0));
-            RUN(gemm_auto(1, 0, V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, nullptr, 0, b0, rmap, 2));
-            RUN(caphn_colsum_f32(BT, V, dlogits, V, g->out_b, cws, b0));
+            RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0));
             if (hook) {
                 RUN(sd.wait(3, b1)); RUN(sd.wait(4, b1));
                 RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, b1));
             }
         }
         RUN(caphn_gemm_f32(0, 0, BP, F, F, ws + w.df, F, p->fc2_w, F, ws + w.dY1, F, nullptr, ws + w.Y1, F, CAPHN_GEMM_MASK, 1, s));
-        RUN(gemm_auto(1, 0, F, D, BP, ws + w.dY1, F, features, D, g->fc0_w, D, nullptr, 0, s));
-        RUN(caphn_colsum_f32(BP, F, ws + w.dY1, F, g->fc0_b, cw0, s));
+        RUN(wgrad_bias(F, D, BP, ws + w.dY1, F, features, D, g->fc0_w, D, g->fc0_b, nullptr, cw0, s));
     }
     // b2 (leaves of the chain) -- d v_a, d b_va, dW_a, db_Wa once dWaf exists; fc2 gradients once df exists
     RUN(sd.wait(2, b2));
     RUN(caphn_colsum_f32(B * w.npc, H + 1, ws + w.apart, H + 1, ws + w.vtmp, cw2, b2));
     if (hipMemcpyAsync(g->va_w, ws + w.vtmp, sizeof(float) * H, hipMemcpyDeviceToDevice, b2) != hipSuccess) return CAPHN_ELAUNCH;
     if (hipMemcpyAsync(g->va_b, ws + w.vtmp + H, sizeof(float), hipMemcpyDeviceToDevice, b2) != hipSuccess) return CAPHN_ELAUNCH;
-    RUN(gemm_auto(1, 0, H, F, BP, ws + w.dWaf, H, f, F, g->Wa_w, F, nullptr, 0, b2));
-    RUN(caphn_colsum_f32(BP, H, ws + w.dWaf, H, g->Wa_b, cw2, b2));
+    RUN(wgrad_bias(H, F, BP, ws + w.dWaf, H, f, F, g->Wa_w, F, g->Wa_b, nullptr, cw2, b2));
     if (!raw) {
         RUN(sd.wait(4, b2));
-        RUN(gemm_auto(1, 0, F, F, BP, ws + w.df, F, ws + w.Y1, F, g->fc2_w, F, nullptr, 0, b2));
-        RUN(caphn_colsum_f32(BP, F, ws + w.df, F, g->fc2_b, cw2, b2));
+        RUN(wgrad_bias(F, F, BP, ws + w.df, F, ws + w.Y1, F, g->fc2_w, F, g->fc2_b, nullptr, cw2, b2));
     }
     RUN(sd.jointo(0)); RUN(sd.jointo(1)); RUN(sd.jointo(2));
     (void)captions;

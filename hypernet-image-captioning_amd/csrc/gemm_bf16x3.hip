@@ -153,7 +153,7 @@ struct TileS {
         }
     }
     // K-tail slab of the branch-free path: zero the elements whose k >= K, then stage
-    __device__ static __forceinline__ void store_tail(f32x4 (&r)[NV], __bf16* __restrict__ S, int tid, int k0, int K) {
+    __device__ static __forceinline__ void mask_tail(f32x4 (&r)[NV], int tid, int k0, int K) {
         if (k0 + BK > K) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
@@ -162,7 +162,6 @@ struct TileS {
                 if (k >= K) r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        store(r, S, tid);
     }
     // MFMA operand of lane l (r = l&31, h = l>>5) for k-step ks: elements k = 16 ks + 8 h + (0..7) of row `row0 + r`
     __device__ static __forceinline__ bf16x8 frag(const __bf16* __restrict__ S, int plane, int row0, int ks, int lane) {
@@ -294,14 +293,23 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             }
         }
     };
+    // fused bias gradient: the n-tile-0 workgroups add up the fp32 A tiles they stage (A is [K, M] here, so a thread
+    // always holds the same four columns: 256 % (BM / 4) == 0)
+    const bool do_cs = TA && g.colsum_a != nullptr && bx == 0;
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     auto stage = [&](f32x4 (&ra)[TileA::NV], f32x4 (&rb)[TileB::NV], int slab, auto fast_c) {
         if constexpr (decltype(fast_c)::value) {
-            TileA::store_tail(ra, As, tid, slab * BK, g.K);
-            TileB::store_tail(rb, Bs, tid, slab * BK, g.K);
-        } else {
-            TileA::store(ra, As, tid);
-            TileB::store(rb, Bs, tid);
+            TileA::mask_tail(ra, tid, slab * BK, g.K);
+            TileB::mask_tail(rb, tid, slab * BK, g.K);
         }
+        if constexpr (TA) {
+            if (do_cs) {
+#pragma unroll
+                for (int i = 0; i < TileA::NV; ++i) csum += ra[i];
+            }
+        }
+        TileA::store(ra, As, tid);
+        TileB::store(rb, Bs, tid);
     };
     auto mainloop = [&](auto fc) {
         // In the branch-free path the look-ahead loads are issued UNCONDITIONALLY (slab index clamped to the last one,
@@ -334,6 +342,22 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         }
     };
     if (fast) mainloop(std::true_type{}); else mainloop(std::false_type{});
+
+    if constexpr (TA) {
+        if (do_cs) {        // workgroup-uniform; the main loop ended on a barrier, LDS is free
+            constexpr int CG = BM / 4, RG = 256 / CG;      // column groups, threads per group
+            float* red = reinterpret_cast<float*>(lds);
+            const int cg = tid % CG, rg = tid / CG;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[rg * BM + cg * 4 + e] = csum[e];
+            __syncthreads();
+            if (tid < BM && m0 + tid < g.M) {
+                float v = 0.f;
+                for (int r = 0; r < RG; ++r) v += red[r * BM + tid];
+                atomicAdd(g.colsum_a + m0 + tid, v);
+            }
+        }
+    }
 
     if constexpr (DUAL) {
 #pragma unroll

@@ -199,8 +199,36 @@ int caphn_gemm_mapped(int ta, int tb, int M, int N, int K, const float* A, int l
     g.slabs_per_split = (nslab + g.splitk - 1) / g.splitk;
     g.vecA = caphn_aligned16(A) && (lda % 4 == 0);
     g.vecB = caphn_aligned16(B) && (ldb % 4 == 0);
-    g.row_map = row_map; g.dev_count = dev_count; g.map_mode = map_mode;
+    g.row_map = row_map; g.dev_count = dev_count; g.map_mode = map_mode; g.colsum_a = nullptr;
     return caphn_gemm_bf16x3_launch(g, ta, tb, s);      // the row subset lives in the split-bf16 back end
+}
+
+int caphn_gemm_tn_colsum(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                         float* colsum_out, int splitk, const int* rowmap, void* cws, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || !colsum_out) return CAPHN_EINVAL;
+    const int nslab = (K + 31) / 32;
+    if (splitk > nslab) splitk = nslab;
+    if (splitk < 1) splitk = 1;
+    if (splitk > 1 || rowmap) {
+        if (ldc == N) { int rc = caphn_zero_f32(C, (size_t)M * N, s); if (rc) return rc; }
+        else if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, s) != hipSuccess) return CAPHN_ELAUNCH;
+    }
+    if (g_tune_gemm != 1) {      // fp32 back end: no fusion
+        int rc = rowmap ? caphn_gemm_mapped(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, splitk, rowmap + 4, rowmap, 2, s)
+                        : caphn_gemm_f32(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, 0, splitk, s);
+        if (rc) return rc;
+        return caphn_colsum_f32(K, M, A, lda, colsum_out, cws, s);
+    }
+    int rc = caphn_zero_f32(colsum_out, (size_t)M, s); if (rc) return rc;
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.bias = nullptr; g.mask = nullptr; g.ldmask = 0; g.flags = 0;
+    g.splitk = splitk; g.slabs_per_split = (nslab + splitk - 1) / splitk;
+    g.vecA = caphn_aligned16(A) && (lda % 4 == 0);
+    g.vecB = caphn_aligned16(B) && (ldb % 4 == 0);
+    g.row_map = rowmap ? rowmap + 4 : nullptr; g.dev_count = rowmap; g.map_mode = rowmap ? 2 : 0;
+    g.colsum_a = colsum_out;
+    return caphn_gemm_bf16x3_launch(g, 1, 0, s);
 }
 
 extern "C" int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
@@ -215,7 +243,7 @@ extern "C" int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.mask = mask; g.ldmask = ldmask; g.flags = flags;
-    g.row_map = nullptr; g.dev_count = nullptr; g.map_mode = 0;
+    g.row_map = nullptr; g.dev_count = nullptr; g.map_mode = 0; g.colsum_a = nullptr;
     if (g_tune_gemm == 1) {          // split-bf16 back end: three bf16 planes per operand, 6 MFMAs per K=16
         const int nslab = (K + 31) / 32;
         if (splitk > nslab) splitk = nslab;

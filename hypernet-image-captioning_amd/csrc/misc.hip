@@ -1,6 +1,7 @@
 // Loss, bias-gradient column sums, embedding gather/scatter, gradient-norm clipping and Adam.
 // All of these are HBM-bound streams: 16-byte coalesced accesses, grid-stride, no MFMA.
 #include "common.h"
+#include "gemm_internal.h"
 #include <math.h>
 
 namespace {
@@ -73,6 +74,20 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(int rows, const float* _
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) { out[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)nvalid[0]); out[1] = nvalid[0]; }
+}
+
+// ------------------------------------------------------------------ zero fill
+// hipMemsetAsync's fill kernel moves ~370 GB/s (20 us for a 7.7 MB gradient); this one is a plain dwordx4 store stream
+__global__ __launch_bounds__(256) void zero_kernel(float* __restrict__ p, size_t n, int vec) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (vec) {
+        f32x4* p4 = reinterpret_cast<f32x4*>(p);
+        const size_t n4 = n >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) p4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+    }
 }
 
 // ------------------------------------------------------------------ column sums
@@ -379,6 +394,16 @@ extern "C" int caphn_colsum_f32(int M, int N, const float* A, int lda, float* ou
         hipLaunchKernelGGL(colsum_kernel, dim3(cb, S), dim3(256), 0, s, M, N, A, lda, part, rows_per);
         hipLaunchKernelGGL(colsum_kernel, dim3(cb, 1), dim3(256), 0, s, S, N, part, N, out, S);
     }
+    return caphn_launch_status();
+}
+
+int caphn_zero_f32(float* p, size_t n, hipStream_t s) {
+    if (!p) return CAPHN_EINVAL;
+    if (n == 0) return CAPHN_OK;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, (int)caphn_aligned16(p));
     return caphn_launch_status();
 }
 
