@@ -34,7 +34,7 @@ class HyperGrads(C.Structure):
 
 class DecoderDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "T", "P", "D", "F", "E", "H", "V", "cell", "raw_features", "row_subset",
-                                         "precomputed")]
+                                         "grads_zeroed", "precomputed")]
 
 
 _DEC_FIELDS = ("fc0_w", "fc0_b", "fc2_w", "fc2_b", "embed_w", "out_w", "out_b", "Wa_w", "Wa_b",
@@ -84,6 +84,7 @@ SIGNATURES = {
     "caphn_device_arch": (C.c_int, [C.c_char_p, C.c_int]),
     "caphn_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_int,
                                  c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
+    "caphn_zero_f32": (C.c_int, [c_fp, C.c_size_t, c_fp]),
     "caphn_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "caphn_colsum_f32": (C.c_int, [C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]),
     "caphn_hyper_acts_floats": (C.c_int, [C.POINTER(HyperDesc)]),

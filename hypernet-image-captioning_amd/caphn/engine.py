@@ -162,7 +162,8 @@ class FusedTrainer:
         b = self._bufs.get(key)
         if b is None:
             import dataclasses
-            dims = dataclasses.replace(self.cap.dec_dims(B, T, P), rows=self.skip_ignored_rows)
+            # gz: the gradient arena is cleared once per step (forward_backward), not tensor by tensor
+            dims = dataclasses.replace(self.cap.dec_dims(B, T, P), rows=self.skip_ignored_rows, gz=True)
             b = {"dims": dims, "ws": ops.decoder_workspace(dims, self.dev),
                  "logits": torch.empty(B, T, dims.V, dtype=torch.float32, device=self.dev),
                  "alphas": torch.empty(B, T, P, dtype=torch.float32, device=self.dev),
@@ -205,6 +206,7 @@ class FusedTrainer:
             x = self._view(self.flat_p, "captioner.embed.weight")[style_token]
         else:
             x = x_style.reshape(-1).to(device=self.dev, dtype=torch.float32)
+        ops.zero_(self.flat_g)          # every split-K / atomic target of the backward lives in this arena
         theta = getattr(self, "_theta", None)
         if theta is None:
             theta = self._theta = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)

@@ -45,6 +45,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, ta: bool = False, tb: bool = False,
     return out
 
 
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    """Zero-fill a contiguous fp32 CUDA tensor with libcaphn's dwordx4 store kernel."""
+    lib = L.load()
+    L.check(lib.caphn_zero_f32(L.ptr(t), t.numel(), L.stream_ptr()), "caphn_zero_f32")
+    return t
+
+
 def colsum(a: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = L.load()
     M, N = a.shape
@@ -189,6 +196,7 @@ class DecDims:
     raw: bool = False        # True: no feature_fc, attention over the raw D-channel features (F == D)
     rows: bool = False       # True: vocab GEMMs only touch rows with a live target (decoder_prepare_rows first)
     pre: bool = False        # True: decoder_precompute already ran on the workspace for these features
+    gz: bool = False         # True: the caller zero-filled every gradient output (one zero_ over its arena)
 
     @property
     def NG(self) -> int:
@@ -196,7 +204,7 @@ class DecDims:
 
     def c(self) -> L.DecoderDims:
         return L.DecoderDims(self.B, self.T, self.P, self.D, self.F, self.E, self.H, self.V,
-                             1 if self.cell == "lstm" else 0, int(self.raw), int(self.rows), int(self.pre))
+                             1 if self.cell == "lstm" else 0, int(self.raw), int(self.rows), int(self.gz), int(self.pre))
 
     def fields(self):
         """Ordered (C struct field, parameter name) pairs this configuration uses."""

@@ -178,17 +178,18 @@ inline int pick_splitk(int M, int N, int K) {
 // C = A^T-or-not . B with optional split-K (zero-fills C first when splitting)
 inline int gemm_auto(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      float* C, int ldc, const float* bias, int flags, hipStream_t s,
-                     const int* rowmap = nullptr, int map_mode = 0) {
+                     const int* rowmap = nullptr, int map_mode = 0, bool prezeroed = false) {
     int sk = pick_splitk(M, N, K);
     if (rowmap) {      // row subset: rowmap[0] = count (device), rowmap + 4 = indices
-        if (sk > 1) {
+        if (sk > 1 && !prezeroed) {
             if (ldc == N) { RUN(caphn_zero_f32(C, (size_t)M * N, s)); }
             else if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, s) != hipSuccess) return CAPHN_ELAUNCH;
         }
         return caphn_gemm_mapped(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, sk, rowmap + 4, rowmap, map_mode, s);
     }
     if (sk > 1 && (flags & ~CAPHN_GEMM_BIAS) == 0) {
-        if (ldc == N) {
+        if (prezeroed) {
+        } else if (ldc == N) {
             RUN(caphn_zero_f32(C, (size_t)M * N, s));
         } else {
             if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, s) != hipSuccess) return CAPHN_ELAUNCH;
@@ -200,8 +201,8 @@ inline int gemm_auto(int ta, int tb, int M, int N, int K, const float* A, int ld
 
 // weight gradient dW = A^T B (A stored [K, M]) with its bias gradient db = column sums of A fused into the GEMM
 inline int wgrad_bias(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* dW, int ldc, float* db,
-                      const int* rowmap, void* cws, hipStream_t s) {
-    return caphn_gemm_tn_colsum(M, N, K, A, lda, B, ldb, dW, ldc, db, pick_splitk(M, N, K), rowmap, cws, s);
+                      const int* rowmap, void* cws, hipStream_t s, bool prezeroed) {
+    return caphn_gemm_tn_colsum(M, N, K, A, lda, B, ldb, dW, ldc, db, pick_splitk(M, N, K), rowmap, cws, prezeroed, s);
 }
 
 // feature_fc, init_hidden (+ init_c), W_a f, G = f W_ih[:,E:]^T  -- everything that does not depend on the captions.
@@ -392,9 +393,10 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     // needed by the optimiser: branch 0 computes them beside the BPTT kernel, which occupies B of the 256 CUs.
     const int* rmap = d->row_subset ? reinterpret_cast<const int*>(ws + w.rowmap) : nullptr;
     const bool late = g_tune_fork != 2;
+    const bool gz = d->grads_zeroed != 0;
     if (!late) {
         RUN(sd.forkto(0));
-        RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, sd.s(0)));
+        RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, sd.s(0), gz));
     }
     if (rmap) {   // rows of ignored targets have d logits == 0: dHs of those rows is zero, the others are gathered
         RUN(caphn_zero_f32(ws + w.dHs, (size_t)BT * H, s));
@@ -424,7 +426,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     const bool hold_big = late && !raw && g_tune_fork == 3;   // 3: release the two big leaves only once df exists (measured: no gain)
     if (late) RUN(sd.forkto(0));
     if (late && !hold_big) {   // the optimiser-only vocab gradients
-        RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0));
+        RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0, gz));
     }
     if (!raw) {
         if (!g->fc0_w || !g->fc0_b || !g->fc2_w || !g->fc2_b) return CAPHN_EINVAL;
@@ -444,15 +446,15 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     RUN(sd.record(2, s));
     // b2 -- input weights dW_ih[:, :E] = dgi^T Xe, dW_ih[:, E:] = dgi^T ctx; embedding gradient
     RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, b2));
-    if (lstm) RUN(gemm_auto(1, 0, GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, nullptr, 0, b2));
-    else RUN(wgrad_bias(GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, g->b_ih, nullptr, cw2, b2));      // + db_ih
-    RUN(gemm_auto(1, 0, GH, F, BT, dgi, GH, ws + w.ctx, F, g->w_ih + E, EF, nullptr, 0, b2));
+    if (lstm) RUN(gemm_auto(1, 0, GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, nullptr, 0, b2, nullptr, 0, gz));
+    else RUN(wgrad_bias(GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, g->b_ih, nullptr, cw2, b2, gz));      // + db_ih
+    RUN(gemm_auto(1, 0, GH, F, BT, dgi, GH, ws + w.ctx, F, g->w_ih + E, EF, nullptr, 0, b2, nullptr, 0, gz));
     RUN(sd.record(3, b2));
     RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, b2));
-    RUN(caphn_zero_f32(g->embed_w, (size_t)V * E, b2));
+    if (!gz) RUN(caphn_zero_f32(g->embed_w, (size_t)V * E, b2));
     RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, b2));
     // b1 -- recurrent weights dW_hh = dgh^T Hprev, dU_a = duah^T Hprev, biases by column sums; init_h / init_c
-    RUN(wgrad_bias(GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, g->b_hh, nullptr, cw1, b1));
+    RUN(wgrad_bias(GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, g->b_hh, nullptr, cw1, b1, gz));
     if (lstm) RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cw1, b1));      // dgh aliases dgi: db_ih == db_hh
     if (hook && !hold_big) {
         // dL/dtheta = [dW_ih | dW_hh | db_ih | db_hh] is complete once E3 has fired: the hypernet VJP (HBM-bound
@@ -460,9 +462,9 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
         RUN(sd.wait(3, b1));
         RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, b1));
     }
-    RUN(wgrad_bias(H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, g->Ua_b, nullptr, cw1, b1));
-    RUN(wgrad_bias(H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, g->inith_b, nullptr, cw1, b1));
-    if (lstm) RUN(wgrad_bias(H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, g->initc_b, nullptr, cw1, b1));
+    RUN(wgrad_bias(H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, g->Ua_b, nullptr, cw1, b1, gz));
+    RUN(wgrad_bias(H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, g->inith_b, nullptr, cw1, b1, gz));
+    if (lstm) RUN(wgrad_bias(H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, g->initc_b, nullptr, cw1, b1, gz));
     // main -- df = alpha^T dctx + dmean/P + dWaf W_a, then feature_fc backward
     if (!raw) {
         RUN(caphn_launch_df(B, T, P, F, ws + w.alphas, ws + w.dctx, ws + w.dmeanf, ws + w.df, s));
@@ -473,24 +475,24 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
             // df_kernel in the kernel trace), so the latency-critical front of the chain runs first; the optimiser-only
             // vocab gradients (b0) and the hypernet VJP (b1) start here, beside the two remaining chain GEMMs.
             RUN(sd.wait(4, b0));
-            RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0));
+            RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0, gz));
             if (hook) {
                 RUN(sd.wait(3, b1)); RUN(sd.wait(4, b1));
                 RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, b1));
             }
         }
         RUN(caphn_gemm_f32(0, 0, BP, F, F, ws + w.df, F, p->fc2_w, F, ws + w.dY1, F, nullptr, ws + w.Y1, F, CAPHN_GEMM_MASK, 1, s));
-        RUN(wgrad_bias(F, D, BP, ws + w.dY1, F, features, D, g->fc0_w, D, g->fc0_b, nullptr, cw0, s));
+        RUN(wgrad_bias(F, D, BP, ws + w.dY1, F, features, D, g->fc0_w, D, g->fc0_b, nullptr, cw0, s, gz));
     }
     // b2 (leaves of the chain) -- d v_a, d b_va, dW_a, db_Wa once dWaf exists; fc2 gradients once df exists
     RUN(sd.wait(2, b2));
     RUN(caphn_colsum_f32(B * w.npc, H + 1, ws + w.apart, H + 1, ws + w.vtmp, cw2, b2));
     if (hipMemcpyAsync(g->va_w, ws + w.vtmp, sizeof(float) * H, hipMemcpyDeviceToDevice, b2) != hipSuccess) return CAPHN_ELAUNCH;
     if (hipMemcpyAsync(g->va_b, ws + w.vtmp + H, sizeof(float), hipMemcpyDeviceToDevice, b2) != hipSuccess) return CAPHN_ELAUNCH;
-    RUN(wgrad_bias(H, F, BP, ws + w.dWaf, H, f, F, g->Wa_w, F, g->Wa_b, nullptr, cw2, b2));
+    RUN(wgrad_bias(H, F, BP, ws + w.dWaf, H, f, F, g->Wa_w, F, g->Wa_b, nullptr, cw2, b2, gz));
     if (!raw) {
         RUN(sd.wait(4, b2));
-        RUN(wgrad_bias(F, F, BP, ws + w.df, F, ws + w.Y1, F, g->fc2_w, F, g->fc2_b, nullptr, cw2, b2));
+        RUN(wgrad_bias(F, F, BP, ws + w.df, F, ws + w.Y1, F, g->fc2_w, F, g->fc2_b, nullptr, cw2, b2, gz));
     }
     RUN(sd.jointo(0)); RUN(sd.jointo(1)); RUN(sd.jointo(2));
     (void)captions;

@@ -204,12 +204,12 @@ int caphn_gemm_mapped(int ta, int tb, int M, int N, int K, const float* A, int l
 }
 
 int caphn_gemm_tn_colsum(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                         float* colsum_out, int splitk, const int* rowmap, void* cws, hipStream_t s) {
+                         float* colsum_out, int splitk, const int* rowmap, void* cws, bool prezeroed, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || !colsum_out) return CAPHN_EINVAL;
     const int nslab = (K + 31) / 32;
     if (splitk > nslab) splitk = nslab;
     if (splitk < 1) splitk = 1;
-    if (splitk > 1 || rowmap) {
+    if ((splitk > 1 || rowmap) && !prezeroed) {
         if (ldc == N) { int rc = caphn_zero_f32(C, (size_t)M * N, s); if (rc) return rc; }
         else if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, s) != hipSuccess) return CAPHN_ELAUNCH;
     }
@@ -219,7 +219,7 @@ int caphn_gemm_tn_colsum(int M, int N, int K, const float* A, int lda, const flo
         if (rc) return rc;
         return caphn_colsum_f32(K, M, A, lda, colsum_out, cws, s);
     }
-    int rc = caphn_zero_f32(colsum_out, (size_t)M, s); if (rc) return rc;
+    if (!prezeroed) { int rc = caphn_zero_f32(colsum_out, (size_t)M, s); if (rc) return rc; }
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = nullptr; g.mask = nullptr; g.ldmask = 0; g.flags = 0;

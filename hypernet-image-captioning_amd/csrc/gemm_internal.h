@@ -29,8 +29,7 @@ int caphn_gemm_mapped(int ta, int tb, int M, int N, int K, const float* A, int l
 // C = A^T B (+ split-K) with db = column sums of A fused in when the split-bf16 back end is active; falls back to the
 // separate column-sum kernel otherwise.  Zero-fills C (when splitting) and db itself.  cws: caphn_colsum workspace.
 int caphn_gemm_tn_colsum(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                         float* colsum_out, int splitk, const int* rowmap, void* cws, hipStream_t s);
-int caphn_zero_f32(float* p, size_t n, hipStream_t s);      // fast zero fill (misc.hip)
+                         float* colsum_out, int splitk, const int* rowmap, void* cws, bool prezeroed, hipStream_t s);
 
 // split-bf16 back end (gemm_bf16x3.hip): BK = 32
 int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s);

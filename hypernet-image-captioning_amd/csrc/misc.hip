@@ -397,7 +397,8 @@ extern "C" int caphn_colsum_f32(int M, int N, const float* A, int lda, float* ou
     return caphn_launch_status();
 }
 
-int caphn_zero_f32(float* p, size_t n, hipStream_t s) {
+extern "C" int caphn_zero_f32(float* p, size_t n, caphn_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
     if (!p) return CAPHN_EINVAL;
     if (n == 0) return CAPHN_OK;
     size_t blocks = (n / 4 + 255) / 256;

@@ -61,6 +61,8 @@ int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
                    const float* mask, int ldmask, int flags, int splitk,
                    caphn_stream_t stream);
 
+/* p[0..n) = 0 with dwordx4 stores (hipMemsetAsync's fill kernel is ~8x slower on large buffers). */
+int caphn_zero_f32(float* p, size_t n, caphn_stream_t stream);
 /* out[n] = sum_m A[m,n]  (bias gradients).  ws: caphn_colsum_workspace_bytes(M,N). */
 size_t caphn_colsum_workspace_bytes(int M, int N);
 int caphn_colsum_f32(int M, int N, const float* A, int lda, float* out, void* ws, caphn_stream_t stream);
@@ -132,6 +134,9 @@ typedef struct caphn_decoder_dims {
                            its two backward GEMMs touch only rows whose target is not ignored by the loss (logits rows
                            of ignored targets are left unwritten, their d logits must be zero).  For fused training;
                            the module API, which must return every logits row, uses 0. */
+    int grads_zeroed;   /* 1: every gradient output of caphn_decoder_backward is already zero on entry (a trainer that keeps all
+                           gradients in one arena clears it with one caphn_zero_f32): the composite then skips its ~16
+                           per-tensor zero fills (split-K / atomic accumulation targets) */
     int precomputed;    /* 1: caphn_decoder_precompute has already filled this workspace for these features with the
                            current feature_fc / attention.W_a / init_h parameters; caphn_decoder_forward skips that part */
 } caphn_decoder_dims;
