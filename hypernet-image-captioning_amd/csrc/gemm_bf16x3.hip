@@ -118,8 +118,11 @@ struct TileS {
     // a select at the load site makes the compiler wait for the data right after requesting it.  A
     // static load count lets the compiler wait with s_waitcnt vmcnt(n > 0) for the OLDER register set only; with
     // the bounds checks as branches it had to drain everything (vmcnt(0)), which cancelled the look-ahead.
+    // kl (K-slow operands only): LDS copy of the row map for logical k in [kbase, ...): the physical row comes from a
+    // ds_read, so the number of VMEM loads stays static
     __device__ static __forceinline__ void load_fast(f32x4 (&r)[NV], const float* __restrict__ G, int ld,
-                                                     int rows, int K, int r0, int k0, int tid, const int (&pr)[NV]) {
+                                                     int rows, int K, int r0, int k0, int tid, const int (&pr)[NV],
+                                                     const int* kl, int kbase) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + 256 * i;
@@ -130,7 +133,8 @@ struct TileS {
             } else {                // memory [K, rows]
                 const int m = min(r0 + (idx % (BMN / 4)) * 4, rows - 4);
                 const int k = k0 + idx / (BMN / 4);
-                const int kc = min(k, K - 1);
+                int kc = min(k, K - 1);
+                if (kl) kc = kl[kc - kbase];
                 issue(r[i], G + (size_t)kc * ld + m);
             }
         }
@@ -236,14 +240,27 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     // every 1 KB wave-load waits for at least one miss): SQ_WAIT_ANY was 27-47 % of wave time.
     f32x4 ra0[TileA::NV], rb0[TileB::NV], ra1[TileA::NV], rb1[TileB::NV];
     int pra[TileA::NV], prb[TileB::NV];
-    const bool fast = !(g.flags & (1 << 21)) && g.vecA && g.vecB && !kmap && g.M >= 4 && g.N >= 4 && g.K >= 4 && (g.K & 3) == 0 &&
-                      (!TA || (g.M & 3) == 0) && (TB || (g.N & 3) == 0);
+    // a K row map (weight gradients over live rows only) goes to LDS once per workgroup, so the mapped GEMM keeps the
+    // branch-free path; only TN has both operands K-slow
+    const int* kl = nullptr;
+    const int kbase = slab0 * BK;
+    bool fast = !(g.flags & (1 << 21)) && g.vecA && g.vecB && g.M >= 4 && g.N >= 4 && g.K >= 4 && (g.K & 3) == 0 &&
+                (!TA || (g.M & 3) == 0) && (TB || (g.N & 3) == 0);
+    if (kmap) {
+        const int need = (slab1 - slab0) * BK;
+        if (fast && TA && !TB && g.kmap_lds >= need) {
+            int* kls = reinterpret_cast<int*>(lds + TileA::ELEMS + TileB::ELEMS);
+            for (int i = tid; i < need; i += 256) kls[i] = kmap[min(kbase + i, g.K - 1)];
+            __syncthreads();
+            kl = kls;
+        } else fast = false;
+    }
     TileA::phys_rows(pra, g.M, m0, tid, rmapA, fast);
     TileB::phys_rows(prb, g.N, n0, tid, nullptr, fast);
     auto gload = [&](f32x4 (&ra)[TileA::NV], f32x4 (&rb)[TileB::NV], int slab, auto fast_c) {
         if constexpr (decltype(fast_c)::value) {
-            TileA::load_fast(ra, g.A, g.lda, g.M, g.K, m0, slab * BK, tid, pra);
-            TileB::load_fast(rb, g.B, g.ldb, g.N, g.K, n0, slab * BK, tid, prb);
+            TileA::load_fast(ra, g.A, g.lda, g.M, g.K, m0, slab * BK, tid, pra, kl, kbase);
+            TileB::load_fast(rb, g.B, g.ldb, g.N, g.K, n0, slab * BK, tid, prb, kl, kbase);
         } else {
             TileA::load(ra, g.A, g.lda, g.M, g.K, m0, slab * BK, g.vecA, tid, pra, kmap);
             TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, slab * BK, g.vecB, tid, prb, kmap);
@@ -392,11 +409,13 @@ template <int BM, int BN, bool TA, bool TB>
 int launch_one(const GemmArgs& g, hipStream_t s) {
     using TileA = TileS<BM, !TA>;
     using TileB = TileS<BN, TB>;
-    constexpr size_t lds = sizeof(__bf16) * (TileA::ELEMS + TileB::ELEMS);
+    constexpr size_t lds_tiles = sizeof(__bf16) * (TileA::ELEMS + TileB::ELEMS);
+    size_t lds = lds_tiles;
+    if (g.kmap_lds > 0) lds += sizeof(int) * (size_t)g.kmap_lds;
     static bool attr_set = false;          // one flag per instantiation; one host thread drives one device
-    if (lds > 48 * 1024 && !attr_set) {
+    if (lds_tiles + 16384 > 48 * 1024 && !attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<BM, BN, TA, TB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CAPHN_ELAUNCH;
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_tiles + 16384)) != hipSuccess) return CAPHN_ELAUNCH;
         attr_set = true;
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk > 1 ? g.splitk : 1);
@@ -421,6 +440,12 @@ int g_tune_gemm_tile = 0;     // 0 (default): 128x128 when >= 512 such tiles els
 // travel from L2/HBM once per short-side tile (4x for N = 200).  A tile spanning the whole short side reads it once.
 int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
     if (g_tune_gemm_xcd) g.flags |= 1 << 20;
+    g.kmap_lds = 0;
+    if (g.map_mode == 2 && ta && !tb) {      // LDS slice of the K map: slabs per split (upper bound from the host-side K) x 32
+        const int nslab = (g.K + 31) / 32, sk = g.splitk > 1 ? g.splitk : 1;
+        const int ints = ((nslab + sk - 1) / sk) * 32;
+        if (ints <= 4096) g.kmap_lds = ints;      // 16 KB at most next to the 30 KB of tiles (64x64 configuration)
+    }
     if (!g_tune_gemm_fast) g.flags |= 1 << 21;
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.splitk;
     if (g_tune_gemm_tile == 2) {

@@ -199,7 +199,7 @@ int caphn_gemm_mapped(int ta, int tb, int M, int N, int K, const float* A, int l
     g.slabs_per_split = (nslab + g.splitk - 1) / g.splitk;
     g.vecA = caphn_aligned16(A) && (lda % 4 == 0);
     g.vecB = caphn_aligned16(B) && (ldb % 4 == 0);
-    g.row_map = row_map; g.dev_count = dev_count; g.map_mode = map_mode; g.colsum_a = nullptr;
+    g.row_map = row_map; g.dev_count = dev_count; g.map_mode = map_mode; g.colsum_a = nullptr; g.kmap_lds = 0;
     return caphn_gemm_bf16x3_launch(g, ta, tb, s);      // the row subset lives in the split-bf16 back end
 }
 
@@ -227,7 +227,7 @@ int caphn_gemm_tn_colsum(int M, int N, int K, const float* A, int lda, const flo
     g.vecA = caphn_aligned16(A) && (lda % 4 == 0);
     g.vecB = caphn_aligned16(B) && (ldb % 4 == 0);
     g.row_map = rowmap ? rowmap + 4 : nullptr; g.dev_count = rowmap; g.map_mode = rowmap ? 2 : 0;
-    g.colsum_a = colsum_out;
+    g.colsum_a = colsum_out; g.kmap_lds = 0;
     return caphn_gemm_bf16x3_launch(g, 1, 0, s);
 }
 
@@ -243,7 +243,7 @@ extern "C" int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.mask = mask; g.ldmask = ldmask; g.flags = flags;
-    g.row_map = nullptr; g.dev_count = nullptr; g.map_mode = 0; g.colsum_a = nullptr;
+    g.row_map = nullptr; g.dev_count = nullptr; g.map_mode = 0; g.colsum_a = nullptr; g.kmap_lds = 0;
     if (g_tune_gemm == 1) {          // split-bf16 back end: three bf16 planes per operand, 6 MFMAs per K=16
         const int nslab = (K + 31) / 32;
         if (splitk > nslab) splitk = nslab;

@@ -19,6 +19,7 @@ struct GemmArgs {
     // optional fused bias gradient of a weight-gradient GEMM (ta = 1, A stored [K, M]): colsum_a[m] += sum_k A[k][m],
     // accumulated by the n-tile-0 workgroups from the fp32 tiles they stage anyway (atomics; the caller zero-fills)
     float* colsum_a;
+    int kmap_lds;        // map_mode 2: ints of LDS reserved behind the tiles for this workgroup's slice of the K map (0: none)
 };
 
 // internal entry (decoder.hip): caphn_gemm_f32 plus the row subset
