@@ -423,7 +423,7 @@ extern "C" int caphn_hyper_backward(const caphn_hyper_desc* d, const float* dthe
         }
         int kv = 0;
         for (int i = 0; i < nh; ++i) if (jobs.j[i].vec && jobs.j[i].k <= 2048) kv = std::max(kv, jobs.j[i].k);
-        const size_t shm = sizeof(float) * 4 * kmax;
+        const size_t shm = sizeof(float) * 4 * (kv > 0 ? kv : 1);      // only the wave path (k <= 2048, aligned) uses LDS
         if (kv <= 256) hipLaunchKernelGGL(gemv_t_partial_kernel<1>, dim3(b0), dim3(256), shm, s, jobs);
         else if (kv <= 512) hipLaunchKernelGGL(gemv_t_partial_kernel<2>, dim3(b0), dim3(256), shm, s, jobs);
         else if (kv <= 1024) hipLaunchKernelGGL(gemv_t_partial_kernel<4>, dim3(b0), dim3(256), shm, s, jobs);

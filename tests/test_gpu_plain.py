@@ -174,3 +174,43 @@ def test_medium_size_vs_oracle(cell, L):
             t = gr[("lstm_cell." if li == 0 else f"layers.{li - 1}.") + n]
             dth[off:off + t.numel()] += t.flatten(); off += t.numel()
     assert maxdiff(dth.cpu(), dtheta) < 5e-6
+
+
+def test_hypernet_py_literal_configuration():
+    """hypernet.py:203 -- HyperNet(200, 150, len(vocab), vocab, 2, type='gru') at B=128, T=20: 2.785 G hypernet
+    parameters (11.1 GB), heads (11250, 90000), 3 x (8437, 67500), 4 x (450, 450) -- row widths that are neither
+    multiples of four nor below the register-tiled kernels' 2048-column limit.  Size-independent properties against
+    plain PyTorch on the same device: theta, the rank-1 structure of the big gradient, dead heads."""
+    from hypernet import HyperNet
+    torch.manual_seed(0)
+    E, H, V, L, B, T = 200, 150, 9684, 2, 128, 20
+    with torch.device(DEV):
+        net = HyperNet(E, H, V, _Vocab(), num_layers=L, type="gru")
+    assert [(h[0].out_features, h[2].out_features) for h in net.hn_heads] == \
+        [(11250, 90000), (8437, 67500), (450, 450), (450, 450), (8437, 67500), (8437, 67500), (450, 450), (450, 450)]
+    assert sum(p.numel() for p in net.hn_heads.parameters()) + sum(p.numel() for p in net.hn_base.parameters()) == 2784955161
+    feats = torch.randn(B, E, device=DEV, requires_grad=True)
+    caps = torch.randint(0, V, (B, T), device=DEV)
+    style = torch.tensor([4], device=DEV)
+    cap = net(net.captioner.embed(style))
+    logits = cap(feats, caps, True)
+    loss = F.cross_entropy(logits.view(-1, V), caps.view(-1))
+    loss.backward()
+    with torch.no_grad():
+        x = net.captioner.embed.weight[4:5]
+        base = F.leaky_relu(F.linear(F.leaky_relu(F.linear(x, net.hn_base[0].weight, net.hn_base[0].bias)),
+                                     net.hn_base[2].weight, net.hn_base[2].bias))
+        acts = [F.leaky_relu(F.linear(base, h[0].weight, h[0].bias)) for h in net.hn_heads]
+        theta_ref = torch.cat([F.linear(a, h[2].weight, h[2].bias).flatten() for a, h in zip(acts, net.hn_heads)])
+    names = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+    got = torch.cat([getattr(net.captioner.lstm_cell, n).detach().flatten() for n in names])
+    assert float((got - theta_ref[:got.numel()]).abs().max()) < 2e-6
+    # utils.py:68: the extra layer re-reads theta from offset 0
+    lay = torch.cat([getattr(net.captioner.layers[0], n).detach().flatten() for n in names])
+    assert torch.equal(lay, theta_ref[:lay.numel()].reshape(-1)) or float((lay - theta_ref[:lay.numel()]).abs().max()) < 2e-6
+    g, db = net.hn_heads[0][2].weight.grad, net.hn_heads[0][2].bias.grad
+    rows = torch.randint(0, g.shape[0], (64,), device=DEV)
+    assert float((g[rows] - db[rows, None] * acts[0][0][None, :]).abs().max()) < 1e-9
+    assert float(g.abs().max()) > 0
+    assert all(float(net.hn_heads[i][2].weight.grad.abs().sum()) == 0.0 for i in range(4, 8))
+    assert bool(torch.isfinite(loss))
