@@ -52,10 +52,11 @@ def _worker(rank, world, port, same_batch, q, flickr=False):
         x = torch.zeros(dims.he, device="cuda:0")
         x[1 if same_batch else rank + 1] = 1.0
         losses = []
+        feats_dev, caps_dev = batch["features"].cuda(), batch["captions"].cuda()
         for _ in range(4):
-            if flickr:
+            if flickr:      # bench.py's configuration: next-step theta in the Adam pass + next precompute on a side stream
                 tok = 4 + rank
-                l = tr.step(batch["features"].cuda(), batch["captions"].cuda(), style_token=tok, next_style_token=tok)
+                l = tr.step(feats_dev, caps_dev, style_token=tok, next_style_token=tok, next_features=feats_dev)
             else:
                 l = tr.step(batch["features"].cuda(), batch["captions"].cuda(), x_style=x)
             losses.append(float(l[0]))
