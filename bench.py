@@ -146,6 +146,8 @@ def main():
     torch.manual_seed(1234)                       # identical replicas on every rank
     net = HyperNet(F, E, H, V, _Vocab()).to(dev)
     tr = FusedTrainer(net, lr=1e-3, max_norm=5.0)
+    if os.environ.get("CAPHN_OVERLAP_LEVEL"):
+        tr.overlap_level = int(os.environ["CAPHN_OVERLAP_LEVEL"])
     if os.environ.get("CAPHN_OVERLAP_AFTER_HEAD"):
         tr.overlap_after_head = int(os.environ["CAPHN_OVERLAP_AFTER_HEAD"])
     batches = synth_batches(4, B, T, P, D, V, dev, seed=1234 + rank)
@@ -161,11 +163,11 @@ def main():
         do_step = tr.step_graphed if use_graph else tr.step
     else:
         # the loader is one batch ahead, so the next batch's style is known when the optimiser runs
-        nxt = {batches[i][0].data_ptr(): batches[(i + 1) % len(batches)][0] for i in range(len(batches))}
+        nxt = {batches[i][0].data_ptr(): batches[(i + 1) % len(batches)] for i in range(len(batches))}
 
         def do_step(f, c, style_token):
-            return tr.step(f, c, style_token=style_token, next_style_token=style_token,
-                           next_features=None if args.no_overlap else nxt[f.data_ptr()])
+            nf, nc = (None, None) if args.no_overlap else nxt[f.data_ptr()]
+            return tr.step(f, c, style_token=style_token, next_style_token=style_token, next_features=nf, next_captions=nc)
     if use_graph:                                  # two passes over the batch buffers: eager, then capture
         for _ in range(2):
             for f, c in batches:

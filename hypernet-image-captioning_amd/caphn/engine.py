@@ -73,8 +73,11 @@ class FusedTrainer:
         # next-step feature_fc / init_hidden / W_a f issued on a side stream beside the small Adam passes
         self._pre_stream = torch.cuda.Stream(device=dev)
         self._pre_key = None
+        self._theta_pre = None
         self._pre_done = torch.cuda.Event()
         self.overlap_after_head = 0      # the side stream forks after this head's Adam pass (-1: before the first)
+        self.overlap_level = 1           # 2: also G / embedding / x-side gates once the next W_ih exists (measured: no gain,
+                                         # the extra side-stream work slows the concurrent Adam pass by as much)
 
     # ------------------------------------------------------------------ parameter arenas
     def _build_arena(self):
@@ -220,17 +223,22 @@ class FusedTrainer:
             ops.hyper_forward(self.shape, hp, x, theta=theta, acts=self._acts)
         self._next_key = None
         params = self._dec_tensors(theta, grads=False)
-        if dims.rows:
-            ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
         fdims = dims
+        rows_done = False
         if self._pre_key is not None:
-            if self._pre_key == (features.data_ptr(), B, T, P) and not self._readopted:
-                import dataclasses
-                torch.cuda.current_stream().wait_event(self._pre_done)
-                fdims = dataclasses.replace(dims, pre=True)
-            else:       # the announced features did not come: the side-stream work is wasted but must finish first
-                torch.cuda.current_stream().wait_event(self._pre_done)
+            kf, kc, kB, kT, kP, level = self._pre_key
+            torch.cuda.current_stream().wait_event(self._pre_done)      # even if the announced batch did not come
+            if (kf, kB, kT, kP) == (features.data_ptr(), B, T, P) and not self._readopted:
+                if level == 2 and kc == captions.data_ptr() and theta is self._theta_pre:
+                    import dataclasses
+                    fdims = dataclasses.replace(dims, pre=2)
+                    rows_done = True
+                else:
+                    import dataclasses
+                    fdims = dataclasses.replace(dims, pre=1)
             self._pre_key = None
+        if dims.rows and not rows_done:
+            ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
         ops.decoder_forward(fdims, params, features, captions, buf["ws"], logits=buf["logits"], alphas=buf["alphas"],
                             validate=validate)
         lib_loss, dlogits = ops.cross_entropy_fwd_bwd(buf["logits"], captions, 0, dlogits=buf["logits"])
@@ -317,37 +325,54 @@ class FusedTrainer:
             ops.hyper_forward_acts(self.shape, hp, xn, self._acts_next)
             if self._theta_next is None:
                 self._theta_next = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)
-        if next_batch is not None and self.overlap_after_head < 0:
-            self._precompute_next(*next_batch)
-        for i, (gi, ai, o, w, ao, an) in enumerate(segs):
+        # Order of the rank-1 passes when the next minibatch is known: everything the front of the next forward needs
+        # (W_ih, b_ih -- heads 0, 2; and the tiny b_hh head) first, then the side stream starts the next forward's
+        # front end while the W_hh pass (head 1, HBM-bound) is still streaming.
+        full = (self.overlap_level >= 2 and prefetch and next_batch is not None and next_batch[1] is not None and len(segs) == 4 and
+                next_batch[1].dtype == torch.int64 and next_batch[1].is_contiguous())
+        order = [0, 2, 3, 1] if full else list(range(len(segs)))
+        fork_after = order[-2] if full else self.overlap_after_head
+        if next_batch is not None and not full and self.overlap_after_head < 0:
+            self._precompute_next(*next_batch, level=1)
+        for i in order:
+            gi, ai, o, w, ao, an = segs[i]
             kw = {}
             if prefetch:
                 kw = dict(next_a=self._acts_next[ao:ao + an], next_bias=self._owned[f"hn_heads.{i}.2.bias"].data,
                           next_theta=self._theta_next[o:o + w])
             ops.adam_rank(self.W2[i].data, self.W2_m[i], self.W2_v[i], gi, ai, self._coef, self.lr, step,
                           self.betas, self.eps, dev_scalars=self._adam_dev, **kw)
-            if i == self.overlap_after_head and next_batch is not None:
-                self._precompute_next(*next_batch)
+            if i == fork_after and next_batch is not None:
+                self._precompute_next(*next_batch, level=2 if full else 1)
         return self._coef
 
-    def _precompute_next(self, features, T):
+    def _precompute_next(self, features, captions, T, level=1):
         """The decoder's dense parameters are final (adam_dense ran) and the workspace is free (backward is done):
-        run the next minibatch's feature_fc / init_hidden / W_a f (MFMA-bound, 51 MB of reads) on a side stream
-        while the remaining Adam passes stream the hypernet (HBM-bound).  It starts after the head-0 pass, the
-        kernel the roofline figure is quoted on, so that one is measured undisturbed."""
+        run the front of the next minibatch's forward on a side stream while the remaining Adam pass streams the
+        hypernet (HBM-bound).  level 1: feature_fc / init_hidden / W_a f (theta-independent).  level 2 (next theta's
+        W_ih / b_ih already produced by the passes issued so far, captions known): also the live-row map, G, the
+        embedding lookup and the x-side gates, so the next forward starts at the recurrent kernel.  The fork sits
+        after the head-0 pass, the kernel the roofline figure is quoted on, so that one is measured undisturbed."""
         B, P, _ = features.shape
         buf = self._buffers(B, T, P)
-        params = {n: self._view(self.flat_p, "captioner." + n) for n in self._dec_names}
-        # the cell entries are not read by this part; hand over any correctly shaped tensors
-        theta = self._theta if getattr(self, "_theta", None) is not None else torch.empty(self.theta_size, device=self.dev)
-        params.update({n: t for n, t in self._dec_tensors(theta, grads=False).items() if n in self._cell_names})
+        dims = buf["dims"]
+        theta = self._theta_next if level == 2 else (self._theta if getattr(self, "_theta", None) is not None
+                                                     else torch.empty(self.theta_size, device=self.dev))
+        params = self._dec_tensors(theta, grads=False)
         main = torch.cuda.current_stream()
         self._pre_stream.wait_stream(main)
         with torch.cuda.stream(self._pre_stream):
-            ops.decoder_precompute(buf["dims"], params, features, buf["ws"])
+            if level == 2:
+                cl = captions
+                if dims.rows:
+                    ops.decoder_prepare_rows(dims, cl, 0, buf["ws"])
+                ops.decoder_precompute(dims, params, features, buf["ws"], captions=cl)
+            else:
+                ops.decoder_precompute(dims, params, features, buf["ws"])
             self._pre_done.record(self._pre_stream)
-        self._pre_key = (features.data_ptr(), B, T, P)
-
+        self._theta_pre = theta if level == 2 else None
+        self._pre_key = (features.data_ptr(), captions.data_ptr() if (level == 2 and captions is not None) else None,
+                         B, T, P, level)
 
     def optimizer_step(self, next_x_style=None, next_style_token=None, next_batch=None):
         """clip_grad_norm_(max_norm) over ALL gradients + Adam, on device, no host sync.
@@ -358,12 +383,14 @@ class FusedTrainer:
         return self._optimizer_impl(next_x_style, next_style_token, next_batch)
 
     def step(self, features, captions, x_style=None, style_token=None, next_x_style=None, next_style_token=None,
-             next_features=None, next_T=None):
-        """next_features (+ next_T, default: this T): the NEXT minibatch's feature maps when the loader is one batch
-        ahead -- their caption-independent precompute then overlaps this step's optimiser (the next call must pass
-        that same tensor)."""
+             next_features=None, next_captions=None, next_T=None):
+        """next_features (+ next_captions, or next_T when only the length is known; default: this T): the NEXT
+        minibatch when the loader is one batch ahead -- the front of its forward then overlaps this step's optimiser
+        (the next call must pass those same tensors; captions as int64)."""
         loss = self.forward_backward(features, captions, x_style, style_token)
-        nb = None if next_features is None else (next_features, captions.shape[1] if next_T is None else next_T)
+        if next_captions is not None:
+            next_T = next_captions.shape[1]
+        nb = None if next_features is None else (next_features, next_captions, captions.shape[1] if next_T is None else next_T)
         self.optimizer_step(next_x_style, next_style_token, nb)
         return loss
 

@@ -282,15 +282,30 @@ extern "C" int caphn_decoder_prepare_rows(const caphn_decoder_dims* d, const int
     return caphn_launch_status();
 }
 
+// x side of the forward that needs the captions and the generated W_ih: embedding lookup with the reference's zeroed
+// first two inputs, then the gate pre-activations for all T
+static int decoder_inputs(const caphn_decoder_dims* d, const caphn_decoder_params* p, const Ws& w, float* ws,
+                          const int64_t* captions, hipStream_t s) {
+    const int BT = d->B * d->T, E = d->E, GH = w.NG * d->H, EF = d->E + d->F;
+    int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
+    hipLaunchKernelGGL(build_idx_kernel, dim3((BT + 255) / 256), dim3(256), 0, s, d->B, d->T, captions, idx);
+    RUN(caphn_embedding_gather(BT, E, p->embed_w, idx, ws + w.Xe, s));
+    RUN(caphn_gemm_f32(0, 1, BT, GH, E, ws + w.Xe, E, p->w_ih, EF, ws + w.Xg, GH, p->b_ih, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    return CAPHN_OK;
+}
+
 extern "C" int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_params* p, const float* features,
-                                        void* ws_, caphn_stream_t stream) {
+                                        const int64_t* captions, void* ws_, caphn_stream_t stream) {
     if (!dims_ok(d) || !p || !features || !ws_) return CAPHN_EINVAL;
     const bool raw = d->raw_features != 0;
     if (!raw && (!p->fc0_w || !p->fc0_b || !p->fc2_w || !p->fc2_b)) return CAPHN_EINVAL;
     if (d->cell == CAPHN_CELL_LSTM && (!p->initc_w || !p->initc_b)) return CAPHN_EINVAL;
     const Ws w = layout(d);
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const float* f = nullptr;
-    RUN(decoder_precompute(d, p, w, static_cast<float*>(ws_), features, &f, static_cast<hipStream_t>(stream), 1));
+    // captions given: the generated W_ih / b_ih are final too, so G and the x-side gates can be done as well
+    RUN(decoder_precompute(d, p, w, static_cast<float*>(ws_), features, &f, s, captions ? 3 : 1));
+    if (captions) RUN(decoder_inputs(d, p, w, static_cast<float*>(ws_), captions, s));
     return caphn_launch_status();
 }
 
@@ -310,12 +325,9 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     if (!raw && (!p->fc0_w || !p->fc0_b || !p->fc2_w || !p->fc2_b)) return CAPHN_EINVAL;
 
     const float* f = nullptr;
-    RUN(decoder_precompute(d, p, w, ws, features, &f, s, d->precomputed ? 2 : 3));
-    // embedding lookup with the reference's zeroed first two inputs, then the x side of the gates
-    int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
-    hipLaunchKernelGGL(build_idx_kernel, dim3((BT + 255) / 256), dim3(256), 0, s, B, T, captions, idx);
-    RUN(caphn_embedding_gather(BT, E, p->embed_w, idx, ws + w.Xe, s));
-    RUN(caphn_gemm_f32(0, 1, BT, GH, E, ws + w.Xe, E, p->w_ih, EF, ws + w.Xg, GH, p->b_ih, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    // precomputed: 0 nothing, 1 the theta-independent part, 2 everything in front of the recurrent kernel
+    RUN(decoder_precompute(d, p, w, ws, features, &f, s, d->precomputed >= 2 ? 0 : (d->precomputed ? 2 : 3)));
+    if (d->precomputed < 2) RUN(decoder_inputs(d, p, w, ws, captions, s));
 
     RecFwdArgs a;
     a.B = B; a.T = T; a.P = P; a.H = H; a.RG = RG;

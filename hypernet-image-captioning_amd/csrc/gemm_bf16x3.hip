@@ -434,10 +434,9 @@ int launch_cfg(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 
 int g_tune_gemm_xcd = 1;      // 1 (default): XCD-aware tile order
 int g_tune_gemm_fast = 1;     // 1 (default): branch-free loads (static vmcnt) where alignment allows
-int g_tune_gemm_tile = 0;     // 0 (default): 128x128 when >= 512 such tiles else 64x64; 1: also 128x64; 2: skinny 64x256 / 256x64
-                              // tiles (measured slower: two workgroups per CU hide less latency than five)
-// Skinny problems (one extent in (128, 256], the other long): a 64-wide tile on the short side makes the LONG operand
-// travel from L2/HBM once per short-side tile (4x for N = 200).  A tile spanning the whole short side reads it once.
+// Tile choice: 128x128 when that alone gives >= 512 workgroups, else 64x64 (five workgroups per CU).  Measured and
+// dropped: 64x256 / 256x64 tiles spanning the whole short side of the N = 200 problems (the long operand is read once,
+// but two workgroups per CU hide far less latency: 1.3-2x slower) and 128x64 (no change).
 int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
     if (g_tune_gemm_xcd) g.flags |= 1 << 20;
     g.kmap_lds = 0;
@@ -448,14 +447,6 @@ int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
     }
     if (!g_tune_gemm_fast) g.flags |= 1 << 21;
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.splitk;
-    if (g_tune_gemm_tile == 2) {
-        if (g.N > 128 && g.N <= 256 && g.M >= 1024) return launch_cfg<64, 256>(g, ta, tb, s);
-        if (g.M > 128 && g.M <= 256 && g.N >= 1024) return launch_cfg<256, 64>(g, ta, tb, s);
-    }
     if (tiles128 >= 512) return launch_cfg<128, 128>(g, ta, tb, s);
-    if (g_tune_gemm_tile == 1) {
-        const long t12864 = (long)((g.M + 127) / 128) * ((g.N + 63) / 64) * g.splitk;
-        if (t12864 >= 512) return launch_cfg<128, 64>(g, ta, tb, s);
-    }
     return launch_cfg<64, 64>(g, ta, tb, s);
 }

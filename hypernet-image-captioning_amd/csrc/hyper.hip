@@ -494,7 +494,6 @@ extern int g_tune_adam;
 extern int g_tune_gemm;
 extern int g_tune_rec_rotate;
 extern int g_tune_fork;
-extern int g_tune_gemm_tile;
 extern int g_tune_gemm_xcd;
 extern int g_tune_gemm_fast;
 extern "C" int caphn_tune(int key, int value) {
@@ -503,7 +502,6 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 2) { g_tune_gemm = value; return CAPHN_OK; }
     if (key == 3) { g_tune_rec_rotate = value; return CAPHN_OK; }
     if (key == 4) { g_tune_fork = value; return CAPHN_OK; }
-    if (key == 5) { g_tune_gemm_tile = value; return CAPHN_OK; }
     if (key == 6) { g_tune_gemm_xcd = value; return CAPHN_OK; }
     if (key == 7) { g_tune_gemm_fast = value; return CAPHN_OK; }
     return CAPHN_EINVAL;

@@ -138,7 +138,9 @@ typedef struct caphn_decoder_dims {
                            gradients in one arena clears it with one caphn_zero_f32): the composite then skips its ~16
                            per-tensor zero fills (split-K / atomic accumulation targets) */
     int precomputed;    /* 1: caphn_decoder_precompute has already filled this workspace for these features with the
-                           current feature_fc / attention.W_a / init_h parameters; caphn_decoder_forward skips that part */
+                           current feature_fc / attention.W_a / init_h parameters; caphn_decoder_forward skips that part.
+                           2: it was also given the captions (and the final generated W_ih / b_ih): the forward starts
+                           at the recurrent kernel */
 } caphn_decoder_dims;
 
 typedef struct caphn_decoder_params {   /* reference state_dict names in comments */
@@ -175,9 +177,11 @@ int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_decoder_param
                           float* logits, float* alphas, void* ws, caphn_stream_t stream);
 /* The part of the forward that depends neither on the captions nor on the generated cell weights: feature_fc,
  * init_hidden (init_c) and the hoisted W_a f.  A trainer that knows the next minibatch's features can issue it on
- * another stream while the optimiser streams the hypernet (then set dims.precomputed = 1 for that forward). */
+ * another stream while the optimiser streams the hypernet (then set dims.precomputed = 1 for that forward).  With
+ * captions it also produces G = f W_ih[:,E:]^T, the embedding lookup and the x-side gate pre-activations, which need
+ * the generated W_ih / b_ih of THAT forward (dims.precomputed = 2). */
 int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_params* p, const float* features,
-                             void* ws, caphn_stream_t stream);
+                             const int64_t* captions /* optional, see dims.precomputed */, void* ws, caphn_stream_t stream);
 /* Compacts the (b,t) rows whose target differs from ignore_index into a row map kept in the workspace (count stays on
  * the device: no host synchronisation).  Call before caphn_decoder_forward / _backward with dims.row_subset = 1. */
 int caphn_decoder_prepare_rows(const caphn_decoder_dims* d, const int64_t* targets, int64_t ignore_index,
@@ -335,8 +339,9 @@ int caphn_adam_rank_gemv_f32(int R, int rows, int k, float* W, float* m, float* 
 int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out, caphn_stream_t stream);
 
 /* Tuning knob used by tools/microbench_stream.py to A/B kernel variants in one process
- * (key 0: forward-GEMV variant, key 1: rank-Adam variant, key 2: GEMM back end -- 0 fp32 MFMA,
- * 1 split-bf16 MFMA).  Defaults are the measured-fastest. */
+ * (key 0: forward-GEMV variant, key 1: rank-Adam variant, key 2: GEMM back end -- 0 fp32 MFMA, 1 split-bf16 MFMA,
+ * key 3: row rotation in the recurrent kernels, key 4: side-stream forking of the decoder composites, key 6: XCD-aware
+ * GEMM tile order, key 7: branch-free GEMM loads).  Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
 #ifdef __cplusplus

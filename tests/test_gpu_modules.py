@@ -371,11 +371,25 @@ def test_next_precompute_overlaps_optimizer(name):
     xs = None if tok is not None else x.to(DEV)
     ta = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
     tb = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
-    la, lb = [], []
+    tc = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
+    tc.overlap_level = 2
+    caps2 = caps.clone(); caps2[:, 2] = (caps2[:, 2] + 3) % dims.V
+    cseq = [caps, caps2, caps, caps2, caps2]         # level 2 also announces the captions (last one wrong again)
+    cann = [caps2, caps, caps2, caps, None]
+    la, lb, lc, ld = [], [], [], []
+    td = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
     for i, f in enumerate(seq):
         la.append(float(ta.step(f, caps, x_style=xs, style_token=tok)[0]))
         lb.append(float(tb.step(f, caps, x_style=xs, style_token=tok, next_features=ann[i])[0]))
         if ann[i] is not None:
-            assert tb._pre_key is not None
+            assert tb._pre_key is not None and tb._pre_key[-1] == 1
+        # level 2: next style + next features + next captions -> the next forward starts at the recurrent kernel
+        ld.append(float(td.step(f, cseq[i], x_style=xs, style_token=tok)[0]))
+        lc.append(float(tc.step(f, cseq[i], x_style=xs, style_token=tok, next_x_style=xs, next_style_token=tok,
+                                next_features=ann[i], next_captions=cann[i])[0]))
+        if ann[i] is not None:
+            assert tc._pre_key is not None and tc._pre_key[-1] == 2
     assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
     assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 2e-5
+    assert max(abs(a - b) for a, b in zip(ld, lc)) < 2e-5, (ld, lc)
+    assert maxdiff(td.flat_p.cpu(), tc.flat_p.cpu()) < 2e-5

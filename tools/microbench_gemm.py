@@ -31,7 +31,7 @@ def main():
         out = torch.zeros(M, N, device=dev)
         line = f"{name:11s} M={M:5d} N={N:5d} K={K:5d} sk={sk:2d}"
         for mode in (0, 1):
-            lib.caphn_tune(2, 1); lib.caphn_tune(5, 0); lib.caphn_tune(6, 1); lib.caphn_tune(7, mode)
+            lib.caphn_tune(2, 1); lib.caphn_tune(6, 1); lib.caphn_tune(7, mode)
             ts = []
             for _ in range(6):
                 if sk > 1:
@@ -46,7 +46,7 @@ def main():
             t = float(np.median(ts[1:])) * 1e3
             line += f" | {'generic' if mode == 0 else 'fast   '}: {t:7.1f} us {2.0*M*N*K/t/1e6:6.1f} TF err {err:.2e} (rel {rel:.1e})"
         print(line)
-    lib.caphn_tune(2, 1); lib.caphn_tune(5, 0); lib.caphn_tune(6, 1); lib.caphn_tune(7, 1)
+    lib.caphn_tune(2, 1); lib.caphn_tune(6, 1); lib.caphn_tune(7, 1)
 
 
 if __name__ == "__main__":
