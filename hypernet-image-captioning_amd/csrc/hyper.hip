@@ -117,6 +117,32 @@ __device__ __forceinline__ void gemv_rows_oct(const GemvJob& J, int lb, int tid)
     }
 }
 
+// long rows of any width / alignment (hypernet.py's heads: k = 11250, 8437): one wave per row, lane-contiguous dword
+// loads (256 B per wave-instruction whatever the row's alignment), 8 of W and 8 of x in flight per lane; x comes from
+// L2 (45 KB does not fit the L1).  The 8-lanes-per-row fallback below reads 32 B per row per instruction and reached
+// 2.9 TB/s on the 11 GB hypernet; this form does not depend on k % 4.
+__device__ __forceinline__ void gemv_rows_long(const GemvJob& J, int lb, int tid) {
+    const int lane = tid & 63, wave_g = lb * 4 + (tid >> 6), nwaves = J.nblocks * 4;
+    for (int r = wave_g; r < J.rows; r += nwaves) {
+        const float* row = J.W + (size_t)r * J.k;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int c = lane;
+        for (; c + 64 * 7 < J.k; c += 64 * 8) {
+            float w[8], x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { w[u] = __builtin_nontemporal_load(row + c + 64 * u); x[u] = J.x[c + 64 * u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += w[u] * x[u];
+        }
+        for (; c < J.k; c += 64) s[0] += __builtin_nontemporal_load(row + c) * J.x[c];
+        float t = wave_sum(((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])));
+        if (lane == 0) {
+            const float v = t + (J.b ? J.b[r] : 0.f);
+            J.y[r] = J.act ? lrelu(v) : v;
+        }
+    }
+}
+
 // QMAX (chunks of 256 columns per row) is a KERNEL template parameter picked on the host from the widest job:
 // with all widths inlined into one kernel the register allocation is that of QMAX = 8 (185-256 VGPRs, 1-2
 // waves/SIMD) whatever k is; per-width kernels need ~40-70 VGPRs and keep 8 waves/SIMD in flight.
@@ -129,6 +155,8 @@ __global__ __launch_bounds__(256) void gemv_fwd_kernel(GemvJobs jobs) {
     if (J.vec && J.k >= 128 && J.k <= 256 * QMAX) {
         const int wave_g = lb * 4 + (tid >> 6), nwaves = J.nblocks * 4, lane = tid & 63;
         gemv_rows_wave<QMAX, RB, NTL>(J, wave_g, nwaves, lane);
+    } else if (J.k >= 1024) {
+        gemv_rows_long(J, lb, tid);
     } else {
         gemv_rows_oct(J, lb, tid);
     }
