@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cell", choices=["gru", "lstm"], default="gru",
+                    help="gru: the metric's workload; lstm: BASELINE config 3 (hypernet-generated LSTMCell, side measurement)")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not tell the optimiser pass the next minibatch's style (disables the fused next-theta GEMV)")
@@ -144,7 +146,7 @@ def main():
 
     B, T, P, D, F, E, H, V = args.batch, 20, 49, 2048, 200, 200, 200, 9684
     torch.manual_seed(1234)                       # identical replicas on every rank
-    net = HyperNet(F, E, H, V, _Vocab()).to(dev)
+    net = HyperNet(F, E, H, V, _Vocab(), cell=args.cell).to(dev)
     tr = FusedTrainer(net, lr=1e-3, max_norm=5.0)
     if os.environ.get("CAPHN_OVERLAP_LEVEL"):
         tr.overlap_level = int(os.environ["CAPHN_OVERLAP_LEVEL"])
@@ -226,7 +228,7 @@ def main():
             "metric": METRIC, "value": B * world * args.steps / dt, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Flickr30k-shaped GRU+additive-attention decoder + hypernet (3 style domains), "
+            "config": {"workload": f"Flickr30k-shaped {args.cell.upper()}+additive-attention decoder + hypernet (3 style domains), "
                                    "full training step (fwd, CE, bwd, clip 5.0, Adam)",
                        "per_gpu_batch": B, "global_batch": B * world, "T": T, "P": P, "D": D, "F": F, "E": E, "H": H,
                        "V": V, "hypernet_params": int(sum(q.numel() for q in net.hn_base.parameters()) +
