@@ -393,3 +393,42 @@ def test_next_precompute_overlaps_optimizer(name):
     assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 2e-5
     assert max(abs(a - b) for a, b in zip(ld, lc)) < 2e-5, (ld, lc)
     assert maxdiff(td.flat_p.cpu(), tc.flat_p.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("B,T,P", [(1, 1, 1), (1, 2, 1), (2, 3, 2), (3, 2, 64), (1, 5, 65)])
+def test_degenerate_shapes_vs_oracle(B, T, P):
+    """Smallest and awkward extents: one caption, T = 1 / 2 (every input is the zeroed view, decoderlstm.py:82-88),
+    one attention position, P just above a wavefront.  Forward + all gradients through the fused engine vs the oracle."""
+    from caphn.engine import FusedTrainer
+    dims = O.Dims(D=20, F=8, E=8, H=8, V=30, he=4)
+    p = O.init_params(dims, seed=B * 100 + T * 10 + P)
+    batch = O.synth_batch(dims, B, max(T, 5), P, seed=5)
+    feats, caps = batch["features"], batch["captions"][:, :T].contiguous()
+    caps[:, 0] = 1
+    x = torch.zeros(dims.he); x[1] = 1.0
+    loss_ref, _, _, _, grads_ref = O.forward_backward(dims, p, x, feats, caps)
+    for rows in (False, True):          # with and without the live-row map
+        tr = FusedTrainer(build_net(dims, p, cc=True), lr=1e-3)
+        tr.skip_ignored_rows = rows
+        out = tr.forward_backward(feats.to(DEV), caps.to(DEV), x_style=x.to(DEV))
+        assert abs(float(out[0]) - float(loss_ref)) < 2e-6
+        n_checked = 0
+        for n, gref in grads_ref.items():
+            if n in tr.offs and gref is not None:
+                assert maxdiff(tr.grad(n).cpu(), gref) < 2e-6, (n, rows)
+                n_checked += 1
+        assert n_checked >= 20
+        assert maxdiff(tr.flat_g[:tr.theta_size].cpu(), grads_ref["dtheta"]) < 2e-6
+
+
+def test_all_targets_ignored_matches_torch():
+    """Every target is <pad>: F.cross_entropy's mean over zero targets is NaN (0/0); the fused loss must say the same
+    rather than report a finite number, and the live-row map must cope with an empty set."""
+    from caphn.engine import FusedTrainer
+    dims = TINY_DIMS["gru_tiny_cc"]
+    g, p = load_case("gru_tiny_cc")
+    caps = torch.zeros_like(g["captions"])
+    tr = FusedTrainer(build_net(dims, p, cc=True), lr=1e-3)
+    out = tr.forward_backward(g["features"].to(DEV), caps.to(DEV), x_style=g["x_style"].to(DEV))
+    ref = F.cross_entropy(torch.zeros(4, dims.V), torch.zeros(4, dtype=torch.long), ignore_index=0)
+    assert bool(torch.isnan(ref)) and bool(torch.isnan(out[0].cpu())) and float(out[1]) == 0.0
