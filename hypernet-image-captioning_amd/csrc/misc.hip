@@ -5,6 +5,8 @@
 #include <math.h>
 
 namespace {
+constexpr int RMAX = 8;      // data-parallel ranks a rank-R gradient may have (8 GPUs per node)
+
 
 // ------------------------------------------------------------------ cross entropy (fwd + bwd)
 // F.cross_entropy(logits.view(-1,V), caps.view(-1), ignore_index)   hypernet_attention.py:183
@@ -182,6 +184,33 @@ __global__ void rank_gram_finish_kernel(int R, int njobs, const double* __restri
         acc[0] += t;
     }
 }
+// Data parallel: sum_r g_r (x) a_r has at most as many distinct terms as there are distinct activation rows a_r -- ranks
+// that drew the same style / domain produce bit-identical a_r (replicated parameters, same kernels).  Fold their row
+// factors: g_leader += g_r, g_r = 0.  The rank-R Adam pass skips zero row factors, so 8 ranks over 3 style domains cost
+// 3 terms, not 8.
+__global__ __launch_bounds__(256) void rank_leader_kernel(int R, int n, const float* __restrict__ acts, size_t lda, int* __restrict__ leader) {
+    __shared__ int lead[RMAX];
+    if (threadIdx.x < RMAX) lead[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    for (int r = 1; r < R; ++r)
+        for (int s = 0; s < r; ++s) {
+            if (lead[s] != s) continue;                      // block-uniform
+            int same = 1;
+            for (int i = threadIdx.x; i < n; i += 256) same &= (acts[(size_t)s * lda + i] == acts[(size_t)r * lda + i]);
+            if (__syncthreads_and(same)) { if (threadIdx.x == 0) lead[r] = s; __syncthreads(); break; }
+        }
+    __syncthreads();
+    if (threadIdx.x < R) leader[threadIdx.x] = lead[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void rank_fold_kernel(int R, int n, float* __restrict__ gfac, size_t ldg, const int* __restrict__ leader) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    for (int r = 1; r < R; ++r) {
+        const int l = leader[r];
+        if (l != r) { gfac[(size_t)l * ldg + c] += gfac[(size_t)r * ldg + c]; gfac[(size_t)r * ldg + c] = 0.f; }
+    }
+}
+
 __global__ __launch_bounds__(256) void clip_coef_kernel(int nparts, const double* __restrict__ partial, const double* extra,
                                                         double max_norm, double scale, float* coef_out) {
     __shared__ double red[4];
@@ -235,14 +264,14 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(size_t n, float* __rest
 
 // W,m,v [rows,k]; grad[row][col] = coef * sum_r gfac[r][row] * afac[r][col].  One wave per row
 // (row-contiguous dwordx4 streams of W, m and v: read 12 B, write 12 B per element).
-constexpr int RMAX = 8;
 // RB rows per wave iteration (3*RB*QMAX independent dwordx4 loads in flight), NTL / NTS: non-temporal
 // loads / stores.  Variant chosen by caphn_tune(1, v) -- measured A/B.
 struct NextGemv { const float* a; const float* bias; float* theta; };   // theta[row] = W'[row,:] . a + bias[row]
-template <int QMAX, int RB, bool NTL, bool NTS>
+template <int QMAX, int RB, bool NTL, bool NTS, bool MULTI>
 __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W, float* m, float* v,
                                                const float* gfac, size_t ldg, const float* afac, size_t lda,
-                                               float c, const AdamK& K, int wave_g, int nwaves, int lane, NextGemv nx) {
+                                               float c, const AdamK& K, int wave_g, int nwaves, int lane, NextGemv nx,
+                                               const f32x4* a_s /* LDS copy of afac [R][k/4] (R > 1), or null */) {
     const int k4 = k >> 2;
     f32x4 an[QMAX];            // next step's head activations (fused forward GEMV on the updated weights)
 #pragma unroll
@@ -254,7 +283,7 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
 #pragma unroll
     for (int q = 0; q < QMAX; ++q) {
         const int cidx = lane + 64 * q;
-        a1[q] = (R == 1 && cidx < k4) ? reinterpret_cast<const f32x4*>(afac)[cidx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        a1[q] = (!MULTI && cidx < k4) ? reinterpret_cast<const f32x4*>(afac)[cidx] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int row0 = wave_g * RB; row0 < rows; row0 += nwaves * RB) {
         f32x4 pp[RB][QMAX], mm[RB][QMAX], vv[RB][QMAX];
@@ -274,25 +303,36 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
                 }
             }
         }
+        // the R row factors of these RB rows: requested together with the streams above (they were loaded one row at a
+        // time in front of each row's arithmetic: R dependent cache-line fetches per row, +54 % at R = 8)
+        // (MULTI is a template parameter: with the R == 1 case in the same code the extra registers cost the
+        // single-GPU pass 12 %)
+        float grs[RB][MULTI ? RMAX : 1];
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int r = 0; r < (MULTI ? RMAX : 1); ++r)
+                grs[i][r] = (r < R && row0 + i < rows) ? gfac[(size_t)r * ldg + row0 + i] : 0.f;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             if (row0 + i >= rows) continue;
             const size_t base = (size_t)(row0 + i) * k;
             float dot = 0.f;
-            float gr[RMAX];
+            float gr[MULTI ? RMAX : 1];
 #pragma unroll
-            for (int r = 0; r < RMAX; ++r) gr[r] = r < R ? gfac[(size_t)r * ldg + row0 + i] * c : 0.f;
+            for (int r = 0; r < (MULTI ? RMAX : 1); ++r) gr[r] = grs[i][r] * c;
 #pragma unroll
             for (int q = 0; q < QMAX; ++q) {
                 const int cidx = lane + 64 * q;
                 if (cidx < k4) {
                     f32x4 g;
-                    if (R == 1) g = a1[q] * gr[0];
+                    if constexpr (!MULTI) g = a1[q] * gr[0];
                     else {
                         g = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int r = 0; r < RMAX; ++r)
-                            if (r < R) g += reinterpret_cast<const f32x4*>(afac + (size_t)r * lda)[cidx] * gr[r];
+                            if (r < R && gr[r] != 0.f)     // wave-uniform: a rank merged away by caphn_rank_merge_f32 costs nothing
+                                g += (a_s ? a_s[r * k4 + cidx] : reinterpret_cast<const f32x4*>(afac + (size_t)r * lda)[cidx]) * gr[r];
                     }
                     f32x4 po = pp[i][q], mo = mm[i][q], vo = vv[i][q];
 #pragma unroll
@@ -314,15 +354,28 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
 }
 // QMAX is a kernel template parameter chosen on the host (see gemv_fwd_kernel in hyper.hip: with every width
 // inlined the kernel allocated 255 VGPRs and ran at 1-2 waves/SIMD).
-template <int RB, bool NTL, bool NTS, int QMAX>
+template <int RB, bool NTL, bool NTS, int QMAX, bool MULTI>
 __global__ __launch_bounds__(256) void adam_rank_kernel(int R, int rows, int k, float* W, float* m, float* v,
                                                         const float* gfac, size_t ldg, const float* afac, size_t lda,
-                                                        const float* coef, AdamK K, int vec, NextGemv nx) {
+                                                        const float* coef, AdamK K, int vec, NextGemv nx, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 a_lds[];     // R > 1: the ranks' column factors, [R][k/4]
     const float c = coef[0];
     if (K.dev) { K.lr_bc1 = K.dev[0]; K.sqrt_bc2 = K.dev[1]; }
     if (vec && k <= 256 * QMAX) {
+        // data parallel: the gradient is sum_r g_r (x) a_r.  Re-reading a_r from global memory for every row made the
+        // pass 54 % slower at R = 8 (735 vs 477 us on 240000 x 480); the factors (R*k floats, 15 KB) live in LDS instead
+        const f32x4* a_s = nullptr;
+        if (R > 1 && use_lds) {
+            const int k4 = k >> 2;
+            for (int i = threadIdx.x; i < R * k4; i += 256) {
+                const int r = i / k4, cc = i - r * k4;
+                a_lds[i] = reinterpret_cast<const f32x4*>(afac + (size_t)r * lda)[cc];
+            }
+            __syncthreads();
+            a_s = a_lds;
+        }
         const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4, lane = threadIdx.x & 63;
-        adam_rank_rows<QMAX, RB, NTL, NTS>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane, nx);
+        adam_rank_rows<QMAX, RB, NTL, NTS, MULTI>(R, rows, k, W, m, v, gfac, ldg, afac, lda, c, K, wave_g, nwaves, lane, nx, a_s);
     } else {
         const size_t n = (size_t)rows * k, stride = (size_t)gridDim.x * 256;
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -453,6 +506,16 @@ extern "C" int caphn_rank_sumsq_multi_f32(int R, int n, const int* rows, const i
     hipLaunchKernelGGL(rank_gram_finish_kernel, dim3(1), dim3(64), 0, s, R, n, ws, acc);
     return caphn_launch_status();
 }
+extern "C" int caphn_rank_merge_f32(int R, int n_acts, const float* acts, size_t lda, int n_theta, float* gfac, size_t ldg,
+                                    int* leader_ws, caphn_stream_t stream) {
+    if (R <= 0 || R > RMAX || n_acts <= 0 || n_theta <= 0 || !acts || !gfac || !leader_ws) return CAPHN_EINVAL;
+    if (R == 1) return CAPHN_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(rank_leader_kernel, dim3(1), dim3(256), 0, s, R, n_acts, acts, lda, leader_ws);
+    hipLaunchKernelGGL(rank_fold_kernel, dim3((n_theta + 255) / 256), dim3(256), 0, s, R, n_theta, gfac, ldg, leader_ws);
+    return caphn_launch_status();
+}
+
 extern "C" int caphn_clip_coef(int nparts, const double* partial, const double* extra, double max_norm, double scale,
                                float* coef_out, caphn_stream_t stream) {
     if (nparts < 0 || (nparts > 0 && !partial) || !coef_out) return CAPHN_EINVAL;
@@ -483,8 +546,14 @@ static int adam_rank_launch(int R, int rows, int k, float* W, float* m, float* v
     const AdamK K = make_adam(hp);
     const bool fused = vec && k <= 2048;
     NextGemv nk = fused ? nx : NextGemv{nullptr, nullptr, nullptr};
-#define ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, Q) hipLaunchKernelGGL((adam_rank_kernel<RB, NTL, NTS, Q>), dim3((unsigned)nb), dim3(256), 0, s, \
-        R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, vec, nk)
+    const size_t a_bytes = (R > 1 && vec && k <= 2048) ? sizeof(float) * (size_t)R * k : 0;
+    const int use_lds = a_bytes > 0 && a_bytes <= 60 * 1024;
+    const size_t shm = use_lds ? a_bytes : 0;
+#define ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, Q) do { \
+        if (R == 1) hipLaunchKernelGGL((adam_rank_kernel<RB, NTL, NTS, Q, false>), dim3((unsigned)nb), dim3(256), shm, s, \
+                                       R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, vec, nk, use_lds); \
+        else hipLaunchKernelGGL((adam_rank_kernel<RB, NTL, NTS, Q, true>), dim3((unsigned)nb), dim3(256), shm, s, \
+                                R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, vec, nk, use_lds); } while (0)
 #define ADAM_RANK_LAUNCH(RB, NTL, NTS) do { \
         if (k <= 256) ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, 1); else if (k <= 512) ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, 2); \
         else if (k <= 1024) ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, 4); else ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, 8); } while (0)
