@@ -74,7 +74,6 @@ class FusedTrainer:
         self._pre_stream = torch.cuda.Stream(device=dev)
         self._pre_key = None
         self._theta_pre = None
-        self._leader = torch.zeros(8, dtype=torch.int32, device=dev)
         self._pre_done = torch.cuda.Event()
         self.overlap_after_head = 0      # the side stream forks after this head's Adam pass (-1: before the first)
         self.overlap_level = 1           # 2: also G / embedding / x-side gates once the next W_ih exists (measured: no gain,
@@ -296,8 +295,6 @@ class FusedTrainer:
     def _optimizer_impl(self, next_x_style=None, next_style_token=None, next_batch=None):
         R = dp.world(self.group)
         gfac, acts_all = self._exchange()
-        if R > 1:       # ranks that drew the same style / domain share their column factor: fold them
-            ops.rank_merge(gfac, acts_all, self._leader)
         part = ops.sumsq_partials(self.flat_g, self._part)
         self._acc.zero_()
         o = 0

@@ -502,19 +502,6 @@ def decoder_hyper_backward(dims: DecDims, params, features, captions, dlogits, g
     return gx
 
 
-def rank_merge(gfac: torch.Tensor, acts: torch.Tensor, leader_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Fold the row factors of ranks with bit-identical activation rows (in place on gfac [R, n_theta], acts [R, L]);
-    returns the leader index per rank (device int32)."""
-    lib = L.load()
-    R = gfac.shape[0]
-    assert acts.shape[0] == R and gfac.stride(1) == 1 and acts.stride(1) == 1
-    if leader_ws is None:
-        leader_ws = torch.zeros(8, dtype=torch.int32, device=gfac.device)
-    L.check(lib.caphn_rank_merge_f32(R, acts.shape[1], acts.data_ptr(), acts.stride(0), gfac.shape[1], gfac.data_ptr(),
-                                     gfac.stride(0), L.ptr(leader_ws, torch.int32), L.stream_ptr()), "caphn_rank_merge_f32")
-    return leader_ws
-
-
 def clip_coef(partial: torch.Tensor, extra: Optional[torch.Tensor], max_norm: float, scale: float,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = L.load()

@@ -184,33 +184,6 @@ __global__ void rank_gram_finish_kernel(int R, int njobs, const double* __restri
         acc[0] += t;
     }
 }
-// Data parallel: sum_r g_r (x) a_r has at most as many distinct terms as there are distinct activation rows a_r -- ranks
-// that drew the same style / domain produce bit-identical a_r (replicated parameters, same kernels).  Fold their row
-// factors: g_leader += g_r, g_r = 0.  The rank-R Adam pass skips zero row factors, so 8 ranks over 3 style domains cost
-// 3 terms, not 8.
-__global__ __launch_bounds__(256) void rank_leader_kernel(int R, int n, const float* __restrict__ acts, size_t lda, int* __restrict__ leader) {
-    __shared__ int lead[RMAX];
-    if (threadIdx.x < RMAX) lead[threadIdx.x] = threadIdx.x;
-    __syncthreads();
-    for (int r = 1; r < R; ++r)
-        for (int s = 0; s < r; ++s) {
-            if (lead[s] != s) continue;                      // block-uniform
-            int same = 1;
-            for (int i = threadIdx.x; i < n; i += 256) same &= (acts[(size_t)s * lda + i] == acts[(size_t)r * lda + i]);
-            if (__syncthreads_and(same)) { if (threadIdx.x == 0) lead[r] = s; __syncthreads(); break; }
-        }
-    __syncthreads();
-    if (threadIdx.x < R) leader[threadIdx.x] = lead[threadIdx.x];
-}
-__global__ __launch_bounds__(256) void rank_fold_kernel(int R, int n, float* __restrict__ gfac, size_t ldg, const int* __restrict__ leader) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n) return;
-    for (int r = 1; r < R; ++r) {
-        const int l = leader[r];
-        if (l != r) { gfac[(size_t)l * ldg + c] += gfac[(size_t)r * ldg + c]; gfac[(size_t)r * ldg + c] = 0.f; }
-    }
-}
-
 __global__ __launch_bounds__(256) void clip_coef_kernel(int nparts, const double* __restrict__ partial, const double* extra,
                                                         double max_norm, double scale, float* coef_out) {
     __shared__ double red[4];
@@ -331,7 +304,7 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
                         g = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int r = 0; r < RMAX; ++r)
-                            if (r < R && gr[r] != 0.f)     // wave-uniform: a rank merged away by caphn_rank_merge_f32 costs nothing
+                            if (r < R)
                                 g += (a_s ? a_s[r * k4 + cidx] : reinterpret_cast<const f32x4*>(afac + (size_t)r * lda)[cidx]) * gr[r];
                     }
                     f32x4 po = pp[i][q], mo = mm[i][q], vo = vv[i][q];
@@ -506,16 +479,6 @@ extern "C" int caphn_rank_sumsq_multi_f32(int R, int n, const int* rows, const i
     hipLaunchKernelGGL(rank_gram_finish_kernel, dim3(1), dim3(64), 0, s, R, n, ws, acc);
     return caphn_launch_status();
 }
-extern "C" int caphn_rank_merge_f32(int R, int n_acts, const float* acts, size_t lda, int n_theta, float* gfac, size_t ldg,
-                                    int* leader_ws, caphn_stream_t stream) {
-    if (R <= 0 || R > RMAX || n_acts <= 0 || n_theta <= 0 || !acts || !gfac || !leader_ws) return CAPHN_EINVAL;
-    if (R == 1) return CAPHN_OK;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(rank_leader_kernel, dim3(1), dim3(256), 0, s, R, n_acts, acts, lda, leader_ws);
-    hipLaunchKernelGGL(rank_fold_kernel, dim3((n_theta + 255) / 256), dim3(256), 0, s, R, n_theta, gfac, ldg, leader_ws);
-    return caphn_launch_status();
-}
-
 extern "C" int caphn_clip_coef(int nparts, const double* partial, const double* extra, double max_norm, double scale,
                                float* coef_out, caphn_stream_t stream) {
     if (nparts < 0 || (nparts > 0 && !partial) || !coef_out) return CAPHN_EINVAL;

@@ -324,11 +324,6 @@ typedef struct caphn_adam_hparams {
 /* p,m,v,g flat [n]; g is multiplied by coef[0] (device) first. */
 int caphn_adam_dense_f32(size_t n, float* p, float* m, float* v, const float* g, const float* coef,
                          const caphn_adam_hparams* hp, caphn_stream_t stream);
-/* Data parallel: ranks whose activation rows acts[r, 0:n_acts] are bit-identical (same style / domain on replicated
- * parameters) contribute rank-1 terms with the same column factor: their row factors are folded into the first such
- * rank (gfac[leader] += gfac[r]; gfac[r] = 0) and caphn_adam_rank_* skips zero row factors.  leader_ws: R ints. */
-int caphn_rank_merge_f32(int R, int n_acts, const float* acts, size_t lda, int n_theta, float* gfac, size_t ldg,
-                         int* leader_ws, caphn_stream_t stream);
 /* W,m,v [rows,k]; gradient = coef[0] * sum_r gfac[r,row] * afac[r,col], never materialised. */
 int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, float* v,
                         const float* gfac, size_t ldg, const float* afac, size_t lda,

@@ -372,31 +372,19 @@ def test_adam_rank_equals_dense(ops, R, rows, k):
     assert maxdiff(ops.outer(gf[0].to(DEV), af[0].to(DEV)).cpu(), torch.outer(gf[0], af[0])) < 1e-7
 
 
-def test_rank_merge_folds_identical_domains(ops):
-    """Eight ranks over three style domains: the rank-8 gradient sum_r g_r (x) a_r folds to three terms
-    (caphn_rank_merge_f32); the rank-R Adam pass gives the same update with and without the fold."""
+
+def test_adam_rank_eight_ranks_matches_dense(ops):
+    """Rank-8 gradient sum_r g_r (x) a_r (eight data-parallel ranks): factors staged in LDS, row factors hoisted."""
     g = torch.Generator().manual_seed(17)
-    R, rows, k, L = 8, 300, 96, 130
-    dom = [0, 1, 2, 0, 1, 2, 0, 1]
-    base = torch.randn(3, L, generator=g)
-    acts = torch.stack([base[d] for d in dom]).to(DEV)                 # [R, L]; a_r = acts[r, 10:10+k]
+    R, rows, k = 8, 301, 96
+    a = torch.randn(R, k, generator=g).to(DEV)
     gfac = (torch.randn(R, rows, generator=g) * 1e-2).to(DEV)
-    gf0 = gfac.clone()
-    lead = ops.rank_merge(gfac, acts)
-    assert lead[:R].cpu().tolist() == [0, 1, 2, 0, 1, 2, 0, 1]
-    exp = torch.zeros_like(gf0)
-    for r, d in enumerate(dom):
-        exp[d] += gf0[r]
-    assert maxdiff(gfac.cpu(), exp.cpu()) < 1e-7
-    assert float(gfac[3:].abs().max()) == 0.0
     W = torch.randn(rows, k, generator=g).to(DEV)
     coef = torch.tensor([0.7, 0.0], device=DEV)
-    outs = []
-    for gf in (gf0, gfac):
-        Wc, m, v = W.clone(), torch.zeros_like(W), torch.zeros_like(W)
-        ops.adam_rank(Wc, m, v, gf, acts[:, 10:10 + k], coef, 1e-3, 1)
-        outs.append((Wc, m, v))
-    for a, b in zip(*outs):
-        assert maxdiff(a.cpu(), b.cpu()) < 2e-6
-    grad = 0.7 * (gf0.t().double().cpu() @ acts[:, 10:10 + k].double().cpu())
-    assert maxdiff(outs[1][1].cpu(), 0.1 * grad) < 1e-7                 # m after one step = (1 - beta1) * grad
+    Wc, m, v = W.clone(), torch.zeros_like(W), torch.zeros_like(W)
+    ops.adam_rank(Wc, m, v, gfac, a, coef, 1e-3, 1)
+    grad = 0.7 * (gfac.t().double().cpu() @ a.double().cpu())
+    assert maxdiff(m.cpu(), 0.1 * grad) < 1e-7                          # m after one step = (1 - beta1) * grad
+    assert maxdiff(v.cpu(), 0.001 * grad * grad) < 1e-9
+    ref = W.double().cpu() - 1e-3 * grad / (grad.abs() + 1e-8)           # first Adam step: lr * g / (|g| + eps)
+    assert maxdiff(Wc.cpu(), ref) < 2e-6

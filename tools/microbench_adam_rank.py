@@ -21,11 +21,9 @@ def main():
     coef = torch.tensor([1.0, 1.0], device=dev)
     sc = torch.tensor(ops.adam_scalars(1e-3, (0.9, 0.999), 1), device=dev, dtype=torch.float32)
     na = torch.randn(k, device=dev); nb = torch.zeros(rows, device=dev); nt = torch.empty(rows, device=dev)
-    for R, doms in ((1, 1), (2, 2), (4, 4), (8, 8), (8, 3)):
+    for R, doms in ((1, 1), (2, 2), (4, 4), (8, 8)):
         g = torch.randn(R, rows, device=dev) * 1e-3
         a = torch.randn(doms, k, device=dev)[torch.arange(R) % doms].contiguous()
-        if doms < R:
-            ops.rank_merge(g, a)          # ranks that share a style / domain fold into one term
         for fused in (False, True):
             kw = dict(next_a=na, next_bias=nb, next_theta=nt) if fused else {}
             ts = []
