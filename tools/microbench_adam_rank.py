@@ -13,9 +13,8 @@ sys.path.insert(0, os.path.join(ROOT, "hypernet-image-captioning_amd"))
 from caphn import ops  # noqa: E402
 
 
-def main():
+def main(rows=240000, k=480):
     dev = "cuda"
-    rows, k = 240000, 480
     W = torch.randn(rows, k, device=dev) * 0.01
     m = torch.zeros_like(W); v = torch.zeros_like(W)
     coef = torch.tensor([1.0, 1.0], device=dev)
@@ -33,8 +32,31 @@ def main():
                 torch.cuda.synchronize()
                 ts.append(s.elapsed_time(e))
             t = float(np.median(ts[1:]))
-            print(f"R={R} domains={doms} fused_gemv={int(fused)}: {t*1e3:7.1f} us  {24.0*rows*k/t/1e9:6.2f} TB/s")
+            print(f"R={R} fused_gemv={int(fused)}: {t*1e3:7.1f} us  {24.0*rows*k/t/1e9:6.2f} TB/s")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--gram" not in sys.argv:
     main()
+    print("head 1 (120000 x 240):")
+    main(120000, 240)
+
+
+def gram():
+    """Global-norm term of the rank-R gradients (two R x R Gram matrices per head) for the canonical four heads."""
+    dev = "cuda"
+    heads = [(480, 240000), (240, 120000), (200, 600), (200, 600)]
+    for R in (1, 2, 4, 8):
+        pairs = [(torch.randn(R, w, device=dev), torch.randn(R, k, device=dev)) for k, w in heads]
+        acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        ts = []
+        for _ in range(6):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); ops.rank_sumsq_multi(pairs, acc); e.record()
+            torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e))
+        ref = sum(float(((g.double().t() @ a.double()) ** 2).sum()) for g, a in pairs[2:])   # dense check on the small heads
+        print(f"gram R={R}: {float(np.median(ts[1:]))*1e3:7.1f} us")
+
+
+if __name__ == "__main__" and "--gram" in sys.argv:
+    gram()
