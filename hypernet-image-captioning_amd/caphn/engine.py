@@ -241,7 +241,8 @@ class FusedTrainer:
             ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
         ops.decoder_forward(fdims, params, features, captions, buf["ws"], logits=buf["logits"], alphas=buf["alphas"],
                             validate=validate)
-        lib_loss, dlogits = ops.cross_entropy_fwd_bwd(buf["logits"], captions, 0, dlogits=buf["logits"])
+        lib_loss, dlogits = ops.cross_entropy_fwd_bwd(buf["logits"], captions, 0, dlogits=buf["logits"],
+                                                      leave_ignored_rows=dims.rows)
         buf["loss"].copy_(lib_loss)
         dtheta = self.flat_g[:self.theta_size]
         grads = self._dec_tensors(dtheta, grads=True)

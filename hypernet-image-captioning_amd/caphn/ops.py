@@ -406,7 +406,7 @@ def decoder_backward(dims: DecDims, params: Dict[str, torch.Tensor], features: t
 
 # ------------------------------------------------------------------ loss
 def cross_entropy_fwd_bwd(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int = 0,
-                          dlogits: Optional[torch.Tensor] = None):
+                          dlogits: Optional[torch.Tensor] = None, leave_ignored_rows: bool = False):
     """F.cross_entropy(logits.view(-1,V), targets.view(-1), ignore_index) and its gradient.
     Returns (loss_out[2] = {mean loss, n_valid}, dlogits).  dlogits may alias logits."""
     lib = L.load()
@@ -417,7 +417,8 @@ def cross_entropy_fwd_bwd(logits: torch.Tensor, targets: torch.Tensor, ignore_in
     ws = torch.empty(lib.caphn_ce_workspace_bytes(rows), dtype=torch.uint8, device=logits.device)
     out = _f32(2, device=logits.device)
     L.check(lib.caphn_cross_entropy_fwd_bwd(rows, V, L.ptr(logits), L.ptr(targets.reshape(-1), torch.int64),
-                                            ignore_index, L.ptr(dlogits), L.ptr(out), C.c_void_p(ws.data_ptr()),
+                                            ignore_index, L.ptr(dlogits), L.ptr(out), int(leave_ignored_rows),
+                                            C.c_void_p(ws.data_ptr()),
                                             L.stream_ptr()), "caphn_cross_entropy_fwd_bwd")
     return out, dlogits
 

@@ -213,9 +213,9 @@ int caphn_gemm_tn_colsum(int M, int N, int K, const float* A, int lda, const flo
         if (ldc == N) { int rc = caphn_zero_f32(C, (size_t)M * N, s); if (rc) return rc; }
         else if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, s) != hipSuccess) return CAPHN_ELAUNCH;
     }
-    if (g_tune_gemm != 1) {      // fp32 back end: no fusion
-        int rc = rowmap ? caphn_gemm_mapped(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, splitk, rowmap + 4, rowmap, 2, s)
-                        : caphn_gemm_f32(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, 0, splitk, s);
+    if (g_tune_gemm != 1 && !rowmap) {      // fp32 back end: no fusion (a row subset always runs in the split-bf16 back end,
+                                            // and only the fused sum skips the unwritten rows of ignored targets)
+        int rc = caphn_gemm_f32(1, 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, 0, splitk, s);
         if (rc) return rc;
         return caphn_colsum_f32(K, M, A, lda, colsum_out, cws, s);
     }

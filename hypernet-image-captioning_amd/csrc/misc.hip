@@ -68,6 +68,67 @@ __global__ __launch_bounds__(256) void ce_row_kernel(int V, const float* logits,
     if (tid == 0) row_loss[row] = (logf(s) + m - xt);
 }
 
+// One-pass variant for V % 4 == 0, V <= 4 * 256 * NV: the row lives in registers (NV dwordx4 per thread), so it is read
+// once and every exponential is evaluated once (the three-pass kernel above re-reads the 38 KB row from L2 twice and
+// evaluates 2 V exponentials).  skip_ignored: with the live-row map nobody reads the d logits rows of ignored targets.
+template <int NV>
+__global__ __launch_bounds__(256) void ce_row_reg_kernel(int V, const float* logits, const int64_t* __restrict__ tgt,
+                                                         int64_t ignore, const float* __restrict__ nvalid,
+                                                         float* dlogits, float* __restrict__ row_loss, int skip_ignored) {
+    __shared__ float red[4];
+    __shared__ float bc[2];
+    const int row = blockIdx.x, tid = threadIdx.x, V4 = V >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(logits + (size_t)row * V);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dlogits + (size_t)row * V);
+    const int64_t t = tgt[row];
+    if (t == ignore) {
+        if (!skip_ignored) for (int i = tid; i < V4; i += 256) d4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tid == 0) row_loss[row] = 0.f;
+        return;
+    }
+    const float xt = logits[(size_t)row * V + t];
+    f32x4 v[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = tid + 256 * j;
+        v[j] = i < V4 ? x4[i] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        m = fmaxf(fmaxf(m, fmaxf(v[j][0], v[j][1])), fmaxf(v[j][2], v[j][3]));
+    }
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) bc[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    m = bc[0];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] = caphn_exp(v[j][e] - m);        // exp(-inf) = 0 for the padding lanes
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+    s = wave_sum(s);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) bc[1] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    s = bc[1];
+    const float inv = 1.0f / s, scale = 1.0f / nvalid[0];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = tid + 256 * j;
+        if (i < V4) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[j][e] * inv - ((int64_t)(4 * i + e) == t ? 1.f : 0.f)) * scale;
+            d4[i] = o;
+        }
+    }
+    if (tid == 0) row_loss[row] = (logf(s) + m - xt);
+}
+
 __global__ __launch_bounds__(256) void ce_finish_kernel(int rows, const float* __restrict__ row_loss, const float* nvalid, float* out) {
     __shared__ double red[4];
     double s = 0.0;
@@ -391,14 +452,18 @@ extern "C" size_t caphn_ce_workspace_bytes(int rows) { return sizeof(float) * (s
 
 extern "C" int caphn_cross_entropy_fwd_bwd(int rows, int V, const float* logits, const int64_t* targets,
                                            int64_t ignore_index, float* dlogits, float* loss_out,
-                                           void* ws, caphn_stream_t stream) {
+                                           int leave_ignored_rows, void* ws, caphn_stream_t stream) {
     if (rows <= 0 || V <= 0 || !logits || !targets || !dlogits || !loss_out || !ws) return CAPHN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* nvalid = static_cast<float*>(ws);
     float* row_loss = nvalid + 4;
     const int vec = (V % 4 == 0) && caphn_aligned16(logits) && caphn_aligned16(dlogits);
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, rows, targets, ignore_index, nvalid);
-    hipLaunchKernelGGL(ce_row_kernel, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, dlogits, row_loss, vec);
+    const int nv = vec ? (V / 4 + 255) / 256 : 0;
+    if (nv >= 1 && nv <= 4) hipLaunchKernelGGL(ce_row_reg_kernel<4>, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, dlogits, row_loss, leave_ignored_rows);
+    else if (nv > 4 && nv <= 10) hipLaunchKernelGGL(ce_row_reg_kernel<10>, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, dlogits, row_loss, leave_ignored_rows);
+    else if (nv > 10 && nv <= 16) hipLaunchKernelGGL(ce_row_reg_kernel<16>, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, dlogits, row_loss, leave_ignored_rows);
+    else hipLaunchKernelGGL(ce_row_kernel, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, dlogits, row_loss, vec);
     hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, s, rows, row_loss, nvalid, loss_out);
     return caphn_launch_status();
 }

@@ -279,12 +279,14 @@ int caphn_plain_backward(const caphn_plain_dims* d, const caphn_plain_params* p,
  * Loss: F.cross_entropy(logits.view(-1,V), caps.view(-1), ignore_index)   [hypernet_attention.py:183,
  * cc_train_hypernet.py:153].  Writes the mean loss to loss_out[0], the number of non-ignored
  * targets to loss_out[1], and d loss / d logits to dlogits (may alias logits).
+ * leave_ignored_rows = 1: d logits rows of ignored targets are left unwritten instead of zero-filled -- for callers
+ * whose backward only visits live rows (dims.row_subset); their logits rows may be uninitialised, too.
  * ws: caphn_ce_workspace_bytes(rows).
  */
 size_t caphn_ce_workspace_bytes(int rows);
 int caphn_cross_entropy_fwd_bwd(int rows, int V, const float* logits, const int64_t* targets,
                                 int64_t ignore_index, float* dlogits, float* loss_out,
-                                void* ws, caphn_stream_t stream);
+                                int leave_ignored_rows, void* ws, caphn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Embedding                                                     [decoderlstm.py:28,62]
