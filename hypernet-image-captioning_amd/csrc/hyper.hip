@@ -283,20 +283,31 @@ __global__ __launch_bounds__(1024) void gemv_t_reduce_kernel(ReduceJobs jobs) {
 // small matrices: y[c] = (sum_jobs sum_r W_j[r][c] d_j[r]) * lrelu'(post[c])
 struct SmallTJob { const float* W; const float* d; int rows; };
 struct SmallTArgs { SmallTJob j[CAPHN_MAX_HEADS]; int n; int k; const float* post; float* out0; float* out1; };
+// 1024 threads = 8 columns x 128 row lanes (was 64 x 16: with k = 200 that is four workgroups, each thread walking 70
+// rows one dependent load at a time -- 17-43 us for 0.9 MB, on the tail of the hypernet VJP branch)
+constexpr int STC = 8, STR = 128;
 __global__ __launch_bounds__(1024) void gemv_t_small_kernel(SmallTArgs a) {
-    __shared__ float red[RL][65];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    __shared__ float red[STR][STC + 1];
+    const int cl = threadIdx.x & (STC - 1), rl = threadIdx.x / STC;
+    const int c = blockIdx.x * STC + cl;
     float acc = 0.f;
     if (c < a.k)
         for (int i = 0; i < a.n; ++i) {
             const SmallTJob& J = a.j[i];
-            for (int r = rl; r < J.rows; r += RL) acc += J.W[(size_t)r * a.k + c] * J.d[r];
+            for (int r = rl; r < J.rows; r += STR) acc += J.W[(size_t)r * a.k + c] * J.d[r];
         }
-    float s = col_reduce_finish(acc, red);
-    if (rl == 0 && c < a.k) {
-        if (a.post) s *= lrelu_grad(a.post[c]);
-        if (a.out0) a.out0[c] = s;
-        if (a.out1) a.out1[c] = s;
+    red[rl][cl] = acc;
+    __syncthreads();
+    // 128 partial sums per column: one wave folds them (lane = row lane, two per lane), shuffle reduction per column
+    if (threadIdx.x < 64 * STC) {
+        const int col = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        float s = wave_sum(red[lane][col] + red[lane + 64][col]);
+        const int cc = blockIdx.x * STC + col;
+        if (lane == 0 && cc < a.k) {
+            if (a.post) s *= lrelu_grad(a.post[cc]);
+            if (a.out0) a.out0[cc] = s;
+            if (a.out1) a.out1[cc] = s;
+        }
     }
 }
 
@@ -468,17 +479,17 @@ extern "C" int caphn_hyper_backward(const caphn_hyper_desc* d, const float* dthe
     {   // dbase = sum_i W1_i^T dz_i ; dzb2 = dbase * lrelu'(base)
         SmallTArgs a; a.n = nh; a.k = d->he; a.post = acts + L.base; a.out0 = ws + W.dzb2; a.out1 = g->g_base_b2;
         for (int i = 0; i < nh; ++i) { a.j[i].W = d->w1[i]; a.j[i].d = ws + W.dz[i]; a.j[i].rows = d->k[i]; }
-        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + 63) / 64), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d->he + STC - 1) / STC), dim3(1024), 0, s, a);
     }
     {   // da0 = Wb2^T dzb2 ; dzb0 = da0 * lrelu'(a0)
         SmallTArgs a; a.n = 1; a.k = d_mid(d); a.post = acts + L.a0; a.out0 = ws + W.dzb0; a.out1 = g->g_base_b0;
         a.j[0].W = d->base_w2; a.j[0].d = ws + W.dzb2; a.j[0].rows = d->he;
-        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d_mid(d) + 63) / 64), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d_mid(d) + STC - 1) / STC), dim3(1024), 0, s, a);
     }
     if (g->g_x) {   // dx = Wb0^T dzb0
         SmallTArgs a; a.n = 1; a.k = d_in(d); a.post = nullptr; a.out0 = g->g_x; a.out1 = nullptr;
         a.j[0].W = d->base_w0; a.j[0].d = ws + W.dzb0; a.j[0].rows = d_mid(d);
-        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d_in(d) + 63) / 64), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d_in(d) + STC - 1) / STC), dim3(1024), 0, s, a);
     }
     {   // dense weight grads (rank-1 outer products)
         OuterJobs oj; oj.n = 0; long b0 = 0;
