@@ -101,16 +101,17 @@ inline Ws layout(const caphn_decoder_dims* d) {
     w.dXe = take(B * T * E); w.dWaf = take(B * P * H); w.dmeanf = take(raw ? 0 : B * F); w.df = take(raw ? 0 : B * P * F);
     w.dY1 = take(raw ? 0 : B * P * F);
     w.pchunk = 1; w.npc = (int)((P + w.pchunk - 1) / w.pchunk);     // one workgroup per (caption, position)
-    w.apart = take(B * w.npc * (H + 1)); w.vtmp = take(H + 1);
+    const size_t arows = std::max<size_t>(w.npc, (size_t)caphn_rec_bwd_groups((int)P, (int)H));   // per caption: positions, or thread groups when fused
+    w.apart = take(B * arows * (H + 1)); w.vtmp = take(H + 1);
     size_t cs = 0;
     auto need = [&](size_t M, size_t N) { cs = std::max(cs, caphn_colsum_workspace_bytes((int)M, (int)N) / sizeof(float)); };
     need(B * T, V); need(B * T, NG * H); need(B * T, H); need(B * P, H); need(B * P, F); need(B, H);
-    need(B * w.npc, H + 1);
+    need(B * arows, H + 1);
     w.colws = take(cs);
     {   // side-stream branches run their own (small) column sums concurrently
         size_t c2 = 0;
         auto need2 = [&](size_t M, size_t N) { c2 = std::max(c2, caphn_colsum_workspace_bytes((int)M, (int)N) / sizeof(float)); };
-        need2(B * T, NG * H); need2(B * T, H); need2(B * P, H); need2(B * P, F); need2(B, H); need2(B * w.npc, H + 1);
+        need2(B * T, NG * H); need2(B * T, H); need2(B * P, H); need2(B * P, F); need2(B, H); need2(B * arows, H + 1);
         for (int i = 0; i < 3; ++i) w.colws_s[i] = take(c2);
     }
     w.prof = take(64);        // 2 x 8 uint64 phase counters (forward, backward) of the recurrent kernels
@@ -428,6 +429,10 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     a.vecS = (H % 4 == 0) && caphn_aligned16(ws);
     a.prof = reinterpret_cast<unsigned long long*>(ws + w.prof) + 8;
     a.rotate = g_tune_rec_rotate;
+    // attention parameter gradients (dWaf, partial d v_a / d b_va) come out of the BPTT kernel itself when its thread
+    // map can carry them (it evaluates the same tanh for d(U_a h)): one ~50 us kernel less on the chain
+    const int ang = caphn_rec_bwd_groups(P, H);
+    if (ang > 0) { a.dWaf = ws + w.dWaf; a.apart = ws + w.apart; }
     RUN(caphn_launch_rec_bwd(a, lstm, s));
 
     // ---- after BPTT.  Only  attn_param_grads -> df -> dY1 -> dW_fc0  is a true chain (main stream); every other
@@ -454,7 +459,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     ag.T = T; ag.P = P; ag.H = H; ag.pchunk = w.pchunk;
     ag.Waf = ws + w.Waf; ag.uah = ws + w.uah; ag.de = ws + w.de; ag.v_a = p->va_w;
     ag.dWaf = ws + w.dWaf; ag.part = ws + w.apart;
-    RUN(caphn_launch_attn_param_grads(ag, B, w.npc, s));
+    if (ang == 0) RUN(caphn_launch_attn_param_grads(ag, B, w.npc, s));
     RUN(sd.record(2, s));
     // b2 -- input weights dW_ih[:, :E] = dgi^T Xe, dW_ih[:, E:] = dgi^T ctx; embedding gradient
     RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, b2));
@@ -498,7 +503,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     }
     // b2 (leaves of the chain) -- d v_a, d b_va, dW_a, db_Wa once dWaf exists; fc2 gradients once df exists
     RUN(sd.wait(2, b2));
-    RUN(caphn_colsum_f32(B * w.npc, H + 1, ws + w.apart, H + 1, ws + w.vtmp, cw2, b2));
+    RUN(caphn_colsum_f32(B * (ang > 0 ? ang : w.npc), H + 1, ws + w.apart, H + 1, ws + w.vtmp, cw2, b2));
     if (hipMemcpyAsync(g->va_w, ws + w.vtmp, sizeof(float) * H, hipMemcpyDeviceToDevice, b2) != hipSuccess) return CAPHN_ELAUNCH;
     if (hipMemcpyAsync(g->va_b, ws + w.vtmp + H, sizeof(float), hipMemcpyDeviceToDevice, b2) != hipSuccess) return CAPHN_ELAUNCH;
     RUN(wgrad_bias(H, F, BP, ws + w.dWaf, H, f, F, g->Wa_w, F, g->Wa_b, nullptr, cw2, b2, gz));

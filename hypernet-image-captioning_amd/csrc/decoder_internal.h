@@ -40,6 +40,9 @@ struct RecBwdArgs {
     float* dc0;             // [B,H] (LSTM)
     unsigned long long* prof;
     int vecW, vecS, rotate;
+    // attention parameter gradients accumulated across t inside the kernel (the tanh of the d(U_a h) phase is the same
+    // one): dWaf [B,P,H] and the d v_a / d b_va partials part [B*ng, H+1] (ng = caphn_rec_bwd_groups(H)); null = not fused
+    float* dWaf = nullptr; float* apart = nullptr;
 };
 struct AttnGradArgs {
     int T, P, H, pchunk;
@@ -53,6 +56,7 @@ size_t caphn_rec_bwd_lds_bytes(int P, int H, int NG, int RG);
 int caphn_rec_resident_gates(int P, int H, int NG);       // largest RG whose fwd and bwd kernels fit 160 KB; -1 if none
 int caphn_launch_rec_fwd(const RecFwdArgs& a, bool lstm, hipStream_t s);
 int caphn_launch_rec_bwd(const RecBwdArgs& a, bool lstm, hipStream_t s);
+int caphn_rec_bwd_groups(int P, int H);     // > 0: the backward kernel can fuse the attention parameter gradients (rows of `apart` per caption)
 int caphn_launch_attn_param_grads(const AttnGradArgs& a, int B, int npc, hipStream_t s);
 int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const float* f, float* ctx, hipStream_t s);
 int caphn_launch_df(int B, int T, int P, int F, const float* alphas, const float* dctx, const float* dmean, float* df, hipStream_t s);

@@ -20,7 +20,20 @@ namespace {
 
 constexpr int NT = 1024;
 // phase stamp (workgroup 0, thread 0): adds the shader clocks since the previous stamp to counter i
-#define PSTAMP(i) do { if (prof_on) { unsigned long long _n = clock64(); pc[i] += _n - plast; plast = _n; } } while (0)            // 16 waves per workgroup: one workgroup per CU (LDS-bound), 4 waves per SIMD
+// Per-phase shader-clock stamps of workgroup 0 (tools/rec_phase_profile.py): compile with -DCAPHN_REC_PROFILE.  Off by
+// default: the eight 64-bit counters live in VGPRs of every thread (16 registers in kernels that sit at the 128-VGPR cap
+// of a 1024-thread workgroup).
+#ifdef CAPHN_REC_PROFILE
+#define PSTAMP(i) do { if (prof_on) { unsigned long long _n = clock64(); pc[i] += _n - plast; plast = _n; } } while (0)
+#define PDECL const bool prof_on = (b == 0 && tid == 0 && a.prof != nullptr); \
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = prof_on ? clock64() : 0
+#define PFLUSH do { if (prof_on) for (int i = 0; i < 8; ++i) a.prof[i] = pc[i]; } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#define PDECL do { } while (0)
+#define PFLUSH do { } while (0)
+#endif
+//            // 16 waves per workgroup: one workgroup per CU (LDS-bound), 4 waves per SIMD
 
 __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n, int vec, int tid) {
     if (vec) {
@@ -60,6 +73,7 @@ __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const f
     }
 }
 
+constexpr int PGM = 10;     // positions per thread the BPTT kernel can carry attention-gradient accumulators for
 // thread -> (column k, group g) map used to split sums over p across thread groups
 struct KG { int k, g, ng; };
 __device__ __forceinline__ KG kg_map(int tid, int H) {
@@ -127,8 +141,7 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
             wreg[i][q] = (waf_regs && p < P && k < H) ? Waf_b[p * H + k] : 0.f;
         }
     __syncthreads();
-    const bool prof_on = (b == 0 && tid == 0 && a.prof != nullptr);
-    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = prof_on ? clock64() : 0;
+    PDECL;
 
     for (int t = 0; t < T; ++t) {
         const size_t bt = (size_t)b * T + t;
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
         __syncthreads();
         PSTAMP(4);
     }
-    if (prof_on) for (int i = 0; i < 8; ++i) a.prof[i] = pc[i];
+    PFLUSH;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -291,8 +304,13 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
     const int rotU = a.rotate ? (int)(((unsigned)b * 13u) % (unsigned)H) : 0;
     const int rotW = a.rotate ? (int)(((unsigned)b * 37u) % (unsigned)GH) : 0;
     __syncthreads();
-    const bool prof_on = (b == 0 && tid == 0 && a.prof != nullptr);
-    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = prof_on ? clock64() : 0;
+    PDECL;
+    // fused attention parameter gradients: this thread owns column m.k and positions m.g, m.g + ng, ... (<= PGM of them)
+    const bool fuse = a.dWaf != nullptr && m.g >= 0;
+    float dw[PGM];
+#pragma unroll
+    for (int i = 0; i < PGM; ++i) dw[i] = 0.f;
+    float dva = 0.f, dbva = 0.f;
 
     for (int t = T - 1; t >= 0; --t) {
         const size_t bt = (size_t)b * T + t;
@@ -359,7 +377,25 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
         __syncthreads();
         PSTAMP(2);
         // d(U_a h)[k] = v_k sum_p de_p (1 - tanh^2(Waf_pk + uah_k)); p split over thread groups
-        if (m.g >= 0) {
+        if (fuse) {
+            // same sum, with dWaf[p][k] += de_p (1 - tanh^2) and d v_a[k] += de_p tanh accumulated over t in registers
+            const int k = m.k;
+            const float u = uah_s[k];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < PGM; ++i) {
+                const int p = m.g + i * m.ng;
+                if (p < P) {
+                    const float de = dal_s[p];
+                    const float tv = caphn_tanh(Waf_b[p * H + k] + u);
+                    const float w = de * (1.0f - tv * tv);
+                    s += w; dw[i] += w; dva += de * tv;
+                    if (k == 0) dbva += de;
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one position at a time: ten interleaved tanh chains spill
+            }
+            part_s[m.g * H + k] = s;
+        } else if (m.g >= 0) {
             for (int k = m.k; k < H; k += (m.ng == 1 ? NT : H)) {
                 const float u = uah_s[k];
                 float s = 0.f;
@@ -410,10 +446,21 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
         __syncthreads();
         PSTAMP(6);
     }
-    if (prof_on) for (int i = 0; i < 8; ++i) a.prof[i] = pc[i];
+    PFLUSH;
     for (int k = tid; k < H; k += NT) {
         a.dh0[(size_t)b * H + k] = dh_s[k];
         if (LSTM) a.dc0[(size_t)b * H + k] = dc_s[k];
+    }
+    if (fuse) {
+        const float vk = va_s[m.k];
+#pragma unroll
+        for (int i = 0; i < PGM; ++i) {
+            const int p = m.g + i * m.ng;
+            if (p < P) a.dWaf[((size_t)b * P + p) * H + m.k] = dw[i] * vk;
+        }
+        float* row = a.apart + ((size_t)b * m.ng + m.g) * (H + 1);
+        row[m.k] = dva;
+        if (m.k == 0) row[H] = dbva;
     }
 }
 
@@ -527,7 +574,13 @@ int caphn_launch_rec_fwd(const RecFwdArgs& a, bool lstm, hipStream_t s) {
     else hipLaunchKernelGGL(rec_attn_fwd_kernel<false>, dim3(a.B), dim3(NT), lds, s, a);
     return caphn_launch_status();
 }
+int caphn_rec_bwd_groups(int P, int H) {
+    if (H > NT) return 0;
+    const int ng = NT / H;
+    return (P + ng - 1) / ng <= PGM ? ng : 0;
+}
 int caphn_launch_rec_bwd(const RecBwdArgs& a, bool lstm, hipStream_t s) {
+    if (a.dWaf && (!a.apart || caphn_rec_bwd_groups(a.P, a.H) == 0)) return CAPHN_EINVAL;
     const size_t lds = caphn_rec_bwd_lds_bytes(a.P, a.H, lstm ? 4 : 3, a.RG);
     if (lds > LDS_LIMIT) return CAPHN_ELIMIT;
     int rc = ensure_lds_attr(); if (rc) return rc;
