@@ -450,9 +450,8 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
         // The chain's own small inputs stay on the chain's stream: waiting on a side-stream event here stalled
         // the chain for ~275 us in the kernel trace although the producers had long finished.
         RUN(caphn_gemm_f32(0, 0, BT, F, GH, dgi, GH, p->w_ih + E, EF, ws + w.dctx, F, nullptr, nullptr, 0, 0, 1, s));
-        RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dh0, H, p->inith_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, 0, 1, s));
-        if (lstm)
-            RUN(caphn_gemm_f32(0, 0, B, F, H, ws + w.dc0, H, p->initc_w, F, ws + w.dmeanf, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
+        RUN(caphn_launch_dmean(B, H, F, ws + w.dh0, p->inith_w, lstm ? ws + w.dc0 : nullptr, lstm ? p->initc_w : nullptr,
+                               ws + w.dmeanf, s));
     }
     // main: attention parameter gradients (dWaf, partial d v_a)
     AttnGradArgs ag;

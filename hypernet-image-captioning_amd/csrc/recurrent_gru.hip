@@ -497,6 +497,23 @@ __global__ void attn_param_grads_kernel(AttnGradArgs a) {
     }
 }
 
+// dmean[b,k] = sum_j dh0[b,j] W_inith[j,k] (+ dc0 W_initc): the init_hidden backward.  As a 64x64-tile GEMM this M = B
+// product is eight workgroups of seven K-slabs each -- 15-60 us on the post-BPTT chain; one workgroup per caption does it
+// in a few microseconds.
+__global__ __launch_bounds__(256) void dmean_kernel(int H, int F, const float* __restrict__ dh0, const float* __restrict__ Wh,
+                                                    const float* __restrict__ dc0, const float* __restrict__ Wc, float* __restrict__ out) {
+    extern __shared__ float dv[];       // [2][H]
+    const int b = blockIdx.x;
+    for (int j = threadIdx.x; j < H; j += 256) { dv[j] = dh0[(size_t)b * H + j]; dv[H + j] = dc0 ? dc0[(size_t)b * H + j] : 0.f; }
+    __syncthreads();
+    for (int k = threadIdx.x; k < F; k += 256) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int j = 0; j < H; ++j) s0 += dv[j] * Wh[(size_t)j * F + k];
+        if (dc0) for (int j = 0; j < H; ++j) s1 += dv[H + j] * Wc[(size_t)j * F + k];
+        out[(size_t)b * F + k] = s0 + s1;
+    }
+}
+
 // ctx[b,t,k] = sum_p alpha[b,t,p] f[b,p,k]
 __global__ void ctx_kernel(int P, int F, int T, const float* __restrict__ alphas, const float* __restrict__ f, float* __restrict__ ctx) {
     const int b = blockIdx.x, t = blockIdx.y;
@@ -590,6 +607,10 @@ int caphn_launch_rec_bwd(const RecBwdArgs& a, bool lstm, hipStream_t s) {
 }
 int caphn_launch_attn_param_grads(const AttnGradArgs& a, int B, int npc, hipStream_t s) {
     hipLaunchKernelGGL(attn_param_grads_kernel, dim3(B, npc), dim3(a.H >= 192 ? 256 : 64), 0, s, a);
+    return caphn_launch_status();
+}
+int caphn_launch_dmean(int B, int H, int F, const float* dh0, const float* Wh, const float* dc0, const float* Wc, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(dmean_kernel, dim3(B), dim3(256), sizeof(float) * 2 * H, s, H, F, dh0, Wh, dc0, Wc, out);
     return caphn_launch_status();
 }
 int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const float* f, float* ctx, hipStream_t s) {
