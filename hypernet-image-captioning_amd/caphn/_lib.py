@@ -170,7 +170,9 @@ def check(rc, what):
 
 
 def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw hipStream_t of torch's current stream (the direct binding: ~0.3 us instead of ~8 us for
+    torch.cuda.current_stream().cuda_stream -- sixteen of them per training step)."""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def ptr(t, dtype=torch.float32, allow_none=False):

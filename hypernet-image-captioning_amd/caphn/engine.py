@@ -49,6 +49,8 @@ class FusedTrainer:
         d0 = self.cap.dec_dims(1, 1, 1)
         self._cell_names = d0.cell_names()
         self._dec_names = [n for n in d0.names() if n not in self._cell_names]
+        self._vcache = {}
+        self._invalidate_caches()
         self._build_arena()
         self._bufs: Dict[Tuple[int, int, int], dict] = {}
         nh = len(self.shape.heads)
@@ -128,10 +130,22 @@ class FusedTrainer:
         self.W2_v = [torch.zeros_like(w.data) for w in self.W2]
 
     def _view(self, flat, name):
-        o, n, shape = self.offs[name]
-        return flat[o:o + n].view(shape)
+        cache = self._vcache.setdefault(id(flat), {})
+        v = cache.get(name)
+        if v is None:
+            o, n, shape = self.offs[name]
+            v = cache[name] = flat[o:o + n].view(shape)
+        return v
+
+    def _invalidate_caches(self):
+        """The per-step dicts / ctypes structs are memoised (host time per step matters: a slow or contended host
+        starves the GPU); anything that moves a parameter's storage clears them."""
+        self._dt_cache = {}
+        self._hp_cache = None
+        self._hg_cache = None
 
     def _adopt(self, name, p):
+        self._invalidate_caches()
         v = self._view(self.flat_p, name)
         v.copy_(p.data)
         p.data = v
@@ -158,6 +172,7 @@ class FusedTrainer:
                 w.data = w.data.contiguous()
                 self.W2[i] = w
                 self._readopted = True
+                self._invalidate_caches()
 
     # ------------------------------------------------------------------ per-shape buffers
     def _buffers(self, B, T, P):
@@ -176,6 +191,10 @@ class FusedTrainer:
 
     def _dec_tensors(self, theta_flat, grads: bool):
         """decoder parameter (or gradient) dict; the GRU entries are slices of theta / dtheta."""
+        key = (theta_flat.data_ptr(), bool(grads))
+        hit = self._dt_cache.get(key)
+        if hit is not None:
+            return hit
         flat = self.flat_g if grads else self.flat_p
         d = {n: self._view(flat, "captioner." + n) for n in self._dec_names}
         shapes = self.cap.dec_dims(1, 1, 1).param_shapes()
@@ -187,7 +206,20 @@ class FusedTrainer:
             d[n] = theta_flat[o:o + k].view(shapes[n])
             o += k
         assert o == self.theta_size, "hypernet heads do not match the cell's parameter sizes"
+        d["__frozen__"] = True              # same dict object <-> same storage: ops memoise the ctypes struct in it
+        d["__theta__"] = theta_flat         # keeps the storage (and therefore the key) alive
+        self._dt_cache[key] = d
         return d
+
+    def _hyper_params(self):
+        hp = self._hp_cache
+        if hp is None:
+            hp = {n: self._owned[n].data for n in self.shape.param_names() if n in self._owned}
+            for i in range(self._nh):
+                hp[f"hn_heads.{i}.2.weight"] = self.W2[i].data
+            hp["__frozen__"] = True
+            self._hp_cache = hp
+        return hp
 
     # ------------------------------------------------------------------ the step
     def forward_backward(self, features, captions, x_style=None, style_token: Optional[int] = None,
@@ -202,9 +234,7 @@ class FusedTrainer:
         T = captions.shape[1]
         buf = self._buffers(B, T, P)
         dims = buf["dims"]
-        hp = {n: self._owned[n].data for n in self.shape.param_names() if n in self._owned}
-        for i in range(self._nh):
-            hp[f"hn_heads.{i}.2.weight"] = self.W2[i].data
+        hp = self._hyper_params()
         if style_token is not None:
             x = self._view(self.flat_p, "captioner.embed.weight")[style_token]
         else:
@@ -246,7 +276,10 @@ class FusedTrainer:
         buf["loss"].copy_(lib_loss)
         dtheta = self.flat_g[:self.theta_size]
         grads = self._dec_tensors(dtheta, grads=True)
-        hg = {n: self._view(self.flat_g, n) for n in self.offs if n.startswith("hn_")}
+        hg = self._hg_cache
+        if hg is None:
+            hg = self._hg_cache = {n: self._view(self.flat_g, n) for n in self.offs if n.startswith("hn_")}
+            hg["__frozen__"] = True
         if self._hyper_ws is None:
             import ctypes as C
             from . import _lib as L
@@ -314,9 +347,7 @@ class FusedTrainer:
         if prefetch:
             # the small layers (and the style row of the embedding) are already updated: compute the next
             # step's head activations, then let the rank-1 Adam pass emit theta_next = W2' a' + b2' row by row
-            hp = {n: self._owned[n].data for n in self.shape.param_names() if n in self._owned}
-            for i in range(self._nh):
-                hp[f"hn_heads.{i}.2.weight"] = self.W2[i].data
+            hp = self._hyper_params()
             if next_style_token is not None:
                 xn = self._view(self.flat_p, "captioner.embed.weight")[int(next_style_token)]
                 self._next_key = ("tok", int(next_style_token))
