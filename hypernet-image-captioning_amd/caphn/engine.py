@@ -255,18 +255,25 @@ class FusedTrainer:
         params = self._dec_tensors(theta, grads=False)
         fdims = dims
         rows_done = False
+        pre = 0
         if self._pre_key is not None:
             kf, kc, kB, kT, kP, level = self._pre_key
-            torch.cuda.current_stream().wait_event(self._pre_done)      # even if the announced batch did not come
             if (kf, kB, kT, kP) == (features.data_ptr(), B, T, P) and not self._readopted:
-                if level == 2 and kc == captions.data_ptr() and theta is self._theta_pre:
-                    import dataclasses
-                    fdims = dataclasses.replace(dims, pre=2)
-                    rows_done = True
-                else:
-                    import dataclasses
-                    fdims = dataclasses.replace(dims, pre=1)
+                pre = 7 if (level == 2 and kc == captions.data_ptr() and theta is self._theta_pre) else 1
             self._pre_key = None
+            if pre == 1 and validate is False:
+                # what does not depend on the side stream's work goes first, so it hides behind the wait
+                if dims.rows:
+                    ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
+                    rows_done = True
+                ops.decoder_inputs(dims, params, captions, buf["ws"])
+                pre = 5
+            torch.cuda.current_stream().wait_event(self._pre_done)      # even if the announced batch did not come
+            if pre == 7:
+                rows_done = True
+            if pre:
+                import dataclasses
+                fdims = dataclasses.replace(dims, pre=pre)
         if dims.rows and not rows_done:
             ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
         ops.decoder_forward(fdims, params, features, captions, buf["ws"], logits=buf["logits"], alphas=buf["alphas"],

@@ -199,7 +199,7 @@ class DecDims:
     cell: str = "gru"        # "gru" (AttentionGru) or "lstm" (AttentionLstm)
     raw: bool = False        # True: no feature_fc, attention over the raw D-channel features (F == D)
     rows: bool = False       # True: vocab GEMMs only touch rows with a live target (decoder_prepare_rows first)
-    pre: int = 0             # 1: decoder_precompute already ran on the workspace for these features; 2: with captions
+    pre: int = 0             # bit mask (see caphn_decoder_dims.precomputed): 1 precompute, 2 G, 4 inputs
     gz: bool = False         # True: the caller zero-filled every gradient output (one zero_ over its arena)
 
     @property
@@ -280,7 +280,7 @@ def decoder_precompute(dims: DecDims, params: Dict[str, torch.Tensor], features:
                        captions: Optional[torch.Tensor] = None) -> None:
     """feature_fc, init_hidden and W_a f of the forward for `features` (models/decoderlstm.py:61-63, attention.py:34),
     issued ahead of the forward on the current stream; follow with decoder_forward(dims with pre=1).  With captions
-    (and the final generated cell weights in params) also G, the embedding lookup and the x-side gates (pre=2)."""
+    (and the final generated cell weights in params) also G, the embedding lookup and the x-side gates (pre=7)."""
     lib = L.load()
     if tuple(features.shape) != (dims.B, dims.P, dims.D):
         raise L.CaphnError(f"features {tuple(features.shape)} do not match {dims}")
@@ -291,6 +291,18 @@ def decoder_precompute(dims: DecDims, params: Dict[str, torch.Tensor], features:
     L.check(lib.caphn_decoder_precompute(C.byref(cd), C.byref(ps), L.ptr(features),
                                          L.ptr(captions, torch.int64, allow_none=True), C.c_void_p(ws.data_ptr()),
                                          L.stream_ptr()), "caphn_decoder_precompute")
+
+
+def decoder_inputs(dims: DecDims, params: Dict[str, torch.Tensor], captions: torch.Tensor, ws: torch.Tensor) -> None:
+    """Embedding lookup + x-side gate pre-activations of the forward (decoderlstm.py:62, :82-88, :100) ahead of the
+    rest; follow with decoder_forward(dims with pre | 4)."""
+    lib = L.load()
+    if tuple(captions.shape) != (dims.B, dims.T):
+        raise L.CaphnError(f"captions {tuple(captions.shape)} do not match {dims}")
+    cd = dims.c()
+    ps = _dec_struct(L.DecoderParams, dims, params)
+    L.check(lib.caphn_decoder_inputs(C.byref(cd), C.byref(ps), L.ptr(captions, torch.int64), C.c_void_p(ws.data_ptr()),
+                                     L.stream_ptr()), "caphn_decoder_inputs")
 
 
 def decoder_forward(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,

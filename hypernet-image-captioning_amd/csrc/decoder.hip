@@ -227,10 +227,8 @@ static int decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_p
     if (parts & 1) {
         RUN(sd.forkto(0)); RUN(sd.forkto(1));
         // branch 0 -- init_hidden: mean over positions -> Linear(F,H) (and init_c for the LSTM)      :122-135 / :255-260
-        RUN(caphn_launch_mean_p(B, P, F, f, ws + w.meanf, sd.s(0)));
-        RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->inith_w, F, ws + w.h0, H, p->inith_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, sd.s(0)));
-        if (lstm)
-            RUN(caphn_gemm_f32(0, 1, B, H, F, ws + w.meanf, F, p->initc_w, F, ws + w.c0, H, p->initc_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, sd.s(0)));
+        RUN(caphn_launch_init_state(B, P, F, H, f, p->inith_w, p->inith_b, lstm ? p->initc_w : nullptr, lstm ? p->initc_b : nullptr,
+                                    ws + w.meanf, ws + w.h0, lstm ? ws + w.c0 : nullptr, sd.s(0)));
         // branch 1 -- t-invariant attention projection W_a f + b      attention.py:34
         RUN(caphn_gemm_f32(0, 1, BP, H, F, f, F, p->Wa_w, F, ws + w.Waf, H, p->Wa_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, sd.s(1)));
     }
@@ -310,6 +308,14 @@ extern "C" int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn
     return caphn_launch_status();
 }
 
+extern "C" int caphn_decoder_inputs(const caphn_decoder_dims* d, const caphn_decoder_params* p, const int64_t* captions,
+                                    void* ws_, caphn_stream_t stream) {
+    if (!dims_ok(d) || !p || !captions || !ws_ || !p->embed_w || !p->w_ih || !p->b_ih) return CAPHN_EINVAL;
+    const Ws w = layout(d);
+    RUN(decoder_inputs(d, p, w, static_cast<float*>(ws_), captions, static_cast<hipStream_t>(stream)));
+    return caphn_launch_status();
+}
+
 extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_decoder_params* p,
                                      const float* features, const int64_t* captions,
                                      float* logits, float* alphas, void* ws_, caphn_stream_t stream) {
@@ -326,9 +332,10 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     if (!raw && (!p->fc0_w || !p->fc0_b || !p->fc2_w || !p->fc2_b)) return CAPHN_EINVAL;
 
     const float* f = nullptr;
-    // precomputed: 0 nothing, 1 the theta-independent part, 2 everything in front of the recurrent kernel
-    RUN(decoder_precompute(d, p, w, ws, features, &f, s, d->precomputed >= 2 ? 0 : (d->precomputed ? 2 : 3)));
-    if (d->precomputed < 2) RUN(decoder_inputs(d, p, w, ws, captions, s));
+    // precomputed bits: 1 the theta-independent part, 2 G, 4 the x side (embedding lookup + gate pre-activations)
+    const int pc = d->precomputed;
+    if (!(pc & 4)) RUN(decoder_inputs(d, p, w, ws, captions, s));
+    RUN(decoder_precompute(d, p, w, ws, features, &f, s, ((pc & 1) ? 0 : 1) | ((pc & 2) ? 0 : 2)));
 
     RecFwdArgs a;
     a.B = B; a.T = T; a.P = P; a.H = H; a.RG = RG;

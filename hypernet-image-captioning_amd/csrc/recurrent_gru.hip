@@ -535,6 +535,46 @@ __global__ void df_kernel(int P, int F, int T, const float* __restrict__ alphas,
         df[((size_t)b * P + p) * F + k] = s;
     }
 }
+// init_hidden (and init_c) in one launch per caption: mean over the P positions (4 position lanes per column, LDS
+// reduction), then h0 = W_h mean + b_h (c0 likewise), one wave per output row.  Replaces mean_p_kernel + one or two
+// M = B GEMMs of eight workgroups each (16 + 12 us on the front of the forward).
+__global__ __launch_bounds__(1024) void init_state_kernel(int P, int F, int H, const float* __restrict__ f,
+                                                          const float* __restrict__ Wh, const float* __restrict__ bh,
+                                                          const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                          float* __restrict__ meanf, float* __restrict__ h0, float* __restrict__ c0) {
+    extern __shared__ float sm[];           // [4][Fp] partial sums, then mean in sm[0..F)
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Fp = (F + 255) & ~255;
+    for (int k0 = 0; k0 < F; k0 += 256) {
+        const int k = k0 + (tid & 255), pl = tid >> 8;
+        float s = 0.f;
+        if (k < F) for (int p = pl; p < P; p += 4) s += f[((size_t)b * P + p) * F + k];
+        sm[pl * Fp + k0 + (tid & 255)] = s;
+    }
+    __syncthreads();
+    const float invP = 1.0f / (float)P;
+    for (int k = tid; k < F; k += 1024) {
+        const float m = ((sm[k] + sm[Fp + k]) + (sm[2 * Fp + k] + sm[3 * Fp + k])) * invP;
+        sm[4 * Fp + k] = m;
+        meanf[(size_t)b * F + k] = m;
+    }
+    __syncthreads();
+    const float* mean = sm + 4 * Fp;
+    for (int j = wave; j < H; j += 16) {
+        float sh = 0.f, sc = 0.f;
+        for (int k = lane; k < F; k += 64) {
+            const float m = mean[k];
+            sh += Wh[(size_t)j * F + k] * m;
+            if (Wc) sc += Wc[(size_t)j * F + k] * m;
+        }
+        sh = wave_sum(sh);
+        if (Wc) sc = wave_sum(sc);
+        if (lane == 0) {
+            h0[(size_t)b * H + j] = sh + bh[j];
+            if (Wc) c0[(size_t)b * H + j] = sc + bc[j];
+        }
+    }
+}
 // mean over positions
 __global__ void mean_p_kernel(int P, int F, const float* __restrict__ f, float* __restrict__ out) {
     const int b = blockIdx.x;
@@ -619,6 +659,12 @@ int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const floa
 }
 int caphn_launch_df(int B, int T, int P, int F, const float* alphas, const float* dctx, const float* dmean, float* df, hipStream_t s) {
     hipLaunchKernelGGL(df_kernel, dim3(B, P), dim3(F >= 192 ? 256 : 64), 0, s, P, F, T, alphas, dctx, dmean, df);
+    return caphn_launch_status();
+}
+int caphn_launch_init_state(int B, int P, int F, int H, const float* f, const float* Wh, const float* bh, const float* Wc,
+                            const float* bc, float* meanf, float* h0, float* c0, hipStream_t s) {
+    const int Fp = (F + 255) & ~255;
+    hipLaunchKernelGGL(init_state_kernel, dim3(B), dim3(1024), sizeof(float) * (4 * Fp + F), s, P, F, H, f, Wh, bh, Wc, bc, meanf, h0, c0);
     return caphn_launch_status();
 }
 int caphn_launch_mean_p(int B, int P, int F, const float* f, float* out, hipStream_t s) {

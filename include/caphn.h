@@ -137,10 +137,11 @@ typedef struct caphn_decoder_dims {
     int grads_zeroed;   /* 1: every gradient output of caphn_decoder_backward is already zero on entry (a trainer that keeps all
                            gradients in one arena clears it with one caphn_zero_f32): the composite then skips its ~16
                            per-tensor zero fills (split-K / atomic accumulation targets) */
-    int precomputed;    /* 1: caphn_decoder_precompute has already filled this workspace for these features with the
-                           current feature_fc / attention.W_a / init_h parameters; caphn_decoder_forward skips that part.
-                           2: it was also given the captions (and the final generated W_ih / b_ih): the forward starts
-                           at the recurrent kernel */
+    int precomputed;    /* bit mask of what already sits in this workspace for this minibatch, so caphn_decoder_forward
+                           skips it: 1 = feature_fc / init_hidden / W_a f (caphn_decoder_precompute), 2 = G (the same call
+                           given captions, i.e. after the generated W_ih is final), 4 = embedding lookup + x-side gate
+                           pre-activations (caphn_decoder_inputs, or that same call).  7: the forward starts at the
+                           recurrent kernel */
 } caphn_decoder_dims;
 
 typedef struct caphn_decoder_params {   /* reference state_dict names in comments */
@@ -182,6 +183,11 @@ int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_decoder_param
  * the generated W_ih / b_ih of THAT forward (dims.precomputed = 2). */
 int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_params* p, const float* features,
                              const int64_t* captions /* optional, see dims.precomputed */, void* ws, caphn_stream_t stream);
+/* Embedding lookup (with the reference's zeroed first two inputs) and x-side gate pre-activations for all T; needs the
+ * captions and the generated W_ih / b_ih but not the features: a trainer waiting for a side-stream precompute can issue
+ * it first (dims.precomputed |= 4). */
+int caphn_decoder_inputs(const caphn_decoder_dims* d, const caphn_decoder_params* p, const int64_t* captions, void* ws,
+                         caphn_stream_t stream);
 /* Compacts the (b,t) rows whose target differs from ignore_index into a row map kept in the workspace (count stays on
  * the device: no host synchronisation).  Call before caphn_decoder_forward / _backward with dims.row_subset = 1. */
 int caphn_decoder_prepare_rows(const caphn_decoder_dims* d, const int64_t* targets, int64_t ignore_index,
