@@ -61,7 +61,7 @@ class FusedTrainer:
         self._acts = torch.zeros(self._acts_layout["_total"][1], dtype=torch.float32, device=dev)
         self._hyper_ws = None
         self._readopted = False
-        self._tok = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._toks = {}      # style token id -> device index tensor
         self._nh = nh
         # step-dependent Adam scalars live in device memory so a captured hipGraph replays for any step
         self._adam_dev = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -276,7 +276,7 @@ class FusedTrainer:
                 fdims = dataclasses.replace(dims, pre=pre)
         if dims.rows and not rows_done:
             ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
-        ops.decoder_forward(fdims, params, features, captions, buf["ws"], logits=buf["logits"], alphas=buf["alphas"],
+        ops.decoder_forward(fdims, params, features, captions, buf["ws"], logits=buf["logits"], want_alphas=False,
                             validate=validate)
         lib_loss, dlogits = ops.cross_entropy_fwd_bwd(buf["logits"], captions, 0, dlogits=buf["logits"],
                                                       leave_ignored_rows=dims.rows)
@@ -304,8 +304,10 @@ class FusedTrainer:
         if style_token is not None:
             # Flickr path: the style row of the embedding also feeds the hypernet -- add its VJP to the
             # embedding gradient before that gradient is reduced
-            self._tok.fill_(int(style_token))
-            ops.embedding_scatter_add(gx.view(1, -1), self._tok, self._view(self.flat_g, "captioner.embed.weight"))
+            tok = self._toks.get(int(style_token))
+            if tok is None:
+                tok = self._toks[int(style_token)] = torch.full((1,), int(style_token), dtype=torch.int64, device=self.dev)
+            ops.embedding_scatter_add(gx.view(1, -1), tok, self._view(self.flat_g, "captioner.embed.weight"))
             work = dp.all_reduce_dense(self.flat_g[self._hyper_small_end:], self.group, async_op=True)
         self._pending = work
         return buf["loss"]
@@ -426,11 +428,12 @@ class FusedTrainer:
         """next_features (+ next_captions, or next_T when only the length is known; default: this T): the NEXT
         minibatch when the loader is one batch ahead -- the front of its forward then overlaps this step's optimiser
         (the next call must pass those same tensors; captions as int64)."""
+        self._begin_step()          # the Adam scalars' H2D copy goes in front of the forward, off the optimiser's tail
         loss = self.forward_backward(features, captions, x_style, style_token)
         if next_captions is not None:
             next_T = next_captions.shape[1]
         nb = None if next_features is None else (next_features, next_captions, captions.shape[1] if next_T is None else next_T)
-        self.optimizer_step(next_x_style, next_style_token, nb)
+        self._optimizer_impl(next_x_style, next_style_token, nb)
         return loss
 
     def step_graphed(self, features, captions, x_style=None, style_token=None):

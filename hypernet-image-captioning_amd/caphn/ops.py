@@ -307,7 +307,7 @@ def decoder_inputs(dims: DecDims, params: Dict[str, torch.Tensor], captions: tor
 
 def decoder_forward(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,
                     ws: torch.Tensor, logits: Optional[torch.Tensor] = None, alphas: Optional[torch.Tensor] = None,
-                    validate: bool = True):
+                    validate: bool = True, want_alphas: bool = True):
     """AttentionGru.forward(features, captions, 0.0) (models/decoderlstm.py:49-120) or, with
     dims.cell == "lstm", AttentionLstm.forward(captions, features, 0.0) (:224-261).
     validate=True range-checks the token ids (one host sync); the fused engine checks its batches once."""
@@ -321,10 +321,10 @@ def decoder_forward(dims: DecDims, params: Dict[str, torch.Tensor], features: to
     dev = features.device
     if logits is None:
         logits = _f32(dims.B, dims.T, dims.V, device=dev)
-    if alphas is None:
+    if alphas is None and want_alphas:          # want_alphas=False: the attention maps stay in the workspace (no copy out)
         alphas = _f32(dims.B, dims.T, dims.P, device=dev)
     L.check(lib.caphn_decoder_forward(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64),
-                                      L.ptr(logits), L.ptr(alphas), C.c_void_p(ws.data_ptr()), L.stream_ptr()),
+                                      L.ptr(logits), L.ptr(alphas, allow_none=True), C.c_void_p(ws.data_ptr()), L.stream_ptr()),
             "caphn_decoder_forward")
     return logits, alphas
 
