@@ -76,6 +76,8 @@ class FusedTrainer:
         self._pre_stream = torch.cuda.Stream(device=dev)
         self._pre_key = None
         self._theta_pre = None
+        self._loss_done = torch.cuda.Event()
+        self._loss_pending = False
         self._pre_done = torch.cuda.Event()
         self.overlap_after_head = 0      # the side stream forks after this head's Adam pass (-1: before the first)
         self.overlap_level = 1           # 2: also G / embedding / x-side gates once the next W_ih exists (measured: no gain,
@@ -185,7 +187,9 @@ class FusedTrainer:
             b = {"dims": dims, "ws": ops.decoder_workspace(dims, self.dev),
                  "logits": torch.empty(B, T, dims.V, dtype=torch.float32, device=self.dev),
                  "alphas": torch.empty(B, T, P, dtype=torch.float32, device=self.dev),
-                 "loss": torch.zeros(2, dtype=torch.float32, device=self.dev)}
+                 "loss": torch.zeros(2, dtype=torch.float32, device=self.dev),
+                 "ce_ws": ops.ce_workspace(B * T, self.dev)}
+            b["cnt_ptr"] = ops.decoder_rowcount_ptr(dims, b["ws"]) if dims.rows else None
             self._bufs[key] = b
         return b
 
@@ -278,9 +282,20 @@ class FusedTrainer:
             ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
         ops.decoder_forward(fdims, params, features, captions, buf["ws"], logits=buf["logits"], want_alphas=False,
                             validate=validate)
-        lib_loss, dlogits = ops.cross_entropy_fwd_bwd(buf["logits"], captions, 0, dlogits=buf["logits"],
-                                                      leave_ignored_rows=dims.rows)
-        buf["loss"].copy_(lib_loss)
+        # loss: d logits now; the reduction of the per-row losses to the reported scalar runs on the side stream (nothing
+        # on the device waits for it; step() joins it at the end)
+        cnt = buf["cnt_ptr"] if dims.rows else None
+        ops.cross_entropy_rows(buf["logits"], captions, 0, buf["logits"], buf["ce_ws"], leave_ignored_rows=dims.rows,
+                               n_valid_ptr=cnt)
+        dlogits = buf["logits"]
+        if torch.cuda.is_current_stream_capturing():
+            ops.cross_entropy_finish(B * T, buf["ce_ws"], buf["loss"], cnt)
+        else:
+            self._pre_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._pre_stream):
+                ops.cross_entropy_finish(B * T, buf["ce_ws"], buf["loss"], cnt)
+                self._loss_done.record(self._pre_stream)
+            self._loss_pending = True
         dtheta = self.flat_g[:self.theta_size]
         grads = self._dec_tensors(dtheta, grads=True)
         hg = self._hg_cache
@@ -310,6 +325,9 @@ class FusedTrainer:
             ops.embedding_scatter_add(gx.view(1, -1), tok, self._view(self.flat_g, "captioner.embed.weight"))
             work = dp.all_reduce_dense(self.flat_g[self._hyper_small_end:], self.group, async_op=True)
         self._pending = work
+        if self._loss_pending:       # whoever reads the returned loss on the current stream sees the finished value
+            torch.cuda.current_stream().wait_event(self._loss_done)
+            self._loss_pending = False
         return buf["loss"]
 
     def _exchange(self):

@@ -446,6 +446,34 @@ def cross_entropy_fwd_bwd(logits: torch.Tensor, targets: torch.Tensor, ignore_in
     return out, dlogits
 
 
+def cross_entropy_rows(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int, dlogits: torch.Tensor,
+                       ws: torch.Tensor, leave_ignored_rows: bool = False, n_valid_ptr: Optional[int] = None) -> None:
+    """Stage 1 of the loss: d logits (may alias logits) and per-row losses into ws; cross_entropy_finish reduces them."""
+    lib = L.load()
+    V = logits.shape[-1]
+    rows = logits.numel() // V
+    L.check(lib.caphn_cross_entropy_rows(rows, V, L.ptr(logits), L.ptr(targets.reshape(-1), torch.int64), ignore_index,
+                                         L.ptr(dlogits), int(leave_ignored_rows),
+                                         C.c_void_p(n_valid_ptr) if n_valid_ptr else None, C.c_void_p(ws.data_ptr()),
+                                         L.stream_ptr()), "caphn_cross_entropy_rows")
+
+
+def cross_entropy_finish(rows: int, ws: torch.Tensor, out: torch.Tensor, n_valid_ptr: Optional[int] = None) -> None:
+    lib = L.load()
+    L.check(lib.caphn_cross_entropy_finish(rows, C.c_void_p(n_valid_ptr) if n_valid_ptr else None, L.ptr(out),
+                                           C.c_void_p(ws.data_ptr()), L.stream_ptr()), "caphn_cross_entropy_finish")
+
+
+def ce_workspace(rows: int, device) -> torch.Tensor:
+    return torch.empty(L.load().caphn_ce_workspace_bytes(rows), dtype=torch.uint8, device=device)
+
+
+def decoder_rowcount_ptr(dims: DecDims, ws: torch.Tensor) -> int:
+    """Device address (int) of the live-row count decoder_prepare_rows leaves in the workspace."""
+    cd = dims.c()
+    return int(L.load().caphn_decoder_rowcount_ptr(C.byref(cd), C.c_void_p(ws.data_ptr())) or 0)
+
+
 # ------------------------------------------------------------------ embedding
 def embedding_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     lib = L.load()

@@ -272,6 +272,11 @@ extern "C" size_t caphn_decoder_workspace_bytes(const caphn_decoder_dims* d) {
     return layout(d).total * sizeof(float);
 }
 
+extern "C" const int* caphn_decoder_rowcount_ptr(const caphn_decoder_dims* d, void* ws_) {
+    if (!dims_ok(d) || !ws_) return nullptr;
+    return reinterpret_cast<const int*>(static_cast<float*>(ws_) + layout(d).rowmap);
+}
+
 extern "C" int caphn_decoder_prepare_rows(const caphn_decoder_dims* d, const int64_t* targets, int64_t ignore_index,
                                           void* ws_, caphn_stream_t stream) {
     if (!dims_ok(d) || !targets || !ws_) return CAPHN_EINVAL;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void ce_count_kernel(int rows, const int64_t* 
 }
 
 __global__ __launch_bounds__(256) void ce_row_kernel(int V, const float* logits, const int64_t* __restrict__ tgt,
-                                                     int64_t ignore, const float* __restrict__ nvalid,
+                                                     int64_t ignore, const float* __restrict__ nvalid, const int* __restrict__ nvi,
                                                      float* dlogits, float* __restrict__ row_loss, int vec) {
     __shared__ float red[4];
     __shared__ float bc[2];
@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void ce_row_kernel(int V, const float* logits,
         if (tid == 0) row_loss[row] = 0.f;
         return;
     }
-    const float xt = x[t];                   // read before anybody overwrites (dlogits may alias logits)
+    __shared__ float xt_s;                   // read before anybody overwrites (dlogits may alias logits): see ce_row_reg_kernel
+    if (tid == 0) xt_s = x[t];
     float m = -INFINITY;
     if (vec) { const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
         for (int i = tid; i < (V >> 2); i += 256) { f32x4 v = x4[i]; m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3])); } }
@@ -58,14 +59,14 @@ __global__ __launch_bounds__(256) void ce_row_kernel(int V, const float* logits,
     if (tid == 0) bc[1] = red[0] + red[1] + red[2] + red[3];
     __syncthreads();
     s = bc[1];
-    const float inv = 1.0f / s, scale = 1.0f / nvalid[0];
+    const float inv = 1.0f / s, scale = 1.0f / (nvi ? (float)nvi[0] : nvalid[0]);
     if (vec) { const f32x4* x4 = reinterpret_cast<const f32x4*>(x); f32x4* d4 = reinterpret_cast<f32x4*>(dx);
         for (int i = tid; i < (V >> 2); i += 256) { f32x4 v = x4[i], o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (caphn_exp(v[e] - m) * inv - ((int64_t)(4 * i + e) == t ? 1.f : 0.f)) * scale;
             d4[i] = o; } }
     else for (int i = tid; i < V; i += 256) dx[i] = (caphn_exp(x[i] - m) * inv - ((int64_t)i == t ? 1.f : 0.f)) * scale;
-    if (tid == 0) row_loss[row] = (logf(s) + m - xt);
+    if (tid == 0) row_loss[row] = (logf(s) + m - xt_s);
 }
 
 // One-pass variant for V % 4 == 0, V <= 4 * 256 * NV: the row lives in registers (NV dwordx4 per thread), so it is read
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(int V, const float* logits,
 // evaluates 2 V exponentials).  skip_ignored: with the live-row map nobody reads the d logits rows of ignored targets.
 template <int NV>
 __global__ __launch_bounds__(256) void ce_row_reg_kernel(int V, const float* logits, const int64_t* __restrict__ tgt,
-                                                         int64_t ignore, const float* __restrict__ nvalid,
+                                                         int64_t ignore, const float* __restrict__ nvalid, const int* __restrict__ nvi,
                                                          float* dlogits, float* __restrict__ row_loss, int skip_ignored) {
     __shared__ float red[4];
     __shared__ float bc[2];
@@ -86,7 +87,11 @@ __global__ __launch_bounds__(256) void ce_row_reg_kernel(int V, const float* log
         if (tid == 0) row_loss[row] = 0.f;
         return;
     }
-    const float xt = logits[(size_t)row * V + t];
+    // d logits may alias logits: the target's logit must be IN HAND before any thread of this row writes.  Parking it in
+    // LDS in front of the first barrier forces the load to complete there; as a plain register value the compiler may
+    // delay the load to its use after the row has been overwritten by other waves (seen: the reported loss off by 0.2 / n)
+    __shared__ float xt_s;
+    if (tid == 0) xt_s = logits[(size_t)row * V + t];
     f32x4 v[NV];
     float m = -INFINITY;
 #pragma unroll
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256) void ce_row_reg_kernel(int V, const float* log
     if (tid == 0) bc[1] = red[0] + red[1] + red[2] + red[3];
     __syncthreads();
     s = bc[1];
-    const float inv = 1.0f / s, scale = 1.0f / nvalid[0];
+    const float inv = 1.0f / s, scale = 1.0f / (nvi ? (float)nvi[0] : nvalid[0]);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int i = tid + 256 * j;
@@ -126,17 +131,21 @@ __global__ __launch_bounds__(256) void ce_row_reg_kernel(int V, const float* log
             d4[i] = o;
         }
     }
-    if (tid == 0) row_loss[row] = (logf(s) + m - xt);
+    if (tid == 0) row_loss[row] = (logf(s) + m - xt_s);
 }
 
-__global__ __launch_bounds__(256) void ce_finish_kernel(int rows, const float* __restrict__ row_loss, const float* nvalid, float* out) {
+__global__ __launch_bounds__(256) void ce_finish_kernel(int rows, const float* __restrict__ row_loss, const float* nvalid,
+                                                        const int* __restrict__ nvi, float* out) {
     __shared__ double red[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < rows; i += 256) s += (double)row_loss[i];
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) { out[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)nvalid[0]); out[1] = nvalid[0]; }
+    if (threadIdx.x == 0) {
+        const float n = nvi ? (float)nvi[0] : nvalid[0];
+        out[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)n); out[1] = n;
+    }
 }
 
 // ------------------------------------------------------------------ zero fill
@@ -450,22 +459,35 @@ inline AdamK make_adam(const caphn_adam_hparams* hp) {
 
 extern "C" size_t caphn_ce_workspace_bytes(int rows) { return sizeof(float) * (size_t)(rows + 4); }
 
-extern "C" int caphn_cross_entropy_fwd_bwd(int rows, int V, const float* logits, const int64_t* targets,
-                                           int64_t ignore_index, float* dlogits, float* loss_out,
-                                           int leave_ignored_rows, void* ws, caphn_stream_t stream) {
-    if (rows <= 0 || V <= 0 || !logits || !targets || !dlogits || !loss_out || !ws) return CAPHN_EINVAL;
+extern "C" int caphn_cross_entropy_rows(int rows, int V, const float* logits, const int64_t* targets, int64_t ignore_index,
+                                        float* dlogits, int leave_ignored_rows, const int* n_valid_dev, void* ws,
+                                        caphn_stream_t stream) {
+    if (rows <= 0 || V <= 0 || !logits || !targets || !dlogits || !ws) return CAPHN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* nvalid = static_cast<float*>(ws);
     float* row_loss = nvalid + 4;
     const int vec = (V % 4 == 0) && caphn_aligned16(logits) && caphn_aligned16(dlogits);
-    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, rows, targets, ignore_index, nvalid);
+    if (!n_valid_dev) hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, rows, targets, ignore_index, nvalid);
     const int nv = vec ? (V / 4 + 255) / 256 : 0;
-    if (nv >= 1 && nv <= 4) hipLaunchKernelGGL(ce_row_reg_kernel<4>, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, dlogits, row_loss, leave_ignored_rows);
-    else if (nv > 4 && nv <= 10) hipLaunchKernelGGL(ce_row_reg_kernel<10>, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, dlogits, row_loss, leave_ignored_rows);
-    else if (nv > 10 && nv <= 16) hipLaunchKernelGGL(ce_row_reg_kernel<16>, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, dlogits, row_loss, leave_ignored_rows);
-    else hipLaunchKernelGGL(ce_row_kernel, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, dlogits, row_loss, vec);
-    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, s, rows, row_loss, nvalid, loss_out);
+    if (nv >= 1 && nv <= 4) hipLaunchKernelGGL(ce_row_reg_kernel<4>, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, n_valid_dev, dlogits, row_loss, leave_ignored_rows);
+    else if (nv > 4 && nv <= 10) hipLaunchKernelGGL(ce_row_reg_kernel<10>, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, n_valid_dev, dlogits, row_loss, leave_ignored_rows);
+    else if (nv > 10 && nv <= 16) hipLaunchKernelGGL(ce_row_reg_kernel<16>, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, n_valid_dev, dlogits, row_loss, leave_ignored_rows);
+    else hipLaunchKernelGGL(ce_row_kernel, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, n_valid_dev, dlogits, row_loss, vec);
     return caphn_launch_status();
+}
+extern "C" int caphn_cross_entropy_finish(int rows, const int* n_valid_dev, float* loss_out, void* ws, caphn_stream_t stream) {
+    if (rows <= 0 || !loss_out || !ws) return CAPHN_EINVAL;
+    float* nvalid = static_cast<float*>(ws);
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), rows, nvalid + 4, nvalid, n_valid_dev, loss_out);
+    return caphn_launch_status();
+}
+extern "C" int caphn_cross_entropy_fwd_bwd(int rows, int V, const float* logits, const int64_t* targets,
+                                           int64_t ignore_index, float* dlogits, float* loss_out,
+                                           int leave_ignored_rows, void* ws, caphn_stream_t stream) {
+    if (!loss_out) return CAPHN_EINVAL;
+    int rc = caphn_cross_entropy_rows(rows, V, logits, targets, ignore_index, dlogits, leave_ignored_rows, nullptr, ws, stream);
+    if (rc) return rc;
+    return caphn_cross_entropy_finish(rows, nullptr, loss_out, ws, stream);
 }
 
 extern "C" size_t caphn_colsum_workspace_bytes(int M, int N) {

@@ -190,6 +190,8 @@ int caphn_decoder_inputs(const caphn_decoder_dims* d, const caphn_decoder_params
                          caphn_stream_t stream);
 /* Compacts the (b,t) rows whose target differs from ignore_index into a row map kept in the workspace (count stays on
  * the device: no host synchronisation).  Call before caphn_decoder_forward / _backward with dims.row_subset = 1. */
+/* Device address of the live-row count that caphn_decoder_prepare_rows leaves in the workspace. */
+const int* caphn_decoder_rowcount_ptr(const caphn_decoder_dims* d, void* ws);
 int caphn_decoder_prepare_rows(const caphn_decoder_dims* d, const int64_t* targets, int64_t ignore_index,
                                void* ws, caphn_stream_t stream);
 /* Free-running / scheduled-sampling forward (validation, inference; keeps no backward state).
@@ -290,6 +292,12 @@ int caphn_plain_backward(const caphn_plain_dims* d, const caphn_plain_params* p,
  * ws: caphn_ce_workspace_bytes(rows).
  */
 size_t caphn_ce_workspace_bytes(int rows);
+/* The same in two stages, for callers that take the loss value off their critical path: _rows writes d logits (and the
+ * per-row losses into ws), _finish reduces them to loss_out.  n_valid_dev (optional, device int): the number of
+ * non-ignored targets if the caller has it already (caphn_decoder_rowcount_ptr) -- saves the counting kernel. */
+int caphn_cross_entropy_rows(int rows, int V, const float* logits, const int64_t* targets, int64_t ignore_index,
+                             float* dlogits, int leave_ignored_rows, const int* n_valid_dev, void* ws, caphn_stream_t stream);
+int caphn_cross_entropy_finish(int rows, const int* n_valid_dev, float* loss_out, void* ws, caphn_stream_t stream);
 int caphn_cross_entropy_fwd_bwd(int rows, int V, const float* logits, const int64_t* targets,
                                 int64_t ignore_index, float* dlogits, float* loss_out,
                                 int leave_ignored_rows, void* ws, caphn_stream_t stream);
