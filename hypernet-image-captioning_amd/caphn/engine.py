@@ -65,7 +65,10 @@ class FusedTrainer:
         self._nh = nh
         # step-dependent Adam scalars live in device memory so a captured hipGraph replays for any step
         self._adam_dev = torch.zeros(2, dtype=torch.float32, device=dev)
-        self._adam_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        # ring of pinned slots: the asynchronous H2D copy reads its slot when the GPU gets there, and the host may be
+        # several steps ahead by then -- one slot per step (mod 64) instead of one buffer rewritten every step
+        self._adam_host = torch.zeros(64, 2, dtype=torch.float32).pin_memory()
+        self._graph_scalars = False      # eager steps pass the Adam scalars by value (no copy, nothing to race with)
         self._graphs: Dict[tuple, object] = {}
         self._seen = set()
         # next-step theta produced during the optimiser pass (fused GEMV in caphn_adam_rank_gemv_f32)
@@ -349,9 +352,11 @@ class FusedTrainer:
     def _begin_step(self):
         self.step_count += 1
         a, b = ops.adam_scalars(self.lr, self.betas, self.step_count)
-        self._adam_host[0] = a
-        self._adam_host[1] = b
-        self._adam_dev.copy_(self._adam_host, non_blocking=True)
+        if self._graph_scalars:
+            slot = self._adam_host[self.step_count % 64]
+            slot[0] = a
+            slot[1] = b
+            self._adam_dev.copy_(slot, non_blocking=True)
 
     def _optimizer_impl(self, next_x_style=None, next_style_token=None, next_batch=None):
         R = dp.world(self.group)
@@ -369,7 +374,7 @@ class FusedTrainer:
         ops.clip_coef(part, self._acc, self.max_norm, 1.0 / R, out=self._coef)
         step = max(self.step_count, 1)
         ops.adam_dense(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self._coef, self.lr, step,
-                       self.betas, self.eps, dev_scalars=self._adam_dev)
+                       self.betas, self.eps, dev_scalars=self._adam_dev if self._graph_scalars else None)
         prefetch = (next_x_style is not None) or (next_style_token is not None)
         if prefetch:
             # the small layers (and the style row of the embedding) are already updated: compute the next
@@ -400,7 +405,7 @@ class FusedTrainer:
                 kw = dict(next_a=self._acts_next[ao:ao + an], next_bias=self._owned[f"hn_heads.{i}.2.bias"].data,
                           next_theta=self._theta_next[o:o + w])
             ops.adam_rank(self.W2[i].data, self.W2_m[i], self.W2_v[i], gi, ai, self._coef, self.lr, step,
-                          self.betas, self.eps, dev_scalars=self._adam_dev, **kw)
+                          self.betas, self.eps, dev_scalars=self._adam_dev if self._graph_scalars else None, **kw)
             if i == fork_after and next_batch is not None:
                 self._precompute_next(*next_batch, level=2 if full else 1)
         return self._coef
@@ -466,17 +471,23 @@ class FusedTrainer:
         if key not in self._seen:
             self._seen.add(key)
             return self.step(features, captions, x_style, style_token)
-        self._begin_step()
-        g = self._graphs.get(key)
-        if g is None:
-            self._sync_params()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                loss = self.forward_backward(features, captions, x_style, style_token)
-                self._optimizer_impl()
-            self._graphs[key] = (g, loss)
-        g, loss = self._graphs[key]
-        g.replay()
+        # a replayed graph cannot take the step-dependent Adam scalars by value: they come from device memory,
+        # refreshed (stream-ordered, from this step's pinned slot) in front of every replay
+        self._graph_scalars = True
+        try:
+            self._begin_step()
+            g = self._graphs.get(key)
+            if g is None:
+                self._sync_params()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    loss = self.forward_backward(features, captions, x_style, style_token)
+                    self._optimizer_impl()
+                self._graphs[key] = (g, loss)
+            g, loss = self._graphs[key]
+            g.replay()
+        finally:
+            self._graph_scalars = False
         return loss
 
     # ------------------------------------------------------------------ introspection for tests
