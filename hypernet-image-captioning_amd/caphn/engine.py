@@ -232,7 +232,8 @@ class FusedTrainer:
     def forward_backward(self, features, captions, x_style=None, style_token: Optional[int] = None,
                          validate: bool = False):
         """Fills the gradient arena (and the rank-1 factors) for one minibatch; returns the device
-        tensor [loss, n_valid_targets].  Exactly one of x_style ([he] or [1,he]) / style_token (Flickr
+        tensor [loss, n_valid_targets] (a per-shape buffer the next call overwrites: .clone() or .item() it to keep a
+        step's value).  Exactly one of x_style ([he] or [1,he]) / style_token (Flickr
         path: x = captioner.embed.weight[token], hypernet_attention.py:139-142)."""
         if (x_style is None) == (style_token is None):
             raise CaphnError("pass exactly one of x_style / style_token")

@@ -432,3 +432,37 @@ def test_all_targets_ignored_matches_torch():
     out = tr.forward_backward(g["features"].to(DEV), caps.to(DEV), x_style=g["x_style"].to(DEV))
     ref = F.cross_entropy(torch.zeros(4, dims.V), torch.zeros(4, dtype=torch.long), ignore_index=0)
     assert bool(torch.isnan(ref)) and bool(torch.isnan(out[0].cpu())) and float(out[1]) == 0.0
+
+
+def test_host_running_ahead_of_the_gpu_changes_nothing():
+    """Steps issued back to back (the host several steps ahead of the device, as in bench.py) must give the trajectory of
+    steps that are synchronised one by one: nothing the host rewrites per step (Adam scalars, cached structs, pinned
+    buffers) may be read later by the device.  Two synchronised runs already differ in the last bits (fp32 atomics in
+    the split-K weight gradients, amplified by Adam's normalisation: ~1e-3 on single parameters after 6 steps, 1e-7
+    on the loss), so the check is on the loss trajectory, with the parameters only bounded."""
+    from caphn.engine import FusedTrainer
+    from hypernet_attention import HyperNet
+    dims = O.Dims()
+    B, T, P = 32, 12, 49
+    batch = O.synth_batch(dims, B, T, P, seed=2)
+    feats, caps = batch["features"].to(DEV), batch["captions"].to(DEV)
+
+    def run(sync):
+        torch.manual_seed(11)
+        net = HyperNet(dims.F, dims.E, dims.H, dims.V, _Vocab()).to(DEV)
+        tr = FusedTrainer(net, lr=1e-3)
+        losses = []
+        for _ in range(6):
+            losses.append(tr.step(feats, caps, style_token=4, next_style_token=4, next_features=feats,
+                                  next_captions=caps).clone())      # the returned loss is a reused device buffer
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return tr.flat_p.clone(), [float(l.flatten()[0]) for l in losses]
+
+    pa, la = run(True)
+    pb, lb = run(False)
+    assert la[0] > la[-1] + 2.0                       # it trains
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-5 * abs(x), (la, lb)
+    assert maxdiff(pa.cpu(), pb.cpu()) < 5e-3
