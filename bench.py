@@ -131,12 +131,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # rehearsal on a one-GPU box (never the measured configuration): CAPHN_BENCH_REHEARSAL=1 puts every rank on
+    # device 0 and moves the collectives over gloo, so the N>1 control flow can be exercised without a second GPU
+    rehearsal = os.environ.get("CAPHN_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from hypernet_attention import HyperNet
     from caphn.engine import FusedTrainer
@@ -267,7 +275,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "T": T, "P": P, "D": D, "F": F, "E": E, "H": H,
                        "V": V, "hypernet_params": int(sum(q.numel() for q in net.hn_base.parameters()) +
                                                       sum(q.numel() for q in net.hn_heads.parameters())),
-                       "parallelism": f"dp{world}", "launch": "hipGraph" if use_graph else "eager",
+                       "parallelism": f"dp{world}" + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else ""), "launch": "hipGraph" if use_graph else "eager",
                        "next_theta_in_adam_pass": not (use_graph or args.no_prefetch),
                        "next_precompute_beside_adam": not (use_graph or args.no_prefetch or args.no_overlap),
                        "spinup_steps": spin["steps"],
