@@ -85,6 +85,7 @@ SIGNATURES = {
     "caphn_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_int,
                                  c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
     "caphn_zero_f32": (C.c_int, [c_fp, C.c_size_t, c_fp]),
+    "caphn_axpy_f32": (C.c_int, [C.c_size_t, C.c_float, c_fp, c_fp, c_fp]),
     "caphn_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "caphn_colsum_f32": (C.c_int, [C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]),
     "caphn_hyper_acts_floats": (C.c_int, [C.POINTER(HyperDesc)]),

@@ -52,6 +52,14 @@ def zero_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def axpy_(y: torch.Tensor, x: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """y += alpha * x (contiguous fp32, same length)."""
+    lib = L.load()
+    assert x.numel() == y.numel() and x.is_contiguous() and y.is_contiguous()
+    L.check(lib.caphn_axpy_f32(y.numel(), float(alpha), L.ptr(x), L.ptr(y), L.stream_ptr()), "caphn_axpy_f32")
+    return y
+
+
 def colsum(a: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = L.load()
     M, N = a.shape
@@ -700,15 +708,17 @@ def _plain_check(dims: PlainDims, features, captions, h0, c0):
 
 
 def plain_forward(dims: PlainDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,
-                  h0: torch.Tensor, c0: Optional[torch.Tensor], ws: torch.Tensor) -> torch.Tensor:
+                  h0: torch.Tensor, c0: Optional[torch.Tensor], ws: torch.Tensor, check_ids: bool = True,
+                  logits: Optional[torch.Tensor] = None) -> torch.Tensor:
     """DecoderGRU / DecoderRNN forward with teacher forcing (later.py:394-447 / :254-317) -> logits [B,T,V]."""
     lib = L.load()
     _plain_check(dims, features, captions, h0, c0)
-    if bool((captions < 0).any()) or bool((captions >= dims.V).any()):
-        raise IndexError("caption token id out of range")
+    if check_ids and (bool((captions < 0).any()) or bool((captions >= dims.V).any())):      # a host sync: trainers that
+        raise IndexError("caption token id out of range")                                  # validated their loader skip it
     cd = dims.c()
     ps = _plain_struct(L.PlainParams, dims, params)
-    logits = _f32(dims.B, dims.T, dims.V, device=features.device)
+    if logits is None:
+        logits = _f32(dims.B, dims.T, dims.V, device=features.device)
     L.check(lib.caphn_plain_forward(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64), L.ptr(h0),
                                     L.ptr(c0, allow_none=True), L.ptr(logits), C.c_void_p(ws.data_ptr()), L.stream_ptr()),
             "caphn_plain_forward")

@@ -162,6 +162,12 @@ __global__ __launch_bounds__(256) void zero_kernel(float* __restrict__ p, size_t
     }
 }
 
+// y += alpha * x  (gradients of parameters that alias the same theta range: set_all_parameters' child-offset restart)
+__global__ __launch_bounds__(256) void axpy_kernel(size_t n, float alpha, const float* __restrict__ x, float* __restrict__ y) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = fmaf(alpha, x[i], y[i]);
+}
+
 // ------------------------------------------------------------------ column sums
 // 256-thread blocks = 64 columns x 4 row lanes; grid.y slices the rows.  Stage 1 writes
 // part[slice][n], stage 2 is the same kernel over part (one slice).
@@ -429,6 +435,60 @@ __global__ __launch_bounds__(256) void adam_rank_kernel(int R, int rows, int k, 
         }
     }
 }
+// Long rows of any width / alignment (hypernet.py's heads: k = 11250, 8437 -- rows that are only 8 or 4 byte aligned):
+// one wave per row, lane-contiguous dword streams (256 B per wave instruction whatever the alignment), U columns per
+// lane in flight for each of W, m, v.  The element-linear fallback below (a 64-bit divide per element) moved 1.4 TB/s
+// on those shapes.  The next step's theta row is the wave's dot product of the updated row, as in adam_rank_rows.
+template <bool NT>
+__global__ __launch_bounds__(256) void adam_rank_long_kernel(int R, int rows, int k, float* W, float* m, float* v,
+                                                             const float* gfac, size_t ldg, const float* afac, size_t lda,
+                                                             const float* coef, AdamK K, NextGemv nx) {
+    const float c = coef[0];
+    if (K.dev) { K.lr_bc1 = K.dev[0]; K.sqrt_bc2 = K.dev[1]; }
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63, wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int r = wave_g; r < rows; r += nwaves) {
+        const size_t base = (size_t)r * k;
+        float gr[RMAX];
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q) gr[q] = q < R ? gfac[(size_t)q * ldg + r] : 0.f;
+        float dot = 0.f;
+        int col = lane;
+        for (; col + 64 * (U - 1) < k; col += 64 * U) {
+            float w[U], mm[U], vv[U], a[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t i = base + col + 64 * u;
+                if (NT) { w[u] = __builtin_nontemporal_load(W + i); mm[u] = __builtin_nontemporal_load(m + i); vv[u] = __builtin_nontemporal_load(v + i); }
+                else { w[u] = W[i]; mm[u] = m[i]; vv[u] = v[i]; }
+                a[u] = afac[col + 64 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float g = gr[0] * a[u];
+                for (int q = 1; q < R; ++q) g += gr[q] * afac[(size_t)q * lda + col + 64 * u];
+                w[u] = adam_elem(w[u], g * c, mm[u], vv[u], K);
+                if (nx.a) dot += w[u] * nx.a[col + 64 * u];
+                const size_t i = base + col + 64 * u;
+                if (NT) { __builtin_nontemporal_store(w[u], W + i); __builtin_nontemporal_store(mm[u], m + i); __builtin_nontemporal_store(vv[u], v + i); }
+                else { W[i] = w[u]; m[i] = mm[u]; v[i] = vv[u]; }
+            }
+        }
+        for (; col < k; col += 64) {
+            const size_t i = base + col;
+            float g = 0.f;
+            for (int q = 0; q < R; ++q) g += gr[q] * afac[(size_t)q * lda + col];
+            float me = m[i], ve = v[i];
+            const float wn = adam_elem(W[i], g * c, me, ve, K);
+            W[i] = wn; m[i] = me; v[i] = ve;
+            if (nx.a) dot += wn * nx.a[col];
+        }
+        if (nx.a) {
+            dot = wave_sum(dot);
+            if (lane == 0) nx.theta[r] = dot + nx.bias[r];
+        }
+    }
+}
 // generic-shape companion of the fused GEMV (k % 4 != 0 or unaligned): theta[row] = W[row,:] . a + bias[row]
 __global__ __launch_bounds__(256) void rowdot_kernel(int rows, int k, const float* __restrict__ W, NextGemv nx) {
     const int grp = threadIdx.x >> 3, s = threadIdx.x & 7;
@@ -521,6 +581,14 @@ extern "C" int caphn_zero_f32(float* p, size_t n, caphn_stream_t stream) {
     return caphn_launch_status();
 }
 
+extern "C" int caphn_axpy_f32(size_t n, float alpha, const float* x, float* y, caphn_stream_t stream) {
+    if (n == 0) return CAPHN_OK;
+    if (!x || !y) return CAPHN_EINVAL;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), n, alpha, x, y);
+    return caphn_launch_status();
+}
 extern "C" int caphn_embedding_gather(int rows, int E, const float* table, const int64_t* idx, float* out, caphn_stream_t stream) {
     if (rows <= 0 || E <= 0 || !table || !idx || !out) return CAPHN_EINVAL;
     hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), rows, E, table, idx, out);
@@ -594,6 +662,14 @@ static int adam_rank_launch(int R, int rows, int k, float* W, float* m, float* v
     if (nb < 1) nb = 1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const AdamK K = make_adam(hp);
+    const bool longrow = !(vec && k <= 2048) && k >= 512;
+    if (longrow) {
+        long nl = ((long)rows + 3) / 4;
+        if (nl > 8192) nl = 8192;
+        if (g_tune_adam == 0) hipLaunchKernelGGL((adam_rank_long_kernel<false>), dim3((unsigned)nl), dim3(256), 0, s, R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, nx);
+        else hipLaunchKernelGGL((adam_rank_long_kernel<true>), dim3((unsigned)nl), dim3(256), 0, s, R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, nx);
+        return caphn_launch_status();
+    }
     const bool fused = vec && k <= 2048;
     NextGemv nk = fused ? nx : NextGemv{nullptr, nullptr, nullptr};
     const size_t a_bytes = (R > 1 && vec && k <= 2048) ? sizeof(float) * (size_t)R * k : 0;

@@ -502,6 +502,37 @@ def plain_forward_backward(d: PlainDims, p: Dict[str, Tensor], features: Tensor,
     return loss.detach(), logits.detach(), theta.detach(), grads, theta.grad.detach()
 
 
+PLAIN_OPTIMISED_PREFIXES = ("hn_heads.", "hn_base.", "captioner.embed.", "image_encoder.fc.")
+
+
+def plain_train_step(d: PlainDims, p: Dict[str, Tensor], state: Dict[str, Tensor], step: int, imgs: Tensor,
+                     captions: Tensor, h0: Tensor, c0: Optional[Tensor] = None, style_token: int = 4,
+                     lr: float = 1e-6) -> Tensor:
+    """One optimiser step of hypernet.py: training_step (:126-152, teacher forcing, loss without ignore_index),
+    Adam(lr) over hn_heads, hn_base, captioner.embed and image_encoder.fc only (configure_optimizers :116-123 --
+    fc_out has no optimiser entry) and no gradient clipping (the Trainer of :218 sets none).  The generated weights
+    stay attached ("intended" gradients).  imgs: [B, 2048] pooled features through image_encoder.fc (:47, when
+    p holds it) or ready [B, E] embeddings.  In place on p / state ('m.'+name, 'v.'+name); returns the loss."""
+    names = [n for n, _ in plain_param_shapes(d)] + [n for n in ("image_encoder.fc.weight", "image_encoder.fc.bias") if n in p]
+    q = {n: p[n].clone().requires_grad_(True) for n in names}
+    feats = imgs
+    if imgs.shape[1] != d.E:
+        feats = F_.linear(imgs, q["image_encoder.fc.weight"], q["image_encoder.fc.bias"])
+    x = q["captioner.embed.weight"][torch.tensor([style_token])]
+    theta = hyper_forward(q, x, n_heads=len(plain_head_layout(d)))
+    logits = plain_decoder_forward(d, q, plain_inject(d, theta), feats, captions, h0, c0)
+    loss = F_.cross_entropy(logits.reshape(-1, d.V), captions.reshape(-1))
+    loss.backward()
+    for n in names:
+        if not n.startswith(PLAIN_OPTIMISED_PREFIXES):
+            continue
+        g = q[n].grad if q[n].grad is not None else torch.zeros_like(q[n])
+        m = state.setdefault("m." + n, torch.zeros_like(p[n]))
+        v = state.setdefault("v." + n, torch.zeros_like(p[n]))
+        adam_step(p[n], g, m, v, step, lr)
+    return loss.detach()
+
+
 def caption_loss(logits: Tensor, captions: Tensor, pad: int = 0) -> Tensor:
     """hypernet_attention.py:183 / cc_train_hypernet.py:153: target at step t is
     caps[:,t]; mean over non-<pad> targets."""

@@ -390,6 +390,29 @@ def test_adam_rank_eight_ranks_matches_dense(ops):
     assert maxdiff(Wc.cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("R,rows,k,fused", [(1, 77, 1031, True), (1, 50, 2050, False), (3, 41, 2501, True), (1, 9, 8437, True)])
+def test_adam_rank_long_odd_rows(ops, R, rows, k, fused):
+    """Rows longer than 2048 or of a width that is no multiple of 4 (hypernet.py's heads: 11250, 8437): wave-per-row
+    dword streams, with the next step's theta = W' a' + b from the same pass."""
+    g = torch.Generator().manual_seed(k)
+    a = torch.randn(R, k, generator=g)
+    gfac = torch.randn(R, rows, generator=g) * 1e-2
+    W = torch.randn(rows, k, generator=g)
+    na, nb = torch.randn(k, generator=g), torch.randn(rows, generator=g)
+    coef = torch.tensor([0.7, 0.0], device=DEV)
+    Wd, md, vd = W.to(DEV), torch.zeros(rows, k, device=DEV), torch.zeros(rows, k, device=DEV)
+    th = torch.zeros(rows, device=DEV)
+    m, v = torch.zeros(rows, k), torch.zeros(rows, k)
+    dense = (0.7 * (gfac.t().double() @ a.double())).float()
+    for step in (1, 2):
+        O.adam_step(W, dense, m, v, step, 1e-3)
+        kw = dict(next_a=na.to(DEV), next_bias=nb.to(DEV), next_theta=th) if fused else {}
+        ops.adam_rank(Wd, md, vd, gfac.to(DEV), a.to(DEV), coef, 1e-3, step, **kw)
+    assert maxdiff(Wd.cpu(), W) < 2e-6 and maxdiff(md.cpu(), m) < 1e-7 and maxdiff(vd.cpu(), v) < 1e-9
+    if fused:
+        assert maxdiff(th.cpu(), (Wd.cpu().double() @ na.double() + nb.double()).float()) < 2e-5 * (k / 1000) ** 0.5 + 1e-5
+
+
 def test_cross_entropy_in_place_reads_target_logit_before_overwrite(ops):
     """d logits written over the logits (the engine's layout): the target logit of a row must be read before any wave of
     that row stores.  A delayed load showed up as a reported loss off by ~0.2 / n on some runs (gradients unaffected);

@@ -72,6 +72,29 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
         print(f"{name}: {dt*1e3:.2f} ms" + (f"  ({nparam*4/dt/1e12:.2f} TB/s)" if "GEMV" in name else ""))
+    # the fused step (caphn.engine_plain): forward, loss, backward and Adam with rank-1 second-layer gradients
+    from caphn.engine_plain import FusedPlainTrainer
+    for p in net.parameters():
+        p.grad = None
+    torch.cuda.empty_cache()
+    tr = FusedPlainTrainer(net, lr=1e-6)
+    live = sum(w.numel() for w in tr.W2)
+    h0 = torch.rand(B, H, device=dev)
+    f2 = feats.detach()
+    for prefetch in (False, True):
+        for _ in range(3):
+            out = tr.step(f2, caps, 4, h0, None, next_style_token=4 if prefetch else None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            out = tr.step(f2, caps, 4, h0, None, next_style_token=4 if prefetch else None)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        bpp = 28 if prefetch else 32
+        print(f"fused step ({'next theta in the Adam pass' if prefetch else 'separate forward GEMV'}): {dt*1e3:.2f} ms = "
+              f"{B/dt:.0f} img/s; live second-layer parameters {live/1e9:.3f} G of {nparam/1e9:.3f} G, "
+              f"{bpp} B each -> {live*bpp/dt/1e12:.2f} TB/s;  loss {float(out[0]):.4f}")
 
 
 if __name__ == "__main__":
