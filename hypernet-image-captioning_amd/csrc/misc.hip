@@ -439,14 +439,16 @@ __global__ __launch_bounds__(256) void adam_rank_kernel(int R, int rows, int k, 
 // one wave per row, lane-contiguous dword streams (256 B per wave instruction whatever the alignment), U columns per
 // lane in flight for each of W, m, v.  The element-linear fallback below (a 64-bit divide per element) moved 1.4 TB/s
 // on those shapes.  The next step's theta row is the wave's dot product of the updated row, as in adam_rank_rows.
-template <bool NT>
-__global__ __launch_bounds__(256) void adam_rank_long_kernel(int R, int rows, int k, float* W, float* m, float* v,
-                                                             const float* gfac, size_t ldg, const float* afac, size_t lda,
-                                                             const float* coef, AdamK K, NextGemv nx) {
+template <bool NT, bool NTS>
+__global__ __launch_bounds__(256) void adam_rank_long_kernel(int R, int rows, int k, float* __restrict__ W, float* __restrict__ m,
+                                                             float* __restrict__ v, const float* __restrict__ gfac, size_t ldg,
+                                                             const float* __restrict__ afac, size_t lda,
+                                                             const float* __restrict__ coef, AdamK K, NextGemv nx) {
     const float c = coef[0];
     if (K.dev) { K.lr_bc1 = K.dev[0]; K.sqrt_bc2 = K.dev[1]; }
-    constexpr int U = 4;
+    constexpr int U = 8;
     const int lane = threadIdx.x & 63, wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const float* __restrict__ na = nx.a;
     for (int r = wave_g; r < rows; r += nwaves) {
         const size_t base = (size_t)r * k;
         float gr[RMAX];
@@ -468,9 +470,9 @@ __global__ __launch_bounds__(256) void adam_rank_long_kernel(int R, int rows, in
                 float g = gr[0] * a[u];
                 for (int q = 1; q < R; ++q) g += gr[q] * afac[(size_t)q * lda + col + 64 * u];
                 w[u] = adam_elem(w[u], g * c, mm[u], vv[u], K);
-                if (nx.a) dot += w[u] * nx.a[col + 64 * u];
+                if (na) dot += w[u] * na[col + 64 * u];
                 const size_t i = base + col + 64 * u;
-                if (NT) { __builtin_nontemporal_store(w[u], W + i); __builtin_nontemporal_store(mm[u], m + i); __builtin_nontemporal_store(vv[u], v + i); }
+                if (NTS) { __builtin_nontemporal_store(w[u], W + i); __builtin_nontemporal_store(mm[u], m + i); __builtin_nontemporal_store(vv[u], v + i); }
                 else { W[i] = w[u]; m[i] = mm[u]; v[i] = vv[u]; }
             }
         }
@@ -481,9 +483,9 @@ __global__ __launch_bounds__(256) void adam_rank_long_kernel(int R, int rows, in
             float me = m[i], ve = v[i];
             const float wn = adam_elem(W[i], g * c, me, ve, K);
             W[i] = wn; m[i] = me; v[i] = ve;
-            if (nx.a) dot += wn * nx.a[col];
+            if (na) dot += wn * na[col];
         }
-        if (nx.a) {
+        if (na) {
             dot = wave_sum(dot);
             if (lane == 0) nx.theta[r] = dot + nx.bias[r];
         }
@@ -666,8 +668,11 @@ static int adam_rank_launch(int R, int rows, int k, float* W, float* m, float* v
     if (longrow) {
         long nl = ((long)rows + 3) / 4;
         if (nl > 8192) nl = 8192;
-        if (g_tune_adam == 0) hipLaunchKernelGGL((adam_rank_long_kernel<false>), dim3((unsigned)nl), dim3(256), 0, s, R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, nx);
-        else hipLaunchKernelGGL((adam_rank_long_kernel<true>), dim3((unsigned)nl), dim3(256), 0, s, R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, nx);
+        // rows that are not 128-byte aligned share cache lines with their neighbours: non-temporal accesses then fetch /
+        // write those lines twice (13.5 ms plain vs 15.7 ms non-temporal per step on hypernet.py's literal configuration)
+        if (g_tune_adam == 7) hipLaunchKernelGGL((adam_rank_long_kernel<false, true>), dim3((unsigned)nl), dim3(256), 0, s, R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, nx);
+        else if (g_tune_adam == 3) hipLaunchKernelGGL((adam_rank_long_kernel<true, true>), dim3((unsigned)nl), dim3(256), 0, s, R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, nx);
+        else hipLaunchKernelGGL((adam_rank_long_kernel<false, false>), dim3((unsigned)nl), dim3(256), 0, s, R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, nx);
         return caphn_launch_status();
     }
     const bool fused = vec && k <= 2048;

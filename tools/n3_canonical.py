@@ -23,6 +23,11 @@ class Vocab:
 
 def main():
     dev = "cuda"
+    if os.environ.get("CAPHN_TUNE"):                       # e.g. CAPHN_TUNE="1=0,0=0" -> caphn_tune(1, 0), caphn_tune(0, 0)
+        from caphn import _lib
+        for kv in os.environ["CAPHN_TUNE"].split(","):
+            k, v = kv.split("=")
+            assert _lib.load().caphn_tune(int(k), int(v)) == 0
     torch.manual_seed(0)
     E, H, V, L, B, T = 200, 150, 9684, 2, 128, 20
     with torch.device(dev):
