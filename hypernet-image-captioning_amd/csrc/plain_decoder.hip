@@ -231,6 +231,12 @@ extern "C" int caphn_plain_backward(const caphn_plain_dims* d, const caphn_plain
     // BPTT over (t, layer) in reverse evaluation order; carry = gradient reaching h_{t-1, last layer}
     if (hipMemsetAsync(ws + w.carry, 0, sizeof(float) * (size_t)B * H, s) != hipSuccess) return CAPHN_ELAUNCH;
     if (lstm && hipMemsetAsync(ws + w.dcar, 0, sizeof(float) * (size_t)B * H, s) != hipSuccess) return CAPHN_ELAUNCH;
+    // dst += dgates W: [B, GH] x [GH, H] is a handful of tiles with a 15-50 slab K loop on the BPTT critical path (2 per
+    // step and layer); split-K spreads the loop over more workgroups and its atomics are exactly the accumulation
+    const int bptt_sk = std::max(1, std::min(8, ((GH + 31) / 32) / 3));
+    auto accum_gemm = [&](const float* dg, const float* W, float* dst) {
+        return caphn_gemm_f32(0, 0, B, H, GH, dg, GH, W, H, dst, H, nullptr, nullptr, 0, bptt_sk > 1 ? 0 : CAPHN_GEMM_ACCUM, bptt_sk, s);
+    };
     for (int t = T - 1; t >= 0; --t) {
         const size_t oG = (size_t)t * B * GH, oH = (size_t)t * B * H;
         for (int l = L - 1; l >= 0; --l) {
@@ -245,15 +251,15 @@ extern "C" int caphn_plain_backward(const caphn_plain_dims* d, const caphn_plain
                 // dst may alias dh_b: the kernel reads dh_b[i] before writing dst[i] (same thread, same element)
                 hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(nb), dim3(256), 0, s, B, H, T, t, dh_a, dh_b, ws + w.gates[l] + oG,
                                    ws + w.hn[l] + oH, hin, ws + w.dgi[l] + oG, ws + w.dgh[l] + oG, dst);
-                RUN(caphn_gemm_f32(0, 0, B, H, GH, ws + w.dgh[l] + oG, GH, p->w_hh[l], H, dst, H, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
+                RUN(accum_gemm(ws + w.dgh[l] + oG, p->w_hh[l], dst));
                 if (l > 0)     // the layer's input is the same h: add the x-side path
-                    RUN(caphn_gemm_f32(0, 0, B, H, GH, ws + w.dgi[l] + oG, GH, p->w_ih[l], H, dst, H, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
+                    RUN(accum_gemm(ws + w.dgi[l] + oG, p->w_ih[l], dst));
             } else {
                 hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(nb), dim3(256), 0, s, B, H, T, t, dh_a, dh_b, ws + w.gates[l] + oG,
                                    ws + w.Cl[l] + oH, cin, ws + w.dgi[l] + oG, ws + w.dcar);
                 RUN(caphn_gemm_f32(0, 0, B, H, GH, ws + w.dgi[l] + oG, GH, p->w_hh[l], H, dst, H, nullptr, nullptr, 0, 0, 1, s));
                 if (l > 0)
-                    RUN(caphn_gemm_f32(0, 0, B, H, GH, ws + w.dgi[l] + oG, GH, p->w_ih[l], H, dst, H, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
+                    RUN(accum_gemm(ws + w.dgi[l] + oG, p->w_ih[l], dst));
             }
         }
     }

@@ -283,3 +283,22 @@ def test_plain_decoder_hypernet_py(name):
     for li, cw in enumerate(leaves):
         for n, t in cw.items():
             assert maxdiff(t.grad, g["glit/" + ("lstm_cell." if li == 0 else f"layers.{li - 1}.") + n]) < ATOL
+
+
+def test_plain_train_step_protocol():
+    """hypernet.py's optimiser step in the oracle: the loss falls, fc_out (no optimiser entry) and the heads whose theta
+    slices nothing reads (child-offset restart) stay bit-identical, everything else in the optimiser's list moves."""
+    d = O.PlainDims(E=12, H=10, V=30, L=2, cell="gru")
+    p = O.init_plain_params(d, seed=1)
+    p0 = {k: v.clone() for k, v in p.items()}
+    g = torch.Generator().manual_seed(0)
+    imgs, caps, h0 = torch.randn(3, 12, generator=g), torch.randint(0, 30, (3, 5), generator=g), torch.rand(3, 10, generator=g)
+    st = {}
+    losses = [float(O.plain_train_step(d, p, st, s, imgs, caps, h0, lr=1e-2)) for s in (1, 2, 3)]
+    assert losses[2] < losses[0]
+    assert torch.equal(p["captioner.fc_out.weight"], p0["captioner.fc_out.weight"])
+    for i in range(4, 8):
+        assert torch.equal(p[f"hn_heads.{i}.2.weight"], p0[f"hn_heads.{i}.2.weight"])
+        assert torch.equal(p[f"hn_heads.{i}.0.bias"], p0[f"hn_heads.{i}.0.bias"])
+    for n in ("hn_heads.0.2.weight", "hn_heads.3.2.bias", "hn_base.0.weight", "captioner.embed.weight"):
+        assert not torch.equal(p[n], p0[n])
