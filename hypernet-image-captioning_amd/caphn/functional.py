@@ -100,3 +100,82 @@ def plain_decoder_forward(dims: ops.PlainDims, features, captions, h0, c0, named
         raise CaphnError("DecoderGRU / DecoderRNN run on libcaphn's HIP kernels only: move the module and its inputs to a "
                          "CUDA(HIP) device (there is no CPU fallback)")
     return _PlainDecoderFn.apply(dims, features.float(), captions.long(), h0, c0, *[named[n] for n in dims.names()])
+
+
+class _MLPFn(torch.autograd.Function):
+    """x -> Linear, ReLU, ..., Linear over the last dimension (baseline/caption.py:34-47) as one node, so that the ReLU
+    gradients are the mask epilogue of the input-gradient contractions (CAPHN_GEMM_MASK) and nothing runs outside libcaphn."""
+
+    @staticmethod
+    def forward(ctx, x, n_layers, *params):
+        h = x.detach().reshape(-1, x.shape[-1]).contiguous()
+        acts, ws = [h], []
+        for i in range(n_layers):
+            w, b = params[2 * i].detach().contiguous(), params[2 * i + 1].detach().contiguous()
+            h = ops.gemm(h, w, tb=True, bias=b, relu=i < n_layers - 1)
+            ws.append(w)
+            if i < n_layers - 1:
+                acts.append(h)
+        ctx.acts, ctx.ws, ctx.xshape, ctx.need_x = acts, ws, x.shape, x.requires_grad
+        return h.view(*x.shape[:-1], h.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        acts, ws = ctx.acts, ctx.ws
+        n = len(ws)
+        dz = dy.reshape(-1, ws[-1].shape[0]).contiguous()
+        grads = [None] * (2 * n)
+        dx = None
+        for i in range(n - 1, -1, -1):
+            a = acts[i]                                   # input of layer i (post-ReLU output of layer i-1 for i > 0)
+            grads[2 * i] = ops.gemm(dz, a, ta=True, splitk=max(1, min(16, a.shape[0] // 256)))
+            grads[2 * i + 1] = ops.colsum(dz)
+            if i > 0:
+                dz = ops.gemm(dz, ws[i], mask=a)          # zero where the ReLU clamped
+            elif ctx.need_x:
+                dx = ops.gemm(dz, ws[0]).view(ctx.xshape)
+        ctx.acts = ctx.ws = None
+        return (dx, None) + tuple(grads)
+
+
+def mlp(x, layers):
+    """layers: sequence of nn.Linear; ReLU between them, none after the last."""
+    if not x.is_cuda:
+        raise CaphnError("caphn mlp runs on libcaphn's HIP kernels only (no CPU fallback)")
+    params = []
+    for l in layers:
+        params += [l.weight, l.bias]
+    return _MLPFn.apply(x.float(), len(layers), *params)
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    """nn.Conv2d(C_in, C_out, kernel_size=1) on NCHW input (baseline/caption.py:13-14, :27): one [bs*h*w, C_in] x
+    [C_in, C_out] contraction over channels-last rows; the result is returned as an NCHW view of those rows."""
+
+    @staticmethod
+    def forward(ctx, src, w, b):
+        bs, cin, h, wd = src.shape
+        x = src.detach().permute(0, 2, 3, 1).reshape(-1, cin).contiguous()          # layout only
+        wc = w.detach().contiguous()
+        y = ops.gemm(x, wc, tb=True, bias=b.detach().contiguous())
+        ctx.save_for_backward(x, wc)
+        ctx.shape, ctx.need_x = (bs, cin, h, wd), src.requires_grad
+        return y.view(bs, h, wd, -1).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        bs, cin, h, wd = ctx.shape
+        dz = dy.permute(0, 2, 3, 1).reshape(-1, w.shape[0]).contiguous()
+        dw = ops.gemm(dz, x, ta=True, splitk=max(1, min(16, x.shape[0] // 256)))
+        db = ops.colsum(dz)
+        dx = None
+        if ctx.need_x:
+            dx = ops.gemm(dz, w).view(bs, h, wd, cin).permute(0, 3, 1, 2)
+        return dx, dw, db
+
+
+def conv1x1(src, w, b):
+    if not src.is_cuda:
+        raise CaphnError("caphn conv1x1 runs on libcaphn's HIP kernels only (no CPU fallback)")
+    return _Conv1x1Fn.apply(src.float(), w, b)

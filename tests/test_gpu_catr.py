@@ -1,0 +1,94 @@
+"""N4, stage 1 (parity UNPINNED by the reference: it has no hypernet for CATR): the hypernet-generated 1x1 input
+projection and the MLP vocabulary head of baseline/caption.py through libcaphn, against torch's conv2d / linear on
+the same weights and torch autograd through an fp64 restatement of the hypernetwork (oracle.hyper_forward)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import caphn_oracle as O
+from helpers import maxdiff
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ref_generate(mod, x):
+    p = {k: v.detach().double().cpu().requires_grad_(True) for k, v in mod.hyper_named_tensors().items()}
+    theta = O.hyper_forward(p, x.double().cpu().reshape(1, -1), n_heads=len(mod.hn_heads))
+    return p, theta.reshape(-1)
+
+
+@pytest.mark.parametrize("cin,hid,he,bs,h,w", [(48, 16, 10, 3, 5, 4), (2048, 256, 10, 2, 7, 7), (2048, 256, 200, 2, 3, 3)])
+def test_generated_projection_matches_conv2d(cin, hid, he, bs, h, w):
+    from baseline.caption import HyperInputProj
+    torch.manual_seed(cin + he)
+    mod = HyperInputProj(cin, hid, he).to(DEV)
+    src = torch.randn(bs, cin, h, w, device=DEV, requires_grad=True)
+    x = torch.randn(he, device=DEV)
+    out = mod(src, x)
+    assert out.shape == (bs, hid, h, w)
+    p, theta = _ref_generate(mod, x)
+    wr, br = theta[:hid * cin].view(hid, cin, 1, 1), theta[hid * cin:]
+    s64 = src.detach().double().cpu().requires_grad_(True)
+    ref = F.conv2d(s64, wr, br)
+    scale = float(ref.detach().abs().max())
+    assert maxdiff(out.detach().cpu().double(), ref.detach()) < 2e-6 * max(1.0, scale)
+    g = torch.randn(bs, hid, h, w, dtype=torch.float64)
+    out.backward(g.float().to(DEV))
+    ref.backward(g)
+    assert maxdiff(src.grad.cpu().double(), s64.grad) < 2e-6 * max(1.0, float(s64.grad.abs().max()))
+    for name, t in mod.hyper_named_tensors().items():
+        want = p[name].grad
+        tol = 3e-6 * max(1.0, float(want.abs().max()))
+        if t.numel() > 4_000_000:                      # the big second-layer weight: rows sampled, norm in full
+            rows = torch.arange(0, t.shape[0], max(1, t.shape[0] // 97))
+            assert maxdiff(t.grad[rows.to(DEV)].cpu().double(), want[rows]) < tol, name
+            assert abs(float(t.grad.double().norm()) - float(want.norm())) < 1e-5 * float(want.norm()) + 1e-9, name
+        else:
+            assert maxdiff(t.grad.cpu().double(), want) < tol, name
+
+
+def test_mlp_head_matches_torch():
+    from baseline.caption import MLP
+    torch.manual_seed(5)
+    mlp = MLP(64, 96, 301, 3).to(DEV)
+    x = torch.randn(7, 5, 64, device=DEV, requires_grad=True)
+    y = mlp(x)
+    ref_p = [p.detach().double().cpu().requires_grad_(True) for p in mlp.parameters()]
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    hcur = x64
+    for i in range(3):
+        hcur = F.linear(hcur, ref_p[2 * i], ref_p[2 * i + 1])
+        if i < 2:
+            hcur = F.relu(hcur)
+    assert maxdiff(y.detach().cpu().double(), hcur.detach()) < 2e-6
+    g = torch.randn_like(hcur)
+    y.backward(g.float().to(DEV))
+    hcur.backward(g)
+    assert maxdiff(x.grad.cpu().double(), x64.grad) < 2e-6
+    for p, r in zip(mlp.parameters(), ref_p):
+        assert maxdiff(p.grad.cpu().double(), r.grad) < 5e-6
+
+
+def test_caption_wiring_and_no_cpu_path():
+    from baseline.caption import Caption, HyperInputProj
+    from caphn._lib import CaphnError
+
+    class Backbone(torch.nn.Module):
+        def forward(self, samples):
+            return [(samples, torch.zeros(samples.shape[0], samples.shape[2], samples.shape[3], dtype=torch.bool,
+                                          device=samples.device))], [None]
+
+    class Body(torch.nn.Module):             # stands where baseline/transformer.py's Transformer goes: [T, bs, hidden]
+        def forward(self, src, mask, pos, tgt, tgt_mask):
+            return src.flatten(2).mean(-1).unsqueeze(0).expand(tgt.shape[1], -1, -1)
+
+    torch.manual_seed(0)
+    net = Caption(Backbone(), Body(), 16, 50, hyper_emb=10, in_channels=32).to(DEV)
+    out = net(torch.randn(2, 32, 3, 3, device=DEV), torch.zeros(2, 6, dtype=torch.long, device=DEV), None,
+              torch.randn(10, device=DEV))
+    assert out.shape == (2, 6, 50)
+    out.sum().backward()
+    assert all(p.grad is not None for p in net.input_proj.parameters()) and net.mlp.layers[0].weight.grad is not None
+    with pytest.raises(CaphnError):
+        HyperInputProj(16, 12, 10)(torch.randn(1, 16, 2, 2), torch.randn(10))

@@ -130,3 +130,18 @@ def test_no_cpu_fallback():
     net = HyperNet(16, 16, 16, 50, V(), cc=True, hyper_emb=4)
     with pytest.raises(CaphnError):
         net(torch.zeros(4))
+
+
+def test_catr_generated_projection_head_layout_and_cpu_refusal():
+    """N4 stage 1: the hypernet that generates baseline/caption.py:13's 1x1 convolution is sized by the M = 500 rule of
+    hypernet_attention.py; like every other module it refuses CPU tensors instead of falling back."""
+    import torch
+    from baseline.caption import HyperInputProj, MLP
+    from caphn._lib import CaphnError
+    m = HyperInputProj(2048, 256, hyper_emb=10)
+    assert [(h[0].out_features, h[2].out_features) for h in m.hn_heads] == [(1048, 524288), (10, 256)]
+    assert m._shape.theta_size == 256 * 2048 + 256
+    with pytest.raises(CaphnError):
+        m(torch.randn(1, 2048, 2, 2), torch.randn(10))
+    with pytest.raises(CaphnError):
+        MLP(8, 16, 30, 3)(torch.randn(2, 8))
