@@ -122,6 +122,8 @@ def main():
                          "the dominant kernel sit inside the timed region")
     ap.add_argument("--eager", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-spinup", action="store_true", help="skip the untimed spin-up windows after --warmup")
+    ap.add_argument("--from-host", action="store_true", help="side measurement (DESIGN.md): every minibatch starts in pinned HOST "
+                    "memory and crosses PCIe on a copy stream, two batches ahead, into one of three device slots")
     ap.add_argument("--no-overlap", action="store_true", help="do not issue the next batch's caption-independent "
                     "precompute beside the optimiser")
     args = ap.parse_args()
@@ -169,12 +171,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    class HostFeed:
+        """--from-host: batch j lives in pinned host memory and is copied into device slot j % 3 on a copy stream while
+        step j-2 .. j-1 run (step j uses slot j % 3 and, for the next-batch precompute, slot (j+1) % 3)."""
+
+        def __init__(self, dev_batches):
+            self.host = [(f.cpu().pin_memory(), c.cpu().pin_memory()) for f, c in dev_batches]
+            self.slots = [(torch.empty_like(dev_batches[0][0]), torch.empty_like(dev_batches[0][1])) for _ in range(3)]
+            self.copy = torch.cuda.Stream(device=dev)
+            self.copied = [torch.cuda.Event() for _ in range(3)]
+            self.done = [None, None, None]
+            self.next_j = 0
+
+        def _issue(self, j):
+            s = j % 3
+            with torch.cuda.stream(self.copy):
+                if self.done[s] is not None:
+                    self.copy.wait_event(self.done[s])          # the step that last read this slot has finished
+                hf, hc = self.host[j % len(self.host)]
+                self.slots[s][0].copy_(hf, non_blocking=True)
+                self.slots[s][1].copy_(hc, non_blocking=True)
+                self.copied[s].record(self.copy)
+
+        def get(self, j):
+            while self.next_j <= j + 1:                          # batches j and j+1 are on their way
+                self._issue(self.next_j)
+                self.next_j += 1
+            main = torch.cuda.current_stream()
+            main.wait_event(self.copied[j % 3])
+            main.wait_event(self.copied[(j + 1) % 3])
+            return self.slots[j % 3]
+
+        def after(self, j):
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.done[j % 3] = ev
+            self._issue(j + 2)                                   # slot (j+2) % 3 == (j-1) % 3: free once step j-1 is done
+            self.next_j = max(self.next_j, j + 3)
+
+    feed = HostFeed(batches) if args.from_host else None
+
+    def batch_at(j):
+        return feed.get(j) if feed else batches[j % len(batches)]
+
+    def after_step(j):
+        if feed:
+            feed.after(j)
+
     use_graph = (world == 1) and args.graph
     if use_graph or args.no_prefetch:
         do_step = tr.step_graphed if use_graph else tr.step
     else:
         # the loader is one batch ahead, so the next batch's style is known when the optimiser runs
-        nxt = {batches[i][0].data_ptr(): batches[(i + 1) % len(batches)] for i in range(len(batches))}
+        seq = feed.slots if feed else batches
+        nxt = {seq[i][0].data_ptr(): seq[(i + 1) % len(seq)] for i in range(len(seq))}
 
         def do_step(f, c, style_token):
             nf, nc = (None, None) if args.no_overlap else nxt[f.data_ptr()]
@@ -184,8 +234,9 @@ def main():
             for f, c in batches:
                 do_step(f, c, style_token=style)
     for i in range(args.warmup):
-        f, c = batches[i % len(batches)]
+        f, c = batch_at(i)
         do_step(f, c, style_token=style)
+        after_step(i)
     # Spin-up (untimed, additional to --warmup; reported as config.spinup_steps).  The first process on a freshly
     # acquired box stalls ONCE on the host for ~37 ms around its 1200th kernel launch (step 12-13 here; the GPU idles,
     # every kernel keeps its normal duration, a second process on the same box never shows it --
@@ -198,8 +249,9 @@ def main():
             torch.cuda.synchronize()
             t = time.perf_counter()
             for j in range(n):
-                f, c = batches[(args.warmup + spin["steps"] + j) % len(batches)]
+                f, c = batch_at(args.warmup + spin["steps"] + j)
                 do_step(f, c, style_token=style)
+                after_step(args.warmup + spin["steps"] + j)
             torch.cuda.synchronize()
             spin["steps"] += n
             dtw = (time.perf_counter() - t) / n
@@ -238,8 +290,9 @@ def main():
     t0 = time.perf_counter()
     off = args.warmup + spin["steps"]          # continue the batch cycle, so the announced next batch is the one that comes
     for i in range(args.steps):
-        f, c = batches[(off + i) % len(batches)]
+        f, c = batch_at(off + i)
         loss = do_step(f, c, style_token=style)
+        after_step(off + i)
     barrier()
     dt = time.perf_counter() - t0
     ops.adam_rank = orig
@@ -269,7 +322,8 @@ def main():
         line = {
             "metric": METRIC, "value": B * world * args.steps / dt, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (each minibatch copied from pinned host memory inside the timed region)" if args.from_host else ""),
             "config": {"workload": f"Flickr30k-shaped {args.cell.upper()}+additive-attention decoder + hypernet (3 style domains), "
                                    "full training step (fwd, CE, bwd, clip 5.0, Adam)",
                        "per_gpu_batch": B, "global_batch": B * world, "T": T, "P": P, "D": D, "F": F, "E": E, "H": H,
