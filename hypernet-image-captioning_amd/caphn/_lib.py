@@ -62,6 +62,11 @@ class PlainDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "T", "E", "H", "V", "L", "cell")]
 
 
+class AttnDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("bs", "nh", "dh", "tq", "tk", "q_ldt", "q_ldb", "k_ldt", "k_ldb", "v_ldt", "v_ldb",
+                                       "o_ldt", "o_ldb")] + [("scale", C.c_float)]
+
+
 class PlainParams(C.Structure):
     _fields_ = [("embed_w", c_fp), ("out_w", c_fp), ("out_b", c_fp),
                 ("w_ih", c_fp * MAX_LAYERS), ("w_hh", c_fp * MAX_LAYERS), ("b_ih", c_fp * MAX_LAYERS), ("b_hh", c_fp * MAX_LAYERS)]
@@ -116,6 +121,12 @@ SIGNATURES = {
     "caphn_plain_forward": (C.c_int, [C.POINTER(PlainDims), C.POINTER(PlainParams), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "caphn_plain_backward": (C.c_int, [C.POINTER(PlainDims), C.POINTER(PlainParams), c_fp, c_fp, c_fp, c_fp, c_fp,
                                        C.POINTER(PlainGrads), c_fp, c_fp]),
+    "caphn_layernorm_fwd": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "caphn_layernorm_bwd": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_attention_supported": (C.c_int, [C.POINTER(AttnDims)]),
+    "caphn_attention_fwd": (C.c_int, [C.POINTER(AttnDims), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_attention_bwd": (C.c_int, [C.POINTER(AttnDims), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "caphn_ce_workspace_bytes": (C.c_size_t, [C.c_int]),
     "caphn_cross_entropy_rows": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, C.c_int64, c_fp, C.c_int, c_fp, c_fp, c_fp]),
     "caphn_cross_entropy_finish": (C.c_int, [C.c_int, c_fp, c_fp, c_fp, c_fp]),

@@ -737,3 +737,76 @@ def plain_backward(dims: PlainDims, params: Dict[str, torch.Tensor], features: t
     L.check(lib.caphn_plain_backward(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64), L.ptr(h0),
                                      L.ptr(c0, allow_none=True), L.ptr(dlogits), C.byref(gs), C.c_void_p(ws.data_ptr()),
                                      L.stream_ptr()), "caphn_plain_backward")
+
+
+# ------------------------------------------------------------------ N4: transformer pieces (baseline/transformer.py)
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    """nn.LayerNorm over the last dimension -> (y, mean[rows], rstd[rows])."""
+    lib = L.load()
+    d = x.shape[-1]
+    x2 = x.reshape(-1, d)
+    rows = x2.shape[0]
+    y = torch.empty_like(x2)
+    mean, rstd = _f32(rows, device=x.device), _f32(rows, device=x.device)
+    L.check(lib.caphn_layernorm_fwd(rows, d, L.ptr(x2), L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(y), L.ptr(mean), L.ptr(rstd),
+                                    L.stream_ptr()), "caphn_layernorm_fwd")
+    return y.view(x.shape), mean, rstd
+
+
+def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, dy: torch.Tensor):
+    lib = L.load()
+    d = x.shape[-1]
+    x2, dy2 = x.reshape(-1, d), dy.reshape(-1, d)
+    rows = x2.shape[0]
+    dx = torch.empty_like(x2)
+    dg, db = _f32(d, device=x.device), _f32(d, device=x.device)
+    ws = torch.empty(lib.caphn_layernorm_bwd_workspace_bytes(rows, d), dtype=torch.uint8, device=x.device)
+    L.check(lib.caphn_layernorm_bwd(rows, d, L.ptr(x2), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), L.ptr(dy2), L.ptr(dx), L.ptr(dg),
+                                    L.ptr(db), C.c_void_p(ws.data_ptr()), L.stream_ptr()), "caphn_layernorm_bwd")
+    return dx.view(x.shape), dg, db
+
+
+def _attn_dims(q, k, v, o, nh: int) -> L.AttnDims:
+    """q [tq, bs, d], k / v [tk, bs, d], o [tq, bs, d]: sequence-first views whose last stride is 1 (slices of a packed
+    projection are fine)."""
+    tq, bs, dm = q.shape
+    tk = k.shape[0]
+    for t in (q, k, v, o):
+        if t.dim() != 3 or t.stride(2) != 1 or t.shape[1] != bs or t.shape[2] != dm or t.dtype != torch.float32 or not t.is_cuda:
+            raise L.CaphnError("attention operands must be fp32 CUDA [T, bs, d] views with unit last stride")
+    if v.shape[0] != tk or o.shape[0] != tq or dm % nh:
+        raise L.CaphnError("attention shapes do not match")
+    dh = dm // nh
+    d = L.AttnDims(bs, nh, dh, tq, tk, q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                   o.stride(0), o.stride(1), 1.0 / (dh ** 0.5))
+    if not L.load().caphn_attention_supported(C.byref(d)):
+        raise L.CaphnError(f"attention shape not supported by libcaphn (heads of {dh}, {tq} x {tk} positions)")
+    return d
+
+
+def attention_fwd(q, k, v, nh: int, attn_mask: Optional[torch.Tensor] = None, key_padding: Optional[torch.Tensor] = None):
+    """softmax(q k^T / sqrt(dh) + attn_mask + key padding) v per head -> (o [tq, bs, d], lse [bs*nh, tq])."""
+    lib = L.load()
+    o = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    d = _attn_dims(q, k, v, o, nh)
+    lse = _f32(d.bs * nh, d.tq, device=q.device)
+    L.check(lib.caphn_attention_fwd(C.byref(d), C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()),
+                                    L.ptr(attn_mask, allow_none=True), L.ptr(key_padding, torch.uint8, allow_none=True),
+                                    L.ptr(o), L.ptr(lse), L.stream_ptr()), "caphn_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q, k, v, nh: int, attn_mask, key_padding, o, lse, d_o):
+    lib = L.load()
+    d_o = d_o.contiguous()
+    if d_o.stride() != o.stride():
+        raise L.CaphnError("d_o must share o's layout")
+    d = _attn_dims(q, k, v, o, nh)
+    dq, dk, dv = torch.empty_strided(q.shape, q.stride(), dtype=torch.float32, device=q.device), \
+        torch.empty_strided(k.shape, k.stride(), dtype=torch.float32, device=q.device), \
+        torch.empty_strided(v.shape, v.stride(), dtype=torch.float32, device=q.device)
+    L.check(lib.caphn_attention_bwd(C.byref(d), C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()),
+                                    L.ptr(attn_mask, allow_none=True), L.ptr(key_padding, torch.uint8, allow_none=True),
+                                    L.ptr(o), L.ptr(lse), L.ptr(d_o), C.c_void_p(dq.data_ptr()), C.c_void_p(dk.data_ptr()),
+                                    C.c_void_p(dv.data_ptr()), L.stream_ptr()), "caphn_attention_bwd")
+    return dq, dk, dv

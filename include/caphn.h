@@ -363,6 +363,39 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * GEMM tile order, key 7: branch-free GEMM loads).  Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
+/* ---------------------------------------------------------------------------------------
+ * N4 (CATR): the non-GEMM pieces of baseline/transformer.py's layers.  Parity: pinned by vectors generated from the
+ * reference's own Transformer (tests/golden/catr_*.npz, tools/make_golden.py --only-catr).
+ *
+ * nn.LayerNorm over the last dimension (baseline/transformer.py:19,27,138-139,199-201,281; biased variance), d <= 1024.
+ * mean / rstd [rows] are saved for the backward.  ws: caphn_layernorm_bwd_workspace_bytes(rows, d).
+ */
+int caphn_layernorm_fwd(int rows, int d, const float* x, const float* gamma, const float* beta, float eps, float* y,
+                        float* mean, float* rstd, caphn_stream_t stream);
+size_t caphn_layernorm_bwd_workspace_bytes(int rows, int d);
+int caphn_layernorm_bwd(int rows, int d, const float* x, const float* gamma, const float* mean, const float* rstd,
+                        const float* dy, float* dx, float* dgamma, float* dbeta, void* ws, caphn_stream_t stream);
+
+/* The core of nn.MultiheadAttention (baseline/transformer.py:137,197-199 -> F.multi_head_attention_forward):
+ *   o[t,b,h,:] = sum_j softmax_j( q[t,b,h,:].k[j,b,h,:] * scale + attn_mask[t,j] + (key_padding[b,j] ? -inf : 0) ) v[j,b,h,:]
+ * for nh heads of width dh (<= 64).  Tensors are addressed as  base + t*ldt + b*ldb + h*dh  (floats), so the sequence-first
+ * [T, bs, nh*dh] tensors of the reference and slices of a packed in-projection are used in place; o / d_o share o's strides,
+ * dq / dk / dv those of q / k / v.  attn_mask: additive [tq, tk] (-inf = masked) or NULL; key_padding: [bs, tk] bytes,
+ * non-zero = ignore, or NULL.  lse [bs*nh, tq] (log-sum-exp per row) links forward and backward.  A row with every key masked
+ * yields zeros (torch yields NaN).  Limits: caphn_attention_supported() (the K/V or Q/dO side of one (batch, head) must fit LDS:
+ * 512 positions at dh <= 32, 256 at dh <= 64).  Dropout inside attention is not provided (p = 0 only). */
+typedef struct {
+    int bs, nh, dh, tq, tk;
+    int q_ldt, q_ldb, k_ldt, k_ldb, v_ldt, v_ldb, o_ldt, o_ldb;
+    float scale;
+} caphn_attn_dims;
+int caphn_attention_supported(const caphn_attn_dims* d);
+int caphn_attention_fwd(const caphn_attn_dims* d, const float* q, const float* k, const float* v, const float* attn_mask,
+                        const unsigned char* key_padding, float* o, float* lse, caphn_stream_t stream);
+int caphn_attention_bwd(const caphn_attn_dims* d, const float* q, const float* k, const float* v, const float* attn_mask,
+                        const unsigned char* key_padding, const float* o, const float* lse, const float* d_o,
+                        float* dq, float* dk, float* dv, caphn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

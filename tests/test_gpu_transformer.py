@@ -1,0 +1,96 @@
+"""N4: LayerNorm and the multi-head attention core (caphn_layernorm_*, caphn_attention_*) against fp64 torch math."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import maxdiff
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from caphn import ops as o
+    return o
+
+
+@pytest.mark.parametrize("shape,eps", [((300, 256), 1e-5), ((7, 3, 100), 1e-12), ((33, 700), 1e-5), ((5, 64), 1e-5)])
+def test_layernorm_matches_torch(ops, shape, eps):
+    g = torch.Generator().manual_seed(sum(shape))
+    d = shape[-1]
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    dy = torch.randn(shape, generator=g)
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = F.layer_norm(x64, (d,), g64, b64, eps)
+    ref.backward(dy.double())
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), eps)
+    assert maxdiff(y.cpu().double(), ref.detach()) < 3e-6
+    dx, dg, db = ops.layernorm_bwd(x.to(DEV), gamma.to(DEV), mean, rstd, dy.to(DEV))
+    assert maxdiff(dx.cpu().double(), x64.grad) < 5e-6
+    rows = x.numel() // d
+    assert maxdiff(dg.cpu().double(), g64.grad) < 2e-6 * max(1.0, math.sqrt(rows))
+    assert maxdiff(db.cpu().double(), b64.grad) < 2e-6 * max(1.0, math.sqrt(rows))
+
+
+def _ref_attention(q, k, v, nh, attn_mask, kpm):
+    tq, bs, dm = q.shape
+    tk, dh = k.shape[0], dm // nh
+    qh = q.reshape(tq, bs, nh, dh).permute(1, 2, 0, 3)
+    kh = k.reshape(tk, bs, nh, dh).permute(1, 2, 0, 3)
+    vh = v.reshape(tk, bs, nh, dh).permute(1, 2, 0, 3)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(dh)
+    if attn_mask is not None:
+        s = s + attn_mask
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :].bool(), float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return (p @ vh).permute(2, 0, 1, 3).reshape(tq, bs, dm)
+
+
+@pytest.mark.parametrize("bs,nh,dh,tq,tk,causal,pad,packed", [
+    (3, 8, 32, 20, 49, False, True, False), (2, 8, 32, 33, 33, True, True, True), (2, 2, 64, 17, 130, False, False, False),
+    (1, 4, 20, 70, 70, True, False, True), (4, 8, 32, 128, 128, True, True, False)])
+def test_attention_core_matches_torch(ops, bs, nh, dh, tq, tk, causal, pad, packed):
+    g = torch.Generator().manual_seed(bs * 1000 + tq)
+    dm = nh * dh
+    if packed:                                   # q, k, v as slices of one packed projection, as in_proj produces them
+        assert tq == tk
+        qkv = torch.randn(tq, bs, 3 * dm, generator=g).to(DEV)
+        q, k, v = qkv[..., :dm], qkv[..., dm:2 * dm], qkv[..., 2 * dm:]
+    else:
+        q, k, v = (torch.randn(t, bs, dm, generator=g).to(DEV) for t in (tq, tk, tk))
+    mask = None
+    if causal:
+        mask = torch.full((tq, tk), float("-inf")).triu(1)
+    kpm = None
+    if pad:
+        kpm = torch.zeros(bs, tk, dtype=torch.bool)
+        for b in range(bs):
+            kpm[b, tk - 1 - 2 * b:] = True         # the first key is never padded: no fully masked row
+    d_o = torch.randn(tq, bs, dm, generator=g)
+    q64, k64, v64 = (t.detach().cpu().double().requires_grad_(True) for t in (q, k, v))
+    ref = _ref_attention(q64, k64, v64, nh, mask.double() if mask is not None else None, kpm)
+    ref.backward(d_o.double())
+    md = mask.to(DEV) if mask is not None else None
+    kd = kpm.to(torch.uint8).to(DEV) if kpm is not None else None
+    o, lse = ops.attention_fwd(q, k, v, nh, md, kd)
+    assert maxdiff(o.cpu().double(), ref.detach()) < 3e-6
+    dq, dk, dv = ops.attention_bwd(q, k, v, nh, md, kd, o, lse, d_o.to(DEV))
+    assert maxdiff(dq.cpu().double(), q64.grad) < 5e-6
+    assert maxdiff(dk.cpu().double(), k64.grad) < 5e-6
+    assert maxdiff(dv.cpu().double(), v64.grad) < 5e-6
+
+
+def test_attention_limits_are_reported(ops):
+    from caphn._lib import CaphnError
+    q = torch.randn(4, 1, 8 * 32, device=DEV)
+    k = torch.randn(600, 1, 8 * 32, device=DEV)
+    with pytest.raises(CaphnError):
+        ops.attention_fwd(q, k, k, 8)              # 600 keys of one head do not fit LDS
+    with pytest.raises(CaphnError):
+        ops.attention_fwd(q.cpu(), k.cpu(), k.cpu(), 8)
