@@ -179,3 +179,110 @@ def conv1x1(src, w, b):
     if not src.is_cuda:
         raise CaphnError("caphn conv1x1 runs on libcaphn's HIP kernels only (no CPU fallback)")
     return _Conv1x1Fn.apply(src.float(), w, b)
+
+
+def linear(x, w, b):
+    """x W^T + b over the last dimension (one-layer case of mlp; w / b may be row slices of a packed projection)."""
+    if not x.is_cuda:
+        raise CaphnError("caphn linear runs on libcaphn's HIP kernels only (no CPU fallback)")
+    return _MLPFn.apply(x.float(), 1, w, b)
+
+
+def ffn(x, w1, b1, w2, b2):
+    """linear2(relu(linear1(x)))   baseline/transformer.py:149,:213"""
+    if not x.is_cuda:
+        raise CaphnError("caphn ffn runs on libcaphn's HIP kernels only (no CPU fallback)")
+    return _MLPFn.apply(x.float(), 2, w1, b1, w2, b2)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        xc, gc = x.detach().contiguous(), gamma.detach().contiguous()
+        y, mean, rstd = ops.layernorm_fwd(xc, gc, beta.detach().contiguous(), eps)
+        ctx.save_for_backward(xc, gc, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(x, gamma, mean, rstd, dy.contiguous())
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps: float = 1e-5):
+    if not x.is_cuda:
+        raise CaphnError("caphn layer_norm runs on libcaphn's HIP kernels only (no CPU fallback)")
+    return _LayerNormFn.apply(x.float(), gamma, beta, eps)
+
+
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, nh, attn_mask, key_padding):
+        q, k, v = q.detach(), k.detach(), v.detach()
+        o, lse = ops.attention_fwd(q, k, v, nh, attn_mask, key_padding)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.nh, ctx.attn_mask, ctx.key_padding = nh, attn_mask, key_padding
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, lse = ctx.saved_tensors
+        dq, dk, dv = ops.attention_bwd(q, k, v, ctx.nh, ctx.attn_mask, ctx.key_padding, o, lse, d_o)
+        return dq, dk, dv, None, None, None
+
+
+def attention(q, k, v, nh: int, attn_mask=None, key_padding_mask=None):
+    """Multi-head softmax(q k^T / sqrt(dh) + masks) v on sequence-first [T, bs, d] tensors (the core of
+    nn.MultiheadAttention as baseline/transformer.py:137,197-199 calls it).  attn_mask: additive float [tq, tk];
+    key_padding_mask: bool [bs, tk], True = ignore."""
+    if not q.is_cuda:
+        raise CaphnError("caphn attention runs on libcaphn's HIP kernels only (no CPU fallback)")
+    am = attn_mask.to(device=q.device, dtype=torch.float32).contiguous() if attn_mask is not None else None
+    kp = key_padding_mask.to(device=q.device, dtype=torch.uint8).contiguous() if key_padding_mask is not None else None
+    return _AttentionFn.apply(q, k, v, nh, am, kp)
+
+
+class _AddFn(torch.autograd.Function):
+    """a + b (same shape, or b broadcast over dim 1 of a sequence-first tensor is NOT handled: expand first)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = a.detach().contiguous().clone()
+        ops.axpy_(out.view(-1), b.detach().contiguous().view(-1))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    if a.shape != b.shape:
+        b = b.expand_as(a)
+    return _AddFn.apply(a, b)
+
+
+class _EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, table, padding_idx):
+        flat = idx.reshape(-1).contiguous()
+        out = ops.embedding_gather(table.detach().contiguous(), flat)
+        ctx.save_for_backward(flat)
+        ctx.shape, ctx.padding_idx = table.shape, padding_idx
+        return out.view(*idx.shape, table.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        (flat,) = ctx.saved_tensors
+        dt = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        ops.embedding_scatter_add(g.reshape(-1, ctx.shape[1]).contiguous(), flat, dt)
+        if ctx.padding_idx is not None:
+            dt[ctx.padding_idx].zero_()                  # nn.Embedding(padding_idx=...): that row receives no gradient
+        return None, dt, None
+
+
+def embedding(idx, table, padding_idx=None):
+    if not table.is_cuda:
+        raise CaphnError("caphn embedding runs on libcaphn's HIP kernels only (no CPU fallback)")
+    return _EmbeddingFn.apply(idx.long(), table, padding_idx)

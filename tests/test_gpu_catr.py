@@ -92,3 +92,50 @@ def test_caption_wiring_and_no_cpu_path():
     assert all(p.grad is not None for p in net.input_proj.parameters()) and net.mlp.layers[0].weight.grad is not None
     with pytest.raises(CaphnError):
         HyperInputProj(16, 12, 10)(torch.randn(1, 16, 2, 2), torch.randn(10))
+
+
+@pytest.mark.parametrize("name", ["catr_prenorm", "catr_postnorm"])
+def test_transformer_matches_reference_vectors(name):
+    """PINNED: vectors from the reference's own baseline/transformer.py (fp64, dropout 0; tools/make_golden.py
+    --only-catr).  The reference's state_dict loads with strict=True; output and every gradient are compared."""
+    import json
+    import os
+    import numpy as np
+    from helpers import GOLDEN
+    from baseline.transformer import build_transformer
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    with open(os.path.join(GOLDEN, "meta.json")) as f:
+        m = json.load(f)[name]
+
+    class Cfg:
+        pad_token_id = 0; layer_norm_eps = 1e-12; dropout = 0.0
+    Cfg.hidden_dim, Cfg.nheads, Cfg.dim_feedforward = m["hidden_dim"], m["nheads"], m["dim_feedforward"]
+    Cfg.vocab_size, Cfg.max_position_embeddings = m["vocab_size"], m["max_position_embeddings"]
+    Cfg.enc_layers, Cfg.dec_layers, Cfg.pre_norm = m["enc_layers"], m["dec_layers"], m["pre_norm"]
+    net = build_transformer(Cfg)
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p/")}
+    net.load_state_dict(sd, strict=True)
+    assert sum(p.numel() for p in net.parameters()) == m["n_params"]
+    net = net.to(DEV)
+    src = torch.from_numpy(z["src"]).to(DEV).requires_grad_(True)
+    hs = net(src, torch.from_numpy(z["mask"]).to(DEV), torch.from_numpy(z["pos"]).to(DEV), torch.from_numpy(z["tgt"]).to(DEV),
+             torch.from_numpy(z["tgt_mask"]).to(DEV))
+    want = torch.from_numpy(z["hs"])
+    assert hs.shape == want.shape
+    assert maxdiff(hs.detach().cpu().double(), want.double()) < 2e-5
+    (hs * torch.from_numpy(z["R"]).to(DEV)).sum().backward()
+    assert maxdiff(src.grad.cpu().double(), torch.from_numpy(z["dsrc"]).double()) < 5e-5
+    worst = 0.0
+    for k, p in net.named_parameters():
+        g = torch.from_numpy(z["g/" + k]).double()
+        got = p.grad.cpu().double() if p.grad is not None else torch.zeros_like(g)
+        tol = 5e-5 * max(1.0, float(g.abs().max()))
+        assert maxdiff(got, g) < tol, (k, maxdiff(got, g), tol)
+        worst = max(worst, maxdiff(got, g))
+    net.train()
+    for mod in net.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.1
+    with pytest.raises(NotImplementedError):
+        net(src.detach(), torch.from_numpy(z["mask"]).to(DEV), torch.from_numpy(z["pos"]).to(DEV),
+            torch.from_numpy(z["tgt"]).to(DEV), torch.from_numpy(z["tgt_mask"]).to(DEV))

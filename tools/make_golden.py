@@ -519,11 +519,67 @@ PLAIN_CASES = {   # name: (dims, B, T, seed); E=12,H=10 -> head branches 2 and 1
     "plain_lstm_l2": (dict(E=12, H=10, V=9684, L=2, cell="lstm"), 3, 5, 73),
 }
 
+# --------------------------------------------------------------------------
+# N4: the reference's own baseline/transformer.py (pure torch, imported by path) on seeded inputs
+# --------------------------------------------------------------------------
+CATR_CASES = {   # name: (pre_norm, enc_layers, dec_layers, seed)
+    "catr_prenorm": (True, 2, 2, 91),
+    "catr_postnorm": (False, 1, 2, 92),
+}
+
+
+def catr_case(name, pre_norm, enc_layers, dec_layers, seed):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_catr_transformer", os.path.join(REF, "baseline", "transformer.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+
+    class Cfg:        # the fields baseline/transformer.py reads from baseline/configuration.py, at test size; dropout off
+        hidden_dim = 32; pad_token_id = 0; max_position_embeddings = 12; layer_norm_eps = 1e-12; dropout = 0.0
+        vocab_size = 50; nheads = 4; dim_feedforward = 64
+    Cfg.enc_layers, Cfg.dec_layers, Cfg.pre_norm = enc_layers, dec_layers, pre_norm
+    torch.manual_seed(seed)
+    net = ref.build_transformer(Cfg).double()
+    g = torch.Generator().manual_seed(seed + 1)
+    bs, h, w, T = 3, 3, 5, Cfg.max_position_embeddings
+    src = torch.randn(bs, Cfg.hidden_dim, h, w, generator=g, dtype=torch.float64)
+    pos = torch.randn(bs, Cfg.hidden_dim, h, w, generator=g, dtype=torch.float64)
+    mask = torch.zeros(bs, h, w, dtype=torch.bool)
+    mask[1, :, 4:] = True
+    mask[2, 2:, :] = True
+    tgt = torch.randint(1, Cfg.vocab_size, (bs, T), generator=g)
+    tgt_mask = torch.zeros(bs, T, dtype=torch.bool)
+    tgt[1, 9:] = 0; tgt_mask[1, 9:] = True
+    tgt[2, 5:] = 0; tgt_mask[2, 5:] = True
+    src.requires_grad_(True)
+    hs = net(src, mask, pos, tgt, tgt_mask)
+    R = torch.randn(hs.shape, generator=g, dtype=torch.float64)
+    (hs * R).sum().backward()
+    arrs = {"src": src.detach().float(), "pos": pos.float(), "mask": mask, "tgt": tgt, "tgt_mask": tgt_mask, "R": R.float(),
+            "hs": hs.detach(), "dsrc": src.grad}
+    for k, v in net.state_dict().items():
+        arrs["p/" + k] = v.float()
+    for k, v in net.named_parameters():
+        arrs["g/" + k] = v.grad if v.grad is not None else torch.zeros_like(v)
+    save_npz(os.path.join(OUT, name + ".npz"), **arrs)
+    return {"pre_norm": pre_norm, "enc_layers": enc_layers, "dec_layers": dec_layers, "hidden_dim": Cfg.hidden_dim, "nheads": Cfg.nheads,
+            "dim_feedforward": Cfg.dim_feedforward, "vocab_size": Cfg.vocab_size, "max_position_embeddings": T,
+            "n_params": int(sum(p.numel() for p in net.parameters())), "hs_abs_max": float(hs.abs().max())}
+
 
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     meta = {"torch": torch.__version__, "reference": "zacharie12/Hypernet-image-captioning @ /root/reference"}
+    if "--only-catr" in sys.argv:              # the CATR transformer vectors only
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        for nm, args in CATR_CASES.items():
+            meta[nm] = catr_case(nm, *args)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        print(json.dumps({k: meta[k] for k in CATR_CASES}, indent=1))
+        return
     if "--only-plain" in sys.argv:             # refresh the hypernet.py / later.py vectors only
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -555,6 +611,8 @@ def main():
     meta["gru_search"] = search_case("gru_search", tiny, n_images=6, P=7, seed=462, end_bump=SEARCH_END_BUMP, sharpen=SEARCH_SHARPEN)
     for nm, (dd, B, T, sd) in PLAIN_CASES.items():
         meta[nm] = plain_case(nm, O.PlainDims(**dd), B, T, sd)
+    for nm, args in CATR_CASES.items():
+        meta[nm] = catr_case(nm, *args)
     if os.environ.get("CAPHN_GOLDEN_FULL", "1") == "1":
         meta["gru_full"] = full_case("gru_full", seed=2024)
     with open(os.path.join(OUT, "meta.json"), "w") as f:
