@@ -177,9 +177,9 @@ class DecoderEmbeddings(nn.Module):
         return _ln(self.LayerNorm, e)
 
 
-def generate_square_subsequent_mask(sz):
+def generate_square_subsequent_mask(sz, device=None):
     """0 on and below the diagonal, -inf above (baseline/transformer.py:319-326)."""
-    return torch.full((sz, sz), float("-inf")).triu(1)
+    return torch.full((sz, sz), float("-inf"), device=device).triu(1)
 
 
 class Transformer(nn.Module):
@@ -195,6 +195,7 @@ class Transformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
         self.d_model, self.nhead = d_model, nhead
+        self._causal = {}                                    # (length, device) -> mask, built on the device once
 
     def forward(self, src, mask, pos_embed, tgt, tgt_mask):
         """src [bs, C, H, W] (projected backbone features), mask [bs, H, W] bool (True = padding), pos_embed like src,
@@ -208,8 +209,12 @@ class Transformer(nn.Module):
         ids = torch.arange(table.shape[0], dtype=torch.long, device=table.device).unsqueeze(1).expand(-1, bs)
         query_embed = CF.embedding(ids, table)
         memory = self.encoder(src, src_key_padding_mask=mask, pos=pos_embed)
+        key = (len(tgt), tgt.device)
+        causal = self._causal.get(key)
+        if causal is None:
+            causal = self._causal[key] = generate_square_subsequent_mask(len(tgt), tgt.device)
         return self.decoder(tgt, memory, memory_key_padding_mask=mask, tgt_key_padding_mask=tgt_mask, pos=pos_embed,
-                            query_pos=query_embed, tgt_mask=generate_square_subsequent_mask(len(tgt)).to(tgt.device))
+                            query_pos=query_embed, tgt_mask=causal)
 
 
 def build_transformer(config):

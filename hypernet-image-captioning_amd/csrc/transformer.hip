@@ -87,9 +87,15 @@ struct AttnArgs {
     const float* attn_mask; const unsigned char* key_padding;
     float* out0; float* out1;          // fwd: o, lse   dq: dq, -   dkv: dk, dv
     const float* lse; const float* D;  // backward inputs
-    int side;                          // rows of the LDS-resident side (tk for fwd / dq, tq for dkv)
+    int rpb;                           // rows of the wave side per block
 };
-constexpr int RPB = 16;                // rows of the wave side per block
+// Every block stages the whole LDS side of its (batch, head) (32 KB at 128 positions), so the wave side should not be cut
+// finer than the chip needs: 16 rows per block made the staging the dominant cost (attention 7.7 ms of a 34 ms CATR step)
+inline int attn_rows_per_block(int bh, int rows) {
+    int rpb = 64;
+    while (rpb > 8 && (long)bh * ((rows + rpb - 1) / rpb) < 1024) rpb >>= 1;
+    return rpb;
+}
 
 __device__ __forceinline__ size_t at(int t, int b, int h, int ldt, int ldb, int dh) { return (size_t)t * ldt + (size_t)b * ldb + (size_t)h * dh; }
 
@@ -120,8 +126,8 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnArgs a) {
         Vs[j * (DH + 1) + e] = ok ? a.v[at(j, b, h, d.v_ldt, d.v_ldb, d.dh) + e] : 0.f;
     }
     __syncthreads();
-    const int r_end = min(d.tq, (int)(blockIdx.x + 1) * RPB);
-    for (int r = blockIdx.x * RPB + wave; r < r_end; r += 4) {
+    const int r_end = min(d.tq, (int)(blockIdx.x + 1) * a.rpb);
+    for (int r = blockIdx.x * a.rpb + wave; r < r_end; r += 4) {
         float qr[DH], gr[DH];
         const float* qp = a.q + at(r, b, h, d.q_ldt, d.q_ldb, d.dh);
 #pragma unroll
@@ -196,8 +202,8 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(AttnArgs a) {
         D_s[r] = s; lse_s[r] = a.lse[(size_t)bh * tq + r];
     }
     __syncthreads();
-    const int j_end = min(d.tk, (int)(blockIdx.x + 1) * RPB);
-    for (int j = blockIdx.x * RPB + wave; j < j_end; j += 4) {
+    const int j_end = min(d.tk, (int)(blockIdx.x + 1) * a.rpb);
+    for (int j = blockIdx.x * a.rpb + wave; j < j_end; j += 4) {
         float kr[DH], vr[DH];
         const float* kp = a.k + at(j, b, h, d.k_ldt, d.k_ldb, d.dh);
         const float* vp = a.v + at(j, b, h, d.v_ldt, d.v_ldb, d.dh);
@@ -284,7 +290,8 @@ extern "C" int caphn_attention_fwd(const caphn_attn_dims* d, const float* q, con
     const size_t lds = attn_q_lds(d->tk, DH);
     if (lds > ATTN_LDS_MAX) return CAPHN_EINVAL;
     AttnArgs a{}; a.d = *d; a.q = q; a.k = k; a.v = v; a.attn_mask = attn_mask; a.key_padding = key_padding; a.out0 = o; a.out1 = lse;
-    const dim3 grid((d->tq + RPB - 1) / RPB, d->bs * d->nh);
+    a.rpb = attn_rows_per_block(d->bs * d->nh, d->tq);
+    const dim3 grid((d->tq + a.rpb - 1) / a.rpb, d->bs * d->nh);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return DH == 32 ? launch_attn(attn_q_kernel<32, 0>, grid, lds, a, s) : launch_attn(attn_q_kernel<64, 0>, grid, lds, a, s);
 }
@@ -298,10 +305,12 @@ extern "C" int caphn_attention_bwd(const caphn_attn_dims* d, const float* q, con
     AttnArgs a{}; a.d = *d; a.q = q; a.k = k; a.v = v; a.o = o; a.dO = d_o; a.lse = lse; a.attn_mask = attn_mask; a.key_padding = key_padding;
     hipStream_t s = static_cast<hipStream_t>(stream);
     a.out0 = dq; a.out1 = nullptr;
-    const dim3 gq((d->tq + RPB - 1) / RPB, d->bs * d->nh);
+    a.rpb = attn_rows_per_block(d->bs * d->nh, d->tq);
+    const dim3 gq((d->tq + a.rpb - 1) / a.rpb, d->bs * d->nh);
     int rc = DH == 32 ? launch_attn(attn_q_kernel<32, 1>, gq, lq, a, s) : launch_attn(attn_q_kernel<64, 1>, gq, lq, a, s);
     if (rc != CAPHN_OK) return rc;
     a.out0 = dk; a.out1 = dv;
-    const dim3 gk((d->tk + RPB - 1) / RPB, d->bs * d->nh);
+    a.rpb = attn_rows_per_block(d->bs * d->nh, d->tk);
+    const dim3 gk((d->tk + a.rpb - 1) / a.rpb, d->bs * d->nh);
     return DH == 32 ? launch_attn(attn_kv_kernel<32>, gk, lkv, a, s) : launch_attn(attn_kv_kernel<64>, gk, lkv, a, s);
 }

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 at its per-GPU share (bs = 512 / 8 = 64): Caption = generated 1x1 projection -> 6+6 pre-norm
+transformer (d 256, 8 heads, ff 2048) -> MLP head over 30522 tokens, T = 128, cross entropy; forward + backward
+through the drop-in modules (module API: the loss and the optimiser stay the caller's).  Side measurement for DESIGN.md."""
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "hypernet-image-captioning_amd"))
+from baseline.caption import Caption  # noqa: E402
+from baseline.configuration import Config  # noqa: E402
+from baseline.transformer import build_transformer  # noqa: E402
+
+
+class Backbone(torch.nn.Module):
+    """precomputed ResNet feature maps stand where the backbone goes (the trunk is out of scope)."""
+
+    def forward(self, samples):
+        src, pos = samples
+        return [(src, torch.zeros(src.shape[0], src.shape[2], src.shape[3], dtype=torch.bool, device=src.device))], [pos]
+
+
+def main():
+    dev = "cuda"
+    torch.manual_seed(0)
+    bs = int(os.environ.get("CATR_BS", "64"))
+    hw = int(os.environ.get("CATR_HW", "7"))
+    cfg = Config(dropout=0.0)
+    net = Caption(Backbone(), build_transformer(cfg), cfg.hidden_dim, cfg.vocab_size, hyper_emb=10).to(dev)
+    n_tr = sum(p.numel() for p in net.transformer.parameters())
+    n_hy = sum(p.numel() for p in net.input_proj.parameters())
+    print(f"transformer {n_tr/1e6:.1f} M, MLP {sum(p.numel() for p in net.mlp.parameters())/1e6:.1f} M, projection hypernet {n_hy/1e6:.1f} M parameters")
+    src = torch.randn(bs, 2048, hw, hw, device=dev)
+    pos = torch.randn(bs, cfg.hidden_dim, hw, hw, device=dev)
+    T = cfg.max_position_embeddings
+    tgt = torch.randint(1, cfg.vocab_size, (bs, T), device=dev)
+    tmask = torch.zeros(bs, T, dtype=torch.bool, device=dev)
+    x = torch.zeros(10, device=dev); x[3] = 1.0
+
+    def step():
+        for p in net.parameters():
+            p.grad = None
+        out = net((src, pos), tgt, tmask, x)
+        loss = F.cross_entropy(out.reshape(-1, cfg.vocab_size), tgt.reshape(-1))
+        loss.backward()
+        return loss
+
+    for _ in range(2):
+        loss = step()
+    torch.cuda.synchronize()
+    n = 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"bs {bs}, {hw}x{hw} positions, T {T}: forward+backward {dt*1e3:.1f} ms = {bs/dt:.0f} img/s; loss {float(loss.detach()):.4f}; "
+          f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+
+
+if __name__ == "__main__":
+    main()
