@@ -1,0 +1,48 @@
+"""torch.optim.Adam's update on libcaphn (caphn_adam_dense_f32), for models that run through the module API
+(CATR: cc_train_catr.py:56-61 builds Adam over every parameter).  Same constructor surface for the arguments the
+reference uses (params, lr, betas, eps); state lives in plain tensors next to each parameter."""
+from typing import Iterable, Optional
+
+import torch
+
+from . import ops
+from ._lib import CaphnError
+
+
+class FusedAdam:
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 max_norm: Optional[float] = None):
+        """max_norm: torch.nn.utils.clip_grad_norm_(params, max_norm) over all gradients before the update."""
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FusedAdam got no trainable parameters")
+        for p in self.params:
+            if not p.is_cuda or p.dtype != torch.float32:
+                raise CaphnError("FusedAdam needs fp32 parameters on a CUDA(HIP) device (there is no CPU fallback)")
+        self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
+        self.step_count = 0
+        dev = self.params[0].device
+        self.m = [torch.zeros_like(p.data) for p in self.params]
+        self.v = [torch.zeros_like(p.data) for p in self.params]
+        self._one = torch.tensor([1.0, 0.0], dtype=torch.float32, device=dev)
+        self._coef = torch.zeros(2, dtype=torch.float32, device=dev)
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                ops.zero_(p.grad.view(-1))
+
+    def step(self):
+        self.step_count += 1
+        live = [(p, m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
+        coef = self._one
+        if self.max_norm is not None:
+            parts = torch.cat([ops.sumsq_partials(p.grad.contiguous().view(-1)) for p, _, _ in live])
+            coef = ops.clip_coef(parts, None, self.max_norm, 1.0, out=self._coef)
+        for p, m, v in live:
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            if not p.data.is_contiguous():
+                raise CaphnError("FusedAdam needs contiguous parameters")
+            ops.adam_dense(p.data.view(-1), m.view(-1), v.view(-1), g.view(-1), coef, self.lr, self.step_count, self.betas, self.eps)

@@ -139,3 +139,25 @@ def test_transformer_matches_reference_vectors(name):
     with pytest.raises(NotImplementedError):
         net(src.detach(), torch.from_numpy(z["mask"]).to(DEV), torch.from_numpy(z["pos"]).to(DEV),
             torch.from_numpy(z["tgt"]).to(DEV), torch.from_numpy(z["tgt_mask"]).to(DEV))
+
+
+@pytest.mark.parametrize("max_norm", [None, 0.1])
+def test_fused_adam_matches_torch_adam(max_norm):
+    """caphn.optim.FusedAdam (cc_train_catr.py:56-61: Adam over every parameter) against torch.optim.Adam
+    (+ clip_grad_norm_) on the same gradients, three steps."""
+    from caphn.optim import FusedAdam
+    g = torch.Generator().manual_seed(9)
+    shapes = [(37, 5), (300,), (64, 64), (1,), (2049,)]
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    opt_a, opt_b = FusedAdam(pa, lr=1e-2, max_norm=max_norm), torch.optim.Adam(pb, lr=1e-2)
+    for _ in range(3):
+        grads = [torch.randn(s, generator=g).to(DEV) * 0.05 for s in shapes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        pa[3].grad = None; pb[3].grad = None                   # a parameter without gradient is skipped by both
+        if max_norm is not None:
+            torch.nn.utils.clip_grad_norm_(pb, max_norm)
+        opt_a.step(); opt_b.step()
+    for p, q in zip(pa, pb):
+        assert maxdiff(p.detach().cpu(), q.detach().cpu()) < 2e-6

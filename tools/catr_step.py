@@ -41,12 +41,17 @@ def main():
     tmask = torch.zeros(bs, T, dtype=torch.bool, device=dev)
     x = torch.zeros(10, device=dev); x[3] = 1.0
 
+    from caphn.optim import FusedAdam
+    opt = FusedAdam(net.parameters(), lr=1e-4)               # cc_train_catr.py:56-61: Adam over every parameter
+    with_opt = os.environ.get("CATR_OPT", "1") == "1"
+
     def step():
-        for p in net.parameters():
-            p.grad = None
+        opt.zero_grad()
         out = net((src, pos), tgt, tmask, x)
         loss = F.cross_entropy(out.reshape(-1, cfg.vocab_size), tgt.reshape(-1))
         loss.backward()
+        if with_opt:
+            opt.step()
         return loss
 
     for _ in range(2):
@@ -58,7 +63,8 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print(f"bs {bs}, {hw}x{hw} positions, T {T}: forward+backward {dt*1e3:.1f} ms = {bs/dt:.0f} img/s; loss {float(loss.detach()):.4f}; "
+    what = "forward+backward+Adam" if with_opt else "forward+backward"
+    print(f"bs {bs}, {hw}x{hw} positions, T {T}: {what} {dt*1e3:.1f} ms = {bs/dt:.0f} img/s; loss {float(loss.detach()):.4f}; "
           f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
 
 
