@@ -64,6 +64,16 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     what = "forward+backward+Adam" if with_opt else "forward+backward"
+    # algorithmic matrix work of one forward (multiply-add = 2 flop), x3 for forward + both backward contractions
+    d, ff, V, S, rows_t, rows_s = cfg.hidden_dim, cfg.dim_feedforward, cfg.vocab_size, hw * hw, bs * T, bs * hw * hw
+    dh = d // cfg.nheads
+    enc = cfg.enc_layers * (4 * rows_s * d * d + 2 * rows_s * d * ff + 2 * rows_s * S * d) * 2
+    dec = cfg.dec_layers * (6 * rows_t * d * d + 2 * rows_s * d * d + 2 * rows_t * d * ff + 2 * rows_t * T * d + 2 * rows_t * S * d) * 2
+    head = (rows_t * d * 512 + rows_t * 512 * 512 + rows_t * 512 * V) * 2 + rows_s * 2048 * d * 2
+    flops = 3.0 * (enc + dec + head)
+    print(f"matrix work {flops/1e12:.2f} TFLOP per step (fp32) -> {flops/dt/1e12:.1f} TFLOP/s = {flops/dt/157.3e12:.2f} of the 157.3 TFLOP/s "
+          f"fp32 MFMA peak (each fp32 product is 6 bf16 MFMA products here: {6*flops/dt/1e12:.0f} TFLOP/s of bf16 work, "
+          f"{6*flops/dt/2.5e15:.2f} of the 2.5 PFLOP/s bf16 peak)")
     print(f"bs {bs}, {hw}x{hw} positions, T {T}: {what} {dt*1e3:.1f} ms = {bs/dt:.0f} img/s; loss {float(loss.detach()):.4f}; "
           f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
 
