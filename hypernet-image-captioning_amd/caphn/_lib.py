@@ -92,6 +92,7 @@ SIGNATURES = {
     "caphn_zero_f32": (C.c_int, [c_fp, C.c_size_t, c_fp]),
     "caphn_axpy_f32": (C.c_int, [C.c_size_t, C.c_float, c_fp, c_fp, c_fp]),
     "caphn_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "caphn_linear_wgrad_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]),
     "caphn_colsum_f32": (C.c_int, [C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]),
     "caphn_hyper_acts_floats": (C.c_int, [C.POINTER(HyperDesc)]),
     "caphn_hyper_forward": (C.c_int, [C.POINTER(HyperDesc), c_fp, c_fp, c_fp, c_fp]),

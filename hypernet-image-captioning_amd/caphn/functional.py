@@ -128,8 +128,7 @@ class _MLPFn(torch.autograd.Function):
         dx = None
         for i in range(n - 1, -1, -1):
             a = acts[i]                                   # input of layer i (post-ReLU output of layer i-1 for i > 0)
-            grads[2 * i] = ops.gemm(dz, a, ta=True, splitk=max(1, min(16, a.shape[0] // 256)))
-            grads[2 * i + 1] = ops.colsum(dz)
+            grads[2 * i], grads[2 * i + 1] = ops.linear_wgrad(dz, a)
             if i > 0:
                 dz = ops.gemm(dz, ws[i], mask=a)          # zero where the ReLU clamped
             elif ctx.need_x:
@@ -167,8 +166,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         bs, cin, h, wd = ctx.shape
         dz = dy.permute(0, 2, 3, 1).reshape(-1, w.shape[0]).contiguous()
-        dw = ops.gemm(dz, x, ta=True, splitk=max(1, min(16, x.shape[0] // 256)))
-        db = ops.colsum(dz)
+        dw, db = ops.linear_wgrad(dz, x)
         dx = None
         if ctx.need_x:
             dx = ops.gemm(dz, w).view(bs, h, wd, cin).permute(0, 3, 1, 2)

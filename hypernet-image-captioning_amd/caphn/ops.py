@@ -60,6 +60,20 @@ def axpy_(y: torch.Tensor, x: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
     return y
 
 
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor):
+    """(dW [M,N], db [M]) of y = x W^T + b from dy [K,M] and x [K,N] in one launch (bias gradient fused into the
+    weight-gradient GEMM)."""
+    lib = L.load()
+    K, M = dy.shape
+    N = x.shape[1]
+    assert x.shape[0] == K and dy.stride(1) == 1 and x.stride(1) == 1
+    dw, db = _f32(M, N, device=dy.device), _f32(M, device=dy.device)
+    ws = torch.empty(lib.caphn_colsum_workspace_bytes(K, M), dtype=torch.uint8, device=dy.device)
+    L.check(lib.caphn_linear_wgrad_f32(M, N, K, L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(dw), N, L.ptr(db),
+                                       C.c_void_p(ws.data_ptr()), L.stream_ptr()), "caphn_linear_wgrad_f32")
+    return dw, db
+
+
 def colsum(a: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = L.load()
     M, N = a.shape

@@ -692,3 +692,12 @@ extern "C" int caphn_decoder_search_result(const caphn_decoder_dims* d, const ca
     const SearchArgs sa = search_args(d, c, w, static_cast<float*>(ws_), static_cast<char*>(sws_));
     return caphn_launch_search_result(sa, steps_done, seqs, lengths, scores, finished, n_active, static_cast<hipStream_t>(stream));
 }
+
+// nn.Linear's parameter gradients in one pass: dW [M, N] = dY^T X, db [M] = column sums of dY (dY [K, M], X [K, N]).  The bias
+// gradient rides in the weight-gradient GEMM's n-tile-0 workgroups (it is the column sum of an operand that is staged anyway).
+extern "C" int caphn_linear_wgrad_f32(int M, int N, int K, const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw,
+                                      float* db, void* ws, caphn_stream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !dY || !X || !dW || !db || !ws) return CAPHN_EINVAL;
+    return caphn_gemm_tn_colsum(M, N, K, dY, ldy, X, ldx, dW, ldw, db, pick_splitk(M, N, K), nullptr, ws, false,
+                                static_cast<hipStream_t>(stream));
+}

@@ -66,6 +66,10 @@ int caphn_zero_f32(float* p, size_t n, caphn_stream_t stream);
 /* y[0..n) += alpha * x[0..n): sums the gradients of parameters that are views of one theta range (utils.py:62-68: every
    child module restarts at offset 0, so hypernet.py's extra layers alias the first cell's slices). */
 int caphn_axpy_f32(size_t n, float alpha, const float* x, float* y, caphn_stream_t stream);
+/* nn.Linear's parameter gradients in one launch: dW[M,N] = dY^T X and db[M] = column sums of dY, with dY [K,M] (ldy) and
+   X [K,N] (ldx).  ws: caphn_colsum_workspace_bytes(K, M).  Split-K is chosen from the shape. */
+int caphn_linear_wgrad_f32(int M, int N, int K, const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw,
+                           float* db, void* ws, caphn_stream_t stream);
 /* out[n] = sum_m A[m,n]  (bias gradients).  ws: caphn_colsum_workspace_bytes(M,N). */
 size_t caphn_colsum_workspace_bytes(int M, int N);
 int caphn_colsum_f32(int M, int N, const float* A, int lda, float* out, void* ws, caphn_stream_t stream);
