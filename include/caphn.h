@@ -387,7 +387,7 @@ int caphn_layernorm_bwd(int rows, int d, const float* x, const float* gamma, con
  * dq / dk / dv those of q / k / v.  attn_mask: additive [tq, tk] (-inf = masked) or NULL; key_padding: [bs, tk] bytes,
  * non-zero = ignore, or NULL.  lse [bs*nh, tq] (log-sum-exp per row) links forward and backward.  A row with every key masked
  * yields zeros (torch yields NaN).  Limits: caphn_attention_supported() (the K/V or Q/dO side of one (batch, head) must fit LDS:
- * 512 positions at dh <= 32, 256 at dh <= 64).  Dropout inside attention is not provided (p = 0 only). */
+ * about 440 positions at dh <= 32, 200 at dh <= 64).  Dropout inside attention is not provided (p = 0 only). */
 typedef struct {
     int bs, nh, dh, tq, tk;
     int q_ldt, q_ldb, k_ldt, k_ldb, v_ldt, v_ldb, o_ldt, o_ldb;
