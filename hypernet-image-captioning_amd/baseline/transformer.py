@@ -5,9 +5,10 @@ core through caphn_layernorm_* / caphn_attention_*, residuals through caphn_axpy
 through caphn_embedding_*.  nn.MultiheadAttention / nn.LayerNorm / nn.Linear objects are kept as parameter containers
 only (that is what makes the state_dict identical); their forward is never called.
 
-Differences from the reference: dropout must be inactive (p = 0 or eval()): a dropout mask is torch's RNG stream and
-cannot be reproduced -- the fused HIP path of this repository is deterministic teacher-forced training, as for the
-recurrent captioners; `activation` is 'relu' only; one (batch, head) side of an attention must fit LDS
+Differences from the reference: in training mode the dropout masks (residual branches, feed-forward, embeddings and the
+attention probabilities inside nn.MultiheadAttention) come from libcaphn's counter-based hash (caphn_dropout_f32,
+caphn_attn_dims.dropout_p), not from torch's Philox stream: the same regulariser, element-wise different masks, so
+parity with the reference is pinned with dropout off and only statistical with it on; `activation` is 'relu' only; one (batch, head) side of an attention must fit LDS
 (caphn_attention_supported: 512 positions at 32-wide heads).
 Pinned by tests/golden/catr_*.npz, generated from the reference's own classes (tools/make_golden.py --only-catr).
 """
@@ -19,14 +20,12 @@ from torch import nn
 from caphn import functional as CF
 
 
-def _no_dropout(mod: nn.Module, p: float):
-    if p > 0.0 and mod.training:
-        raise NotImplementedError("dropout is not fused (its mask is torch's RNG stream): build with dropout=0.0 or call eval()")
+def _drop(d: nn.Dropout, x):
+    return CF.dropout(x, d.p, d.training)
 
 
 def _mha(m: nn.MultiheadAttention, query, key, value, attn_mask=None, key_padding_mask=None):
     """What m(query, key, value, attn_mask=..., key_padding_mask=...)[0] returns   (baseline/transformer.py:137,197-199)."""
-    _no_dropout(m, m.dropout)
     d = m.embed_dim
     w, b = m.in_proj_weight, m.in_proj_bias
     if query is key:                                         # q = k = x + pos: one packed projection, used in place
@@ -35,7 +34,7 @@ def _mha(m: nn.MultiheadAttention, query, key, value, attn_mask=None, key_paddin
     else:
         q, k = CF.linear(query, w[:d], b[:d]), CF.linear(key, w[d:2 * d], b[d:2 * d])
     v = CF.linear(value, w[2 * d:], b[2 * d:])
-    o = CF.attention(q, k, v, m.num_heads, attn_mask, key_padding_mask)
+    o = CF.attention(q, k, v, m.num_heads, attn_mask, key_padding_mask, dropout_p=m.dropout if m.training else 0.0)
     return CF.linear(o, m.out_proj.weight, m.out_proj.bias)
 
 
@@ -63,18 +62,18 @@ class TransformerEncoderLayer(nn.Module):
         self.normalize_before = normalize_before
 
     def _ffn(self, x):
-        return CF.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
+        return CF.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                      dropout_p=self.dropout.p if self.training else 0.0)
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None, pos=None):
-        _no_dropout(self, self.dropout.p)
         if self.normalize_before:                            # baseline/transformer.py:157-168
             x = _ln(self.norm1, src)
             qk = _with_pos(x, pos)
-            src = CF.add(src, _mha(self.self_attn, qk, qk, x, src_mask, src_key_padding_mask))
-            return CF.add(src, self._ffn(_ln(self.norm2, src)))
+            src = CF.add(src, _drop(self.dropout1, _mha(self.self_attn, qk, qk, x, src_mask, src_key_padding_mask)))
+            return CF.add(src, _drop(self.dropout2, self._ffn(_ln(self.norm2, src))))
         qk = _with_pos(src, pos)                             # :143-155
-        src = _ln(self.norm1, CF.add(src, _mha(self.self_attn, qk, qk, src, src_mask, src_key_padding_mask)))
-        return _ln(self.norm2, CF.add(src, self._ffn(src)))
+        src = _ln(self.norm1, CF.add(src, _drop(self.dropout1, _mha(self.self_attn, qk, qk, src, src_mask, src_key_padding_mask))))
+        return _ln(self.norm2, CF.add(src, _drop(self.dropout2, self._ffn(src))))
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -96,25 +95,25 @@ class TransformerDecoderLayer(nn.Module):
         self.normalize_before = normalize_before
 
     def _ffn(self, x):
-        return CF.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
+        return CF.ffn(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                      dropout_p=self.dropout.p if self.training else 0.0)
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, query_pos=None):
-        _no_dropout(self, self.dropout.p)
         mem_k = _with_pos(memory, pos)
         if self.normalize_before:                            # baseline/transformer.py:229-249
             x = _ln(self.norm1, tgt)
             qk = _with_pos(x, query_pos)
-            tgt = CF.add(tgt, _mha(self.self_attn, qk, qk, x, tgt_mask, tgt_key_padding_mask))
+            tgt = CF.add(tgt, _drop(self.dropout1, _mha(self.self_attn, qk, qk, x, tgt_mask, tgt_key_padding_mask)))
             x = _ln(self.norm2, tgt)
-            tgt = CF.add(tgt, _mha(self.multihead_attn, _with_pos(x, query_pos), mem_k, memory, memory_mask,
-                                   memory_key_padding_mask))
-            return CF.add(tgt, self._ffn(_ln(self.norm3, tgt)))
+            tgt = CF.add(tgt, _drop(self.dropout2, _mha(self.multihead_attn, _with_pos(x, query_pos), mem_k, memory, memory_mask,
+                                                         memory_key_padding_mask)))
+            return CF.add(tgt, _drop(self.dropout3, self._ffn(_ln(self.norm3, tgt))))
         qk = _with_pos(tgt, query_pos)                       # :205-227
-        tgt = _ln(self.norm1, CF.add(tgt, _mha(self.self_attn, qk, qk, tgt, tgt_mask, tgt_key_padding_mask)))
-        tgt = _ln(self.norm2, CF.add(tgt, _mha(self.multihead_attn, _with_pos(tgt, query_pos), mem_k, memory, memory_mask,
-                                               memory_key_padding_mask)))
-        return _ln(self.norm3, CF.add(tgt, self._ffn(tgt)))
+        tgt = _ln(self.norm1, CF.add(tgt, _drop(self.dropout1, _mha(self.self_attn, qk, qk, tgt, tgt_mask, tgt_key_padding_mask))))
+        tgt = _ln(self.norm2, CF.add(tgt, _drop(self.dropout2, _mha(self.multihead_attn, _with_pos(tgt, query_pos), mem_k, memory,
+                                                                    memory_mask, memory_key_padding_mask))))
+        return _ln(self.norm3, CF.add(tgt, _drop(self.dropout3, self._ffn(tgt))))
 
 
 def _get_clones(module, n):
@@ -169,12 +168,11 @@ class DecoderEmbeddings(nn.Module):
         self.dropout = nn.Dropout(config.dropout)
 
     def forward(self, x):
-        _no_dropout(self, self.dropout.p)
         bs, seq = x.shape
         position_ids = torch.arange(seq, dtype=torch.long, device=x.device).unsqueeze(0).expand(bs, seq)
         e = CF.add(CF.embedding(x, self.word_embeddings.weight, self.word_embeddings.padding_idx),
                    CF.embedding(position_ids, self.position_embeddings.weight))
-        return _ln(self.LayerNorm, e)
+        return _drop(self.dropout, _ln(self.LayerNorm, e))
 
 
 def generate_square_subsequent_mask(sz, device=None):

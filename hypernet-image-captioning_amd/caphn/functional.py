@@ -103,11 +103,12 @@ def plain_decoder_forward(dims: ops.PlainDims, features, captions, h0, c0, named
 
 
 class _MLPFn(torch.autograd.Function):
-    """x -> Linear, ReLU, ..., Linear over the last dimension (baseline/caption.py:34-47) as one node, so that the ReLU
+    """x -> Linear, ReLU, [Dropout,] ..., Linear over the last dimension (baseline/caption.py:34-47; with dropout the
+    feed-forward block linear2(dropout(relu(linear1(x)))) of baseline/transformer.py:149,:213) as one node, so that the ReLU
     gradients are the mask epilogue of the input-gradient contractions (CAPHN_GEMM_MASK) and nothing runs outside libcaphn."""
 
     @staticmethod
-    def forward(ctx, x, n_layers, *params):
+    def forward(ctx, x, n_layers, drop_p, seed, *params):
         h = x.detach().reshape(-1, x.shape[-1]).contiguous()
         acts, ws = [h], []
         for i in range(n_layers):
@@ -115,26 +116,31 @@ class _MLPFn(torch.autograd.Function):
             h = ops.gemm(h, w, tb=True, bias=b, relu=i < n_layers - 1)
             ws.append(w)
             if i < n_layers - 1:
+                if drop_p > 0.0:
+                    h = ops.dropout(h, drop_p, seed, offset=i << 40, out=h)      # zero where dropped OR clamped: still the ReLU mask
                 acts.append(h)
-        ctx.acts, ctx.ws, ctx.xshape, ctx.need_x = acts, ws, x.shape, x.requires_grad
+        ctx.acts, ctx.ws, ctx.xshape, ctx.need_x, ctx.drop = acts, ws, x.shape, x.requires_grad, (drop_p, seed)
         return h.view(*x.shape[:-1], h.shape[-1])
 
     @staticmethod
     def backward(ctx, dy):
         acts, ws = ctx.acts, ctx.ws
+        drop_p, seed = ctx.drop
         n = len(ws)
         dz = dy.reshape(-1, ws[-1].shape[0]).contiguous()
         grads = [None] * (2 * n)
         dx = None
         for i in range(n - 1, -1, -1):
-            a = acts[i]                                   # input of layer i (post-ReLU output of layer i-1 for i > 0)
+            a = acts[i]                                   # input of layer i (post-ReLU [post-dropout] output of layer i-1 for i > 0)
             grads[2 * i], grads[2 * i + 1] = ops.linear_wgrad(dz, a)
             if i > 0:
-                dz = ops.gemm(dz, ws[i], mask=a)          # zero where the ReLU clamped
+                dz = ops.gemm(dz, ws[i], mask=a)          # zero where the ReLU clamped (or the unit was dropped)
+                if drop_p > 0.0:
+                    dz = ops.dropout(dz, drop_p, seed, offset=(i - 1) << 40, out=dz)     # the kept units' 1 / (1 - p)
             elif ctx.need_x:
                 dx = ops.gemm(dz, ws[0]).view(ctx.xshape)
         ctx.acts = ctx.ws = None
-        return (dx, None) + tuple(grads)
+        return (dx, None, None, None) + tuple(grads)
 
 
 def mlp(x, layers):
@@ -144,7 +150,7 @@ def mlp(x, layers):
     params = []
     for l in layers:
         params += [l.weight, l.bias]
-    return _MLPFn.apply(x.float(), len(layers), *params)
+    return _MLPFn.apply(x.float(), len(layers), 0.0, 0, *params)
 
 
 class _Conv1x1Fn(torch.autograd.Function):
@@ -183,14 +189,16 @@ def linear(x, w, b):
     """x W^T + b over the last dimension (one-layer case of mlp; w / b may be row slices of a packed projection)."""
     if not x.is_cuda:
         raise CaphnError("caphn linear runs on libcaphn's HIP kernels only (no CPU fallback)")
-    return _MLPFn.apply(x.float(), 1, w, b)
+    return _MLPFn.apply(x.float(), 1, 0.0, 0, w, b)
 
 
-def ffn(x, w1, b1, w2, b2):
-    """linear2(relu(linear1(x)))   baseline/transformer.py:149,:213"""
+def ffn(x, w1, b1, w2, b2, dropout_p: float = 0.0, seed=None):
+    """linear2(dropout(relu(linear1(x))))   baseline/transformer.py:149,:213"""
     if not x.is_cuda:
         raise CaphnError("caphn ffn runs on libcaphn's HIP kernels only (no CPU fallback)")
-    return _MLPFn.apply(x.float(), 2, w1, b1, w2, b2)
+    if dropout_p > 0.0 and seed is None:
+        seed = next_seed()
+    return _MLPFn.apply(x.float(), 2, float(dropout_p), int(seed or 0), w1, b1, w2, b2)
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -214,31 +222,63 @@ def layer_norm(x, gamma, beta, eps: float = 1e-5):
     return _LayerNormFn.apply(x.float(), gamma, beta, eps)
 
 
+_seed_state = {"n": 0}
+
+
+def next_seed() -> int:
+    """A fresh 64-bit dropout seed: torch's initial seed (so torch.manual_seed makes runs repeatable) + a call counter."""
+    _seed_state["n"] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_state["n"] * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return ops.dropout(x.detach(), p, seed)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.dropout(g, ctx.p, ctx.seed), None, None
+
+
+def dropout(x, p: float, training: bool = True, seed=None):
+    """nn.Dropout: identity unless training and p > 0.  The mask comes from libcaphn's counter-based hash, not from torch's
+    generator (statistically the same regulariser; element-wise different from the reference's masks)."""
+    if not training or p <= 0.0:
+        return x
+    if not x.is_cuda:
+        raise CaphnError("caphn dropout runs on libcaphn's HIP kernels only (no CPU fallback)")
+    return _DropoutFn.apply(x.float(), float(p), next_seed() if seed is None else int(seed))
+
+
 class _AttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, nh, attn_mask, key_padding):
+    def forward(ctx, q, k, v, nh, attn_mask, key_padding, dropout_p, seed):
         q, k, v = q.detach(), k.detach(), v.detach()
-        o, lse = ops.attention_fwd(q, k, v, nh, attn_mask, key_padding)
+        o, lse = ops.attention_fwd(q, k, v, nh, attn_mask, key_padding, dropout_p, seed)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.nh, ctx.attn_mask, ctx.key_padding = nh, attn_mask, key_padding
+        ctx.nh, ctx.attn_mask, ctx.key_padding, ctx.dropout_p, ctx.seed = nh, attn_mask, key_padding, dropout_p, seed
         return o
 
     @staticmethod
     def backward(ctx, d_o):
         q, k, v, o, lse = ctx.saved_tensors
-        dq, dk, dv = ops.attention_bwd(q, k, v, ctx.nh, ctx.attn_mask, ctx.key_padding, o, lse, d_o)
-        return dq, dk, dv, None, None, None
+        dq, dk, dv = ops.attention_bwd(q, k, v, ctx.nh, ctx.attn_mask, ctx.key_padding, o, lse, d_o, ctx.dropout_p, ctx.seed)
+        return dq, dk, dv, None, None, None, None, None
 
 
-def attention(q, k, v, nh: int, attn_mask=None, key_padding_mask=None):
+def attention(q, k, v, nh: int, attn_mask=None, key_padding_mask=None, dropout_p: float = 0.0, seed=None):
     """Multi-head softmax(q k^T / sqrt(dh) + masks) v on sequence-first [T, bs, d] tensors (the core of
     nn.MultiheadAttention as baseline/transformer.py:137,197-199 calls it).  attn_mask: additive float [tq, tk];
-    key_padding_mask: bool [bs, tk], True = ignore."""
+    key_padding_mask: bool [bs, tk], True = ignore; dropout_p: dropout on the probabilities (training)."""
     if not q.is_cuda:
         raise CaphnError("caphn attention runs on libcaphn's HIP kernels only (no CPU fallback)")
     am = attn_mask.to(device=q.device, dtype=torch.float32).contiguous() if attn_mask is not None else None
     kp = key_padding_mask.to(device=q.device, dtype=torch.uint8).contiguous() if key_padding_mask is not None else None
-    return _AttentionFn.apply(q, k, v, nh, am, kp)
+    if dropout_p > 0.0 and seed is None:
+        seed = next_seed()
+    return _AttentionFn.apply(q, k, v, nh, am, kp, float(dropout_p), int(seed or 0))
 
 
 class _AddFn(torch.autograd.Function):

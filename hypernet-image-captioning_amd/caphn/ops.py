@@ -780,7 +780,20 @@ def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd
     return dx.view(x.shape), dg, db
 
 
-def _attn_dims(q, k, v, o, nh: int) -> L.AttnDims:
+def dropout(x: torch.Tensor, p: float, seed: int, offset: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x * keep / (1 - p) with the counter-based mask of (seed, offset + i); calling it on a gradient with the same
+    seed is the backward."""
+    lib = L.load()
+    if not x.is_contiguous():
+        x = x.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(lib.caphn_dropout_f32(x.numel(), float(p), int(seed) & (2 ** 64 - 1), int(offset), L.ptr(x), L.ptr(out), L.stream_ptr()),
+            "caphn_dropout_f32")
+    return out
+
+
+def _attn_dims(q, k, v, o, nh: int, dropout_p: float = 0.0, seed: int = 0) -> L.AttnDims:
     """q [tq, bs, d], k / v [tk, bs, d], o [tq, bs, d]: sequence-first views whose last stride is 1 (slices of a packed
     projection are fine)."""
     tq, bs, dm = q.shape
@@ -792,17 +805,19 @@ def _attn_dims(q, k, v, o, nh: int) -> L.AttnDims:
         raise L.CaphnError("attention shapes do not match")
     dh = dm // nh
     d = L.AttnDims(bs, nh, dh, tq, tk, q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                   o.stride(0), o.stride(1), 1.0 / (dh ** 0.5))
+                   o.stride(0), o.stride(1), 1.0 / (dh ** 0.5), float(dropout_p), int(seed) & (2 ** 64 - 1))
     if not L.load().caphn_attention_supported(C.byref(d)):
         raise L.CaphnError(f"attention shape not supported by libcaphn (heads of {dh}, {tq} x {tk} positions)")
     return d
 
 
-def attention_fwd(q, k, v, nh: int, attn_mask: Optional[torch.Tensor] = None, key_padding: Optional[torch.Tensor] = None):
-    """softmax(q k^T / sqrt(dh) + attn_mask + key padding) v per head -> (o [tq, bs, d], lse [bs*nh, tq])."""
+def attention_fwd(q, k, v, nh: int, attn_mask: Optional[torch.Tensor] = None, key_padding: Optional[torch.Tensor] = None,
+                  dropout_p: float = 0.0, seed: int = 0):
+    """softmax(q k^T / sqrt(dh) + attn_mask + key padding) v per head -> (o [tq, bs, d], lse [bs*nh, tq]).  dropout_p > 0:
+    the probabilities are dropped with the mask dropout(ones[bs*nh, tq, tk], dropout_p, seed) before they multiply v."""
     lib = L.load()
     o = torch.empty(q.shape, dtype=torch.float32, device=q.device)
-    d = _attn_dims(q, k, v, o, nh)
+    d = _attn_dims(q, k, v, o, nh, dropout_p, seed)
     lse = _f32(d.bs * nh, d.tq, device=q.device)
     L.check(lib.caphn_attention_fwd(C.byref(d), C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()),
                                     L.ptr(attn_mask, allow_none=True), L.ptr(key_padding, torch.uint8, allow_none=True),
@@ -810,12 +825,12 @@ def attention_fwd(q, k, v, nh: int, attn_mask: Optional[torch.Tensor] = None, ke
     return o, lse
 
 
-def attention_bwd(q, k, v, nh: int, attn_mask, key_padding, o, lse, d_o):
+def attention_bwd(q, k, v, nh: int, attn_mask, key_padding, o, lse, d_o, dropout_p: float = 0.0, seed: int = 0):
     lib = L.load()
     d_o = d_o.contiguous()
     if d_o.stride() != o.stride():
         raise L.CaphnError("d_o must share o's layout")
-    d = _attn_dims(q, k, v, o, nh)
+    d = _attn_dims(q, k, v, o, nh, dropout_p, seed)
     dq, dk, dv = torch.empty_strided(q.shape, q.stride(), dtype=torch.float32, device=q.device), \
         torch.empty_strided(k.shape, k.stride(), dtype=torch.float32, device=q.device), \
         torch.empty_strided(v.shape, v.stride(), dtype=torch.float32, device=q.device)

@@ -30,6 +30,17 @@ __device__ __forceinline__ float caphn_tanh(float x) {
     return __builtin_copysignf(t, x);
 }
 
+// ---- dropout: counter-based keep decision (splitmix64 of seed + index), so the backward pass recomputes the forward's mask
+// from (seed, index) instead of storing it.  Returns 0 (dropped, probability p) or 1 / (1 - p).
+__device__ __forceinline__ float caphn_keep_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);          // 24 uniform bits in [0, 1)
+    return u < p ? 0.f : inv_keep;
+}
+
 // ---- wave reductions (64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -162,6 +162,13 @@ __global__ __launch_bounds__(256) void zero_kernel(float* __restrict__ p, size_t
     }
 }
 
+// out = in * keep / (1 - p); the same launch on a gradient is the backward (nn.Dropout in training mode)
+__global__ __launch_bounds__(256) void dropout_kernel(size_t n, float p, float inv_keep, unsigned long long seed, unsigned long long offset,
+                                                      const float* in, float* out) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = in[i] * caphn_keep_scale(seed, offset + i, p, inv_keep);
+}
+
 // y += alpha * x  (gradients of parameters that alias the same theta range: set_all_parameters' child-offset restart)
 __global__ __launch_bounds__(256) void axpy_kernel(size_t n, float alpha, const float* __restrict__ x, float* __restrict__ y) {
     const size_t stride = (size_t)gridDim.x * 256;
@@ -583,6 +590,16 @@ extern "C" int caphn_zero_f32(float* p, size_t n, caphn_stream_t stream) {
     return caphn_launch_status();
 }
 
+extern "C" int caphn_dropout_f32(size_t n, float p, unsigned long long seed, unsigned long long offset, const float* in, float* out,
+                                 caphn_stream_t stream) {
+    if (n == 0) return CAPHN_OK;
+    if (!in || !out || !(p >= 0.f) || !(p < 1.f)) return CAPHN_EINVAL;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), n, p, 1.0f / (1.0f - p), seed,
+                       offset, in, out);
+    return caphn_launch_status();
+}
 extern "C" int caphn_axpy_f32(size_t n, float alpha, const float* x, float* y, caphn_stream_t stream) {
     if (n == 0) return CAPHN_OK;
     if (!x || !y) return CAPHN_EINVAL;

@@ -210,7 +210,9 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnArgs a) {
             if (MODE == 0) { ps[j] = s; mx = fmaxf(mx, s); }
             else {
                 const float p = lse == -INFINITY ? 0.f : caphn_exp(s - lse);
-                const float dp = dot_row<DH>(gr, Vs, j);
+                float dp = dot_row<DH>(gr, Vs, j);
+                if (d.dropout_p > 0.f)
+                    dp *= caphn_keep_scale(d.seed, ((unsigned long long)bh * d.tq + r) * tk + j, d.dropout_p, 1.0f / (1.0f - d.dropout_p));
                 ps[j] = p * (dp - Dr) * d.scale;                       // ds
             }
         }
@@ -221,7 +223,10 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnArgs a) {
             for (int j = lane; j < tk; j += 64) { const float p = caphn_exp(ps[j] - m0); ps[j] = p; l += p; }
             l = wave_sum(l);
             const float inv = l > 0.f ? 1.0f / l : 0.f;
-            for (int j = lane; j < tk; j += 64) ps[j] *= inv;
+            const bool drop = d.dropout_p > 0.f;
+            const float ik = drop ? 1.0f / (1.0f - d.dropout_p) : 1.f;
+            const unsigned long long row_idx = ((unsigned long long)bh * d.tq + r) * tk;
+            for (int j = lane; j < tk; j += 64) ps[j] *= drop ? inv * caphn_keep_scale(d.seed, row_idx + j, d.dropout_p, ik) : inv;
             __builtin_amdgcn_wave_barrier();
             const f32x4 oe = weighted_rows<DH>(ps, Vs, tk, lane);
             store_cols<DH>(a.out0 + at(r, b, h, d.o_ldt, d.o_ldb, d.dh), oe, d.dh, lane);
@@ -281,8 +286,10 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(AttnArgs a) {
             if (a.attn_mask) s += a.attn_mask[(size_t)r * d.tk + j];
             const float l = lse_s[r];
             const float p = (padded || l == -INFINITY || s == -INFINITY) ? 0.f : caphn_exp(s - l);
-            ps[r] = p;
-            dss[r] = p * (dp - D_s[r]) * d.scale;
+            const float m = d.dropout_p > 0.f
+                ? caphn_keep_scale(d.seed, ((unsigned long long)bh * tq + r) * d.tk + j, d.dropout_p, 1.0f / (1.0f - d.dropout_p)) : 1.f;
+            ps[r] = p * m;                                             // dropped probabilities, for dV
+            dss[r] = p * (dp * m - D_s[r]) * d.scale;
         }
         __builtin_amdgcn_wave_barrier();
         const f32x4 dv = weighted_rows<DH>(ps, Gs, tq, lane);
@@ -301,7 +308,8 @@ inline size_t attn_kv_lds(int side, int DH, int rpb = MAX_RPB) {
     return sizeof(float) * ((size_t)2 * side * (DH + 4) + (size_t)2 * side + (size_t)8 * side + (size_t)2 * rpb * DH);
 }
 inline bool attn_dims_ok(const caphn_attn_dims* d) {
-    return d && d->bs > 0 && d->nh > 0 && d->dh > 0 && d->tq > 0 && d->tk > 0 && attn_dh_class(d->dh) != 0;
+    return d && d->bs > 0 && d->nh > 0 && d->dh > 0 && d->tq > 0 && d->tk > 0 && attn_dh_class(d->dh) != 0 &&
+           d->dropout_p >= 0.f && d->dropout_p < 1.f;
 }
 
 template <typename K>

@@ -63,6 +63,11 @@ int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
 
 /* p[0..n) = 0 with dwordx4 stores (hipMemsetAsync's fill kernel is ~8x slower on large buffers). */
 int caphn_zero_f32(float* p, size_t n, caphn_stream_t stream);
+/* nn.Dropout in training mode: out[i] = in[i] * keep_i / (1 - p), keep_i decided by a counter-based hash of (seed, offset + i)
+   (splitmix64; NOT torch's Philox stream, so masks differ from the reference's -- statistically equivalent, parity unpinned).
+   The mask is never stored: the same call on the gradient is the backward.  in may equal out.  0 <= p < 1. */
+int caphn_dropout_f32(size_t n, float p, unsigned long long seed, unsigned long long offset, const float* in, float* out,
+                      caphn_stream_t stream);
 /* y[0..n) += alpha * x[0..n): sums the gradients of parameters that are views of one theta range (utils.py:62-68: every
    child module restarts at offset 0, so hypernet.py's extra layers alias the first cell's slices). */
 int caphn_axpy_f32(size_t n, float alpha, const float* x, float* y, caphn_stream_t stream);
@@ -387,11 +392,13 @@ int caphn_layernorm_bwd(int rows, int d, const float* x, const float* gamma, con
  * dq / dk / dv those of q / k / v.  attn_mask: additive [tq, tk] (-inf = masked) or NULL; key_padding: [bs, tk] bytes,
  * non-zero = ignore, or NULL.  lse [bs*nh, tq] (log-sum-exp per row) links forward and backward.  A row with every key masked
  * yields zeros (torch yields NaN).  Limits: caphn_attention_supported() (the K/V or Q/dO side of one (batch, head) must fit LDS:
- * about 440 positions at dh <= 32, 200 at dh <= 64).  Dropout inside attention is not provided (p = 0 only). */
+ * about 440 positions at dh <= 32, 200 at dh <= 64).  */
 typedef struct {
     int bs, nh, dh, tq, tk;
     int q_ldt, q_ldb, k_ldt, k_ldb, v_ldt, v_ldb, o_ldt, o_ldb;
     float scale;
+    float dropout_p;               /* dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) in training mode); 0 = off */
+    unsigned long long seed;       /* mask of probability (b*nh + h, t, j): caphn_dropout_f32's hash at index ((b*nh + h)*tq + t)*tk + j */
 } caphn_attn_dims;
 int caphn_attention_supported(const caphn_attn_dims* d);
 int caphn_attention_fwd(const caphn_attn_dims* d, const float* q, const float* k, const float* v, const float* attn_mask,

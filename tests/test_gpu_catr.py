@@ -132,13 +132,25 @@ def test_transformer_matches_reference_vectors(name):
         tol = 5e-5 * max(1.0, float(g.abs().max()))
         assert maxdiff(got, g) < tol, (k, maxdiff(got, g), tol)
         worst = max(worst, maxdiff(got, g))
+    # training mode with dropout: masks come from libcaphn's hash (not torch's stream) -- finite, different from eval,
+    # repeatable under torch.manual_seed
     net.train()
     for mod in net.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.1
-    with pytest.raises(NotImplementedError):
-        net(src.detach(), torch.from_numpy(z["mask"]).to(DEV), torch.from_numpy(z["pos"]).to(DEV),
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.1
+    args = (src.detach(), torch.from_numpy(z["mask"]).to(DEV), torch.from_numpy(z["pos"]).to(DEV),
             torch.from_numpy(z["tgt"]).to(DEV), torch.from_numpy(z["tgt_mask"]).to(DEV))
+    from caphn import functional as CF
+    torch.manual_seed(1); CF._seed_state["n"] = 0
+    a = net(*args)
+    torch.manual_seed(1); CF._seed_state["n"] = 0
+    b = net(*args)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert maxdiff(a.detach().cpu().double(), want.double()) > 1e-3
+    a.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
 
 
 @pytest.mark.parametrize("max_norm", [None, 0.1])

@@ -94,3 +94,74 @@ def test_attention_limits_are_reported(ops):
         ops.attention_fwd(q, k, k, 8)              # 600 keys of one head do not fit LDS
     with pytest.raises(CaphnError):
         ops.attention_fwd(q.cpu(), k.cpu(), k.cpu(), 8)
+
+
+def test_dropout_mask_statistics_and_backward(ops):
+    """caphn_dropout_f32: keep fraction, scale, determinism in (seed, offset), and backward = the same mask."""
+    n, p = 1 << 20, 0.1
+    x = torch.ones(n, device=DEV)
+    y = ops.dropout(x, p, seed=1234)
+    kept = (y > 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 3e-3                                   # 3 sigma of a binomial over 2^20 is 9e-4
+    assert torch.allclose(y[y > 0], torch.full((1,), 1 / (1 - p), device=DEV))
+    assert torch.equal(y, ops.dropout(x, p, seed=1234)) and not torch.equal(y, ops.dropout(x, p, seed=1235))
+    assert torch.equal(ops.dropout(x, p, seed=1234, offset=7)[:-7], y[7:])          # the stream is indexed by offset + i
+    # neighbouring elements are uncorrelated enough: the lag-1 product of the centred mask averages to ~0
+    m = (y > 0).float() - (1 - p)
+    assert abs(float((m[1:] * m[:-1]).mean())) < 1e-3
+    from caphn import functional as CF
+    xr = torch.randn(1000, device=DEV, requires_grad=True)
+    out = CF.dropout(xr, 0.3, True, seed=99)
+    out.backward(torch.ones_like(out))
+    assert torch.equal(xr.grad, ops.dropout(torch.ones(1000, device=DEV), 0.3, 99))
+    assert CF.dropout(xr, 0.3, False) is xr and CF.dropout(xr, 0.0, True) is xr
+
+
+@pytest.mark.parametrize("tq,tk,causal", [(20, 49, False), (33, 33, True)])
+def test_attention_probability_dropout_matches_torch_with_the_same_mask(ops, tq, tk, causal):
+    """Dropout on the attention probabilities (nn.MultiheadAttention(dropout=p), training): the kernel's mask is
+    dropout(ones[bs*nh, tq, tk], p, seed); with that mask handed to an fp64 torch restatement, output and all three
+    gradients agree."""
+    g = torch.Generator().manual_seed(tq)
+    bs, nh, dh, p, seed = 2, 4, 32, 0.2, 4242
+    dm = nh * dh
+    q, k, v = (torch.randn(t, bs, dm, generator=g).to(DEV) for t in (tq, tk, tk))
+    mask = torch.full((tq, tk), float("-inf")).triu(1) if causal else None
+    M = ops.dropout(torch.ones(bs * nh * tq * tk, device=DEV), p, seed).view(bs, nh, tq, tk).cpu().double()
+    assert 0.7 < float((M > 0).double().mean()) < 0.9
+    q64, k64, v64 = (t.detach().cpu().double().requires_grad_(True) for t in (q, k, v))
+    qh = q64.reshape(tq, bs, nh, dh).permute(1, 2, 0, 3)
+    kh = k64.reshape(tk, bs, nh, dh).permute(1, 2, 0, 3)
+    vh = v64.reshape(tk, bs, nh, dh).permute(1, 2, 0, 3)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(dh)
+    if mask is not None:
+        s = s + mask.double()
+    ref = ((torch.softmax(s, -1) * M) @ vh).permute(2, 0, 1, 3).reshape(tq, bs, dm)
+    d_o = torch.randn(tq, bs, dm, generator=g)
+    ref.backward(d_o.double())
+    md = mask.to(DEV) if mask is not None else None
+    o, lse = ops.attention_fwd(q, k, v, nh, md, None, dropout_p=p, seed=seed)
+    assert maxdiff(o.cpu().double(), ref.detach()) < 3e-6
+    dq, dk, dv = ops.attention_bwd(q, k, v, nh, md, None, o, lse, d_o.to(DEV), dropout_p=p, seed=seed)
+    assert maxdiff(dq.cpu().double(), q64.grad) < 5e-6
+    assert maxdiff(dk.cpu().double(), k64.grad) < 5e-6
+    assert maxdiff(dv.cpu().double(), v64.grad) < 5e-6
+
+
+def test_ffn_with_inner_dropout_matches_torch_with_the_same_mask(ops):
+    """linear2(dropout(relu(linear1(x)))): forward and every gradient against torch with the kernel's own mask."""
+    from caphn import functional as CF
+    g = torch.Generator().manual_seed(3)
+    rows, d, ff, p, seed = 37, 24, 56, 0.25, 777
+    x = torch.randn(rows, d, generator=g)
+    w1, b1, w2, b2 = torch.randn(ff, d, generator=g) * 0.3, torch.randn(ff, generator=g), torch.randn(d, ff, generator=g) * 0.3, torch.randn(d, generator=g)
+    dev = [t.to(DEV).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y = CF.ffn(dev[0], dev[1], dev[2], dev[3], dev[4], dropout_p=p, seed=seed)
+    M = ops.dropout(torch.ones(rows * ff, device=DEV), p, seed).view(rows, ff).cpu().double()
+    r64 = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    ref = F.linear(F.relu(F.linear(r64[0], r64[1], r64[2])) * M, r64[3], r64[4])
+    assert maxdiff(y.detach().cpu().double(), ref.detach()) < 3e-6
+    gy = torch.randn(rows, d, generator=g)
+    y.backward(gy.to(DEV)); ref.backward(gy.double())
+    for a, b in zip(dev, r64):
+        assert maxdiff(a.grad.cpu().double(), b.grad) < 1e-5

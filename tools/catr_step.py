@@ -29,7 +29,7 @@ def main():
     torch.manual_seed(0)
     bs = int(os.environ.get("CATR_BS", "64"))
     hw = int(os.environ.get("CATR_HW", "7"))
-    cfg = Config(dropout=0.0)
+    cfg = Config(dropout=float(os.environ.get("CATR_DROPOUT", "0.1")))       # baseline/configuration.py:28
     net = Caption(Backbone(), build_transformer(cfg), cfg.hidden_dim, cfg.vocab_size, hyper_emb=10).to(dev)
     n_tr = sum(p.numel() for p in net.transformer.parameters())
     n_hy = sum(p.numel() for p in net.input_proj.parameters())
@@ -74,7 +74,7 @@ def main():
     print(f"matrix work {flops/1e12:.2f} TFLOP per step (fp32) -> {flops/dt/1e12:.1f} TFLOP/s = {flops/dt/157.3e12:.2f} of the 157.3 TFLOP/s "
           f"fp32 MFMA peak (each fp32 product is 6 bf16 MFMA products here: {6*flops/dt/1e12:.0f} TFLOP/s of bf16 work, "
           f"{6*flops/dt/2.5e15:.2f} of the 2.5 PFLOP/s bf16 peak)")
-    print(f"bs {bs}, {hw}x{hw} positions, T {T}: {what} {dt*1e3:.1f} ms = {bs/dt:.0f} img/s; loss {float(loss.detach()):.4f}; "
+    print(f"bs {bs}, {hw}x{hw} positions, T {T}, dropout {cfg.dropout}: {what} {dt*1e3:.1f} ms = {bs/dt:.0f} img/s; loss {float(loss.detach()):.4f}; "
           f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
 
 
