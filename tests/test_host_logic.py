@@ -145,3 +145,31 @@ def test_catr_generated_projection_head_layout_and_cpu_refusal():
         m(torch.randn(1, 2048, 2, 2), torch.randn(10))
     with pytest.raises(CaphnError):
         MLP(8, 16, 30, 3)(torch.randn(2, 8))
+
+
+@pytest.mark.parametrize("name", ["catr_prenorm", "catr_postnorm"])
+def test_catr_transformer_state_dict_is_the_references(name):
+    """The drop-in baseline.transformer registers exactly the parameters of the reference's Transformer (names and
+    shapes taken from the vectors its own classes produced), so a reference checkpoint loads with strict=True."""
+    import json
+    import os
+    import numpy as np
+    from conftest import REPO
+    from baseline.transformer import build_transformer
+    z = np.load(os.path.join(REPO, "tests", "golden", name + ".npz"))
+    with open(os.path.join(REPO, "tests", "golden", "meta.json")) as f:
+        m = json.load(f)[name]
+
+    class Cfg:
+        pad_token_id = 0; layer_norm_eps = 1e-12; dropout = 0.1
+    Cfg.hidden_dim, Cfg.nheads, Cfg.dim_feedforward = m["hidden_dim"], m["nheads"], m["dim_feedforward"]
+    Cfg.vocab_size, Cfg.max_position_embeddings = m["vocab_size"], m["max_position_embeddings"]
+    Cfg.enc_layers, Cfg.dec_layers, Cfg.pre_norm = m["enc_layers"], m["dec_layers"], m["pre_norm"]
+    net = build_transformer(Cfg)
+    want = {k[2:]: z[k].shape for k in z.files if k.startswith("p/")}
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == {k: tuple(v) for k, v in want.items()}
+    assert sum(p.numel() for p in net.parameters()) == m["n_params"]
+    with pytest.raises(Exception):                      # CPU tensors are refused, not computed
+        net(torch.zeros(1, Cfg.hidden_dim, 2, 2), torch.zeros(1, 2, 2, dtype=torch.bool), torch.zeros(1, Cfg.hidden_dim, 2, 2),
+            torch.zeros(1, Cfg.max_position_embeddings, dtype=torch.long), torch.zeros(1, Cfg.max_position_embeddings, dtype=torch.bool))
