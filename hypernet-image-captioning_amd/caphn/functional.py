@@ -324,3 +324,27 @@ def embedding(idx, table, padding_idx=None):
     if not table.is_cuda:
         raise CaphnError("caphn embedding runs on libcaphn's HIP kernels only (no CPU fallback)")
     return _EmbeddingFn.apply(idx.long(), table, padding_idx)
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(logits.view(-1, V), targets.view(-1), ignore_index=...) (mean over the counted targets): loss and
+    d logits in one pass over the logits (caphn_cross_entropy_fwd_bwd); the backward only applies the upstream scalar."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        lg = logits.detach().contiguous()
+        out, dlogits = ops.cross_entropy_fwd_bwd(lg.view(-1, lg.shape[-1]), targets.reshape(-1).contiguous(), ignore_index)
+        ctx.dlogits, ctx.shape = dlogits, logits.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d = ctx.dlogits
+        ctx.dlogits = None
+        return ops.scale_(d, g.detach().float()).view(ctx.shape), None, None
+
+
+def cross_entropy(logits, targets, ignore_index: int = -100):
+    if not logits.is_cuda:
+        raise CaphnError("caphn cross_entropy runs on libcaphn's HIP kernels only (no CPU fallback)")
+    return _CrossEntropyFn.apply(logits.float(), targets.long(), int(ignore_index))

@@ -52,6 +52,14 @@ def zero_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def scale_(x: torch.Tensor, scale_dev: torch.Tensor) -> torch.Tensor:
+    """x *= scale_dev[0] in place (scale on the device)."""
+    lib = L.load()
+    L.check(lib.caphn_scale_f32(x.numel(), L.ptr(x), L.ptr(scale_dev.reshape(-1)[:1].contiguous()), L.ptr(x), L.stream_ptr()),
+            "caphn_scale_f32")
+    return x
+
+
 def axpy_(y: torch.Tensor, x: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
     """y += alpha * x (contiguous fp32, same length)."""
     lib = L.load()

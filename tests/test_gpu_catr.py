@@ -173,3 +173,20 @@ def test_fused_adam_matches_torch_adam(max_norm):
         opt_a.step(); opt_b.step()
     for p, q in zip(pa, pb):
         assert maxdiff(p.detach().cpu(), q.detach().cpu()) < 2e-6
+
+
+def test_cross_entropy_node_matches_torch():
+    """caphn.functional.cross_entropy as an autograd node (loss + d logits in one pass, upstream scalar applied on the
+    device) against F.cross_entropy, with and without an ignored class, under a non-unit upstream gradient."""
+    from caphn import functional as CF
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(6, 11, 301, generator=g)
+    tgt = torch.randint(0, 301, (6, 11), generator=g)
+    for ignore in (-100, 0):
+        a = logits.to(DEV).requires_grad_(True)
+        b = logits.double().requires_grad_(True)
+        la = CF.cross_entropy(a.view(-1, 301), tgt.to(DEV).view(-1), ignore)
+        lb = F.cross_entropy(b.view(-1, 301), tgt.view(-1), ignore_index=ignore)
+        assert abs(float(la) - float(lb)) < 2e-6
+        (la * 2.5).backward(); (lb * 2.5).backward()
+        assert maxdiff(a.grad.cpu().double(), b.grad) < 1e-7
