@@ -30,6 +30,7 @@ class HyperInputProj(nn.Module):
         self.hn_base, self.hn_heads = build_hypernet_layers(template, hyper_emb)
         self._shape = ops.HyperShape(hyper_emb, [(h[0].out_features, h[2].out_features) for h in self.hn_heads])
         assert self._shape.theta_size == hidden_dim * in_channels + hidden_dim
+        self.rank1_factors = None        # set by caphn.optim.FusedAdam.adopt_rank1(): dict filled by the backward
 
     def hyper_named_tensors(self):
         t = {"hn_base.0.weight": self.hn_base[0].weight, "hn_base.0.bias": self.hn_base[0].bias,
@@ -41,7 +42,7 @@ class HyperInputProj(nn.Module):
 
     def generate(self, x_style):
         """(weight [hidden, in_channels], bias [hidden]) for this style row; attached to the hypernet's graph."""
-        theta = CF.hyper_forward(self._shape, x_style, self.hyper_named_tensors())
+        theta = CF.hyper_forward(self._shape, x_style, self.hyper_named_tensors(), factor_sink=self.rank1_factors)
         n = self.hidden_dim * self.in_channels
         return theta[:n].view(self.hidden_dim, self.in_channels), theta[n:]
 

@@ -47,27 +47,43 @@ class _HyperFn(torch.autograd.Function):
     """theta = cat_i head_i(hn_base(x))   hypernet_attention.py:111-118"""
 
     @staticmethod
-    def forward(ctx, shape, x, *tensors):
+    def forward(ctx, shape, x, factor_sink, *tensors):
         names = shape.param_names()
         params = {n: t.detach().contiguous() for n, t in zip(names, tensors)}
         theta, acts = ops.hyper_forward(shape, params, x.detach().float())
         ctx.shape, ctx.params, ctx.acts, ctx.xshape = shape, params, acts, x.shape
         ctx.need_x = x.requires_grad
+        ctx.factor_sink = factor_sink
         return theta
 
     @staticmethod
     def backward(ctx, dtheta):
         shape = ctx.shape
         dev = dtheta.device
-        grads = {n: torch.empty(s, dtype=torch.float32, device=dev) for n, s in shape.param_shapes().items()}
-        gx = ops.hyper_backward(shape, ctx.params, dtheta.contiguous(), ctx.acts, grads, want_x=ctx.need_x)
-        return (None, gx.reshape(ctx.xshape) if gx is not None else None) + tuple(grads[n] for n in shape.param_names())
+        dtheta = dtheta.contiguous()
+        sink = ctx.factor_sink
+        skip = set()
+        if sink is not None:
+            # rank-1 mode (caphn.optim.FusedAdam): dL/dW2_i = dtheta_i (x) a_i is never materialised -- the factors are handed
+            # to the optimiser, which forms the product on the fly while it streams W, m, v once
+            layout = ops.hyper_acts_layout(shape)
+            o = 0
+            for i, (k, w) in enumerate(shape.heads):
+                ao, an = layout[f"a{i}"]
+                sink[f"hn_heads.{i}.2.weight"] = (dtheta[o:o + w], ctx.acts[ao:ao + an])
+                skip.add(f"hn_heads.{i}.2.weight")
+                o += w
+        grads = {n: torch.empty(s, dtype=torch.float32, device=dev) for n, s in shape.param_shapes().items() if n not in skip}
+        gx = ops.hyper_backward(shape, ctx.params, dtheta, ctx.acts, grads, want_x=ctx.need_x)
+        return (None, gx.reshape(ctx.xshape) if gx is not None else None, None) + tuple(grads.get(n) for n in shape.param_names())
 
 
-def hyper_forward(shape: ops.HyperShape, x: torch.Tensor, named: Dict[str, torch.Tensor]) -> torch.Tensor:
+def hyper_forward(shape: ops.HyperShape, x: torch.Tensor, named: Dict[str, torch.Tensor], factor_sink=None) -> torch.Tensor:
+    """factor_sink: a dict that receives {second-layer weight name: (dtheta_i, a_i)} in the backward INSTEAD of the dense
+    [w_i, k_i] gradients (whose .grad then stays None); for optimisers that apply rank-1 gradients (caphn.optim.FusedAdam)."""
     if not x.is_cuda:
         raise CaphnError("HyperNet.forward runs on libcaphn's HIP kernels only (no CPU fallback)")
-    return _HyperFn.apply(shape, x, *[named[n] for n in shape.param_names()])
+    return _HyperFn.apply(shape, x, factor_sink, *[named[n] for n in shape.param_names()])
 
 
 class _PlainDecoderFn(torch.autograd.Function):

@@ -26,6 +26,21 @@ class FusedAdam:
         self.v = [torch.zeros_like(p.data) for p in self.params]
         self._one = torch.tensor([1.0, 0.0], dtype=torch.float32, device=dev)
         self._coef = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._rank1 = []         # (parameter index, factor dict, key)
+
+    def adopt_rank1(self, hyper_module):
+        """hyper_module: a module with hyper_named_tensors() and a `rank1_factors` slot (baseline.caption.HyperInputProj).  Its
+        second-layer weights W2_i [w_i, k_i] then never get a dense gradient: the backward hands over (dtheta_i, a_i) and
+        step() applies Adam with the rank-1 product formed on the fly (caphn_adam_rank_f32: 24 instead of 32+ bytes per
+        parameter and no 4 B/parameter gradient write)."""
+        if self.max_norm is not None:
+            raise NotImplementedError("rank-1 gradients with global-norm clipping: use caphn.engine's trainers")
+        sink = {}
+        hyper_module.rank1_factors = sink
+        ids = {id(p): i for i, p in enumerate(self.params)}
+        for name, t in hyper_module.hyper_named_tensors().items():
+            if name.endswith(".2.weight") and id(t) in ids:
+                self._rank1.append((ids[id(t)], sink, name))
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -41,6 +56,13 @@ class FusedAdam:
         if self.max_norm is not None:
             parts = torch.cat([ops.sumsq_partials(p.grad.contiguous().view(-1)) for p, _, _ in live])
             coef = ops.clip_coef(parts, None, self.max_norm, 1.0, out=self._coef)
+        for i, sink, key in self._rank1:
+            fac = sink.pop(key, None)
+            if fac is None:
+                continue
+            p = self.params[i]
+            ops.adam_rank(p.data, self.m[i], self.v[i], fac[0].reshape(1, -1), fac[1].reshape(1, -1), coef, self.lr, self.step_count,
+                          self.betas, self.eps)
         for p, m, v in live:
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
             if not p.data.is_contiguous():

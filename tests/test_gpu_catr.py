@@ -190,3 +190,30 @@ def test_cross_entropy_node_matches_torch():
         assert abs(float(la) - float(lb)) < 2e-6
         (la * 2.5).backward(); (lb * 2.5).backward()
         assert maxdiff(a.grad.cpu().double(), b.grad) < 1e-7
+
+
+def test_rank1_optimiser_path_equals_dense():
+    """FusedAdam.adopt_rank1(HyperInputProj): the generated projection's second-layer weights are updated from the factors
+    (dtheta_i, a_i) without a dense gradient; two steps equal the dense path."""
+    from baseline.caption import HyperInputProj
+    from caphn.optim import FusedAdam
+
+    def run(rank1):
+        torch.manual_seed(8)
+        mod = HyperInputProj(96, 32, 10).to(DEV)
+        opt = FusedAdam(mod.parameters(), lr=1e-2)
+        if rank1:
+            opt.adopt_rank1(mod)
+        g = torch.Generator(device=DEV).manual_seed(2)
+        for _ in range(2):
+            src = torch.randn(3, 96, 4, 4, device=DEV, generator=g)
+            x = torch.randn(10, device=DEV, generator=g)
+            opt.zero_grad()
+            (mod(src, x) * torch.randn(3, 32, 4, 4, device=DEV, generator=g)).sum().backward()
+            if rank1:
+                assert mod.hn_heads[0][2].weight.grad is None and mod.hn_heads[0][0].weight.grad is not None
+            opt.step()
+        return [p.detach().clone() for p in mod.parameters()]
+
+    for a, b in zip(run(True), run(False)):
+        assert maxdiff(a.cpu(), b.cpu()) < 2e-6

@@ -45,6 +45,8 @@ def main():
     from caphn.optim import FusedAdam
     opt = FusedAdam(net.parameters(), lr=1e-4)               # cc_train_catr.py:56-61: Adam over every parameter
     with_opt = os.environ.get("CATR_OPT", "1") == "1"
+    if os.environ.get("CATR_RANK1", "1") == "1":
+        opt.adopt_rank1(net.input_proj)                      # the 550 M-parameter head of the generated projection
 
     def step():
         opt.zero_grad()
