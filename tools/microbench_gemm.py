@@ -19,7 +19,18 @@ SHAPES = [  # name, ta, tb, M, N, K, splitk candidates
 ]
 
 
+CATR_SHAPES = [  # BASELINE config 5 at bs 64: T*bs = 8192 target rows, 49*bs = 3136 memory rows, d 256, ff 2048, V 30522
+    ("logits fwd", 0, 1, 8192, 30522, 512, (1,)), ("logits dgrad", 0, 0, 8192, 512, 30522, (1, 4)), ("logits wgrad", 1, 0, 30522, 512, 8192, (1,)),
+    ("ffn1 fwd", 0, 1, 8192, 2048, 256, (1,)), ("ffn2 fwd", 0, 1, 8192, 256, 2048, (1, 2, 4)), ("ffn1 dgrad", 0, 0, 8192, 256, 2048, (1, 2, 4)),
+    ("ffn2 dgrad", 0, 0, 8192, 2048, 256, (1,)), ("ffn1 wgrad", 1, 0, 2048, 256, 8192, (1, 4, 8)), ("proj fwd", 0, 1, 8192, 256, 256, (1, 2)),
+    ("proj wgrad", 1, 0, 256, 256, 8192, (8, 16, 32)), ("enc ffn1 fwd", 0, 1, 3136, 2048, 256, (1,)), ("input_proj", 0, 1, 3136, 256, 2048, (1, 2, 4)),
+]
+
+
 def main():
+    global SHAPES
+    if "--catr" in sys.argv:
+        SHAPES = CATR_SHAPES
     lib = _lib.load()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
