@@ -24,6 +24,11 @@ def _drop(d: nn.Dropout, x):
     return CF.dropout(x, d.p, d.training)
 
 
+def _res(d: nn.Dropout, x, branch):
+    """x + d(branch) in one kernel."""
+    return CF.add(x, branch, d.p, d.training)
+
+
 def _mha(m: nn.MultiheadAttention, query, key, value, attn_mask=None, key_padding_mask=None):
     """What m(query, key, value, attn_mask=..., key_padding_mask=...)[0] returns   (baseline/transformer.py:137,197-199)."""
     d = m.embed_dim
@@ -69,11 +74,11 @@ class TransformerEncoderLayer(nn.Module):
         if self.normalize_before:                            # baseline/transformer.py:157-168
             x = _ln(self.norm1, src)
             qk = _with_pos(x, pos)
-            src = CF.add(src, _drop(self.dropout1, _mha(self.self_attn, qk, qk, x, src_mask, src_key_padding_mask)))
-            return CF.add(src, _drop(self.dropout2, self._ffn(_ln(self.norm2, src))))
+            src = _res(self.dropout1, src, _mha(self.self_attn, qk, qk, x, src_mask, src_key_padding_mask))
+            return _res(self.dropout2, src, self._ffn(_ln(self.norm2, src)))
         qk = _with_pos(src, pos)                             # :143-155
-        src = _ln(self.norm1, CF.add(src, _drop(self.dropout1, _mha(self.self_attn, qk, qk, src, src_mask, src_key_padding_mask))))
-        return _ln(self.norm2, CF.add(src, _drop(self.dropout2, self._ffn(src))))
+        src = _ln(self.norm1, _res(self.dropout1, src, _mha(self.self_attn, qk, qk, src, src_mask, src_key_padding_mask)))
+        return _ln(self.norm2, _res(self.dropout2, src, self._ffn(src)))
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -104,16 +109,16 @@ class TransformerDecoderLayer(nn.Module):
         if self.normalize_before:                            # baseline/transformer.py:229-249
             x = _ln(self.norm1, tgt)
             qk = _with_pos(x, query_pos)
-            tgt = CF.add(tgt, _drop(self.dropout1, _mha(self.self_attn, qk, qk, x, tgt_mask, tgt_key_padding_mask)))
+            tgt = _res(self.dropout1, tgt, _mha(self.self_attn, qk, qk, x, tgt_mask, tgt_key_padding_mask))
             x = _ln(self.norm2, tgt)
-            tgt = CF.add(tgt, _drop(self.dropout2, _mha(self.multihead_attn, _with_pos(x, query_pos), mem_k, memory, memory_mask,
-                                                         memory_key_padding_mask)))
-            return CF.add(tgt, _drop(self.dropout3, self._ffn(_ln(self.norm3, tgt))))
+            tgt = _res(self.dropout2, tgt, _mha(self.multihead_attn, _with_pos(x, query_pos), mem_k, memory, memory_mask,
+                                                memory_key_padding_mask))
+            return _res(self.dropout3, tgt, self._ffn(_ln(self.norm3, tgt)))
         qk = _with_pos(tgt, query_pos)                       # :205-227
-        tgt = _ln(self.norm1, CF.add(tgt, _drop(self.dropout1, _mha(self.self_attn, qk, qk, tgt, tgt_mask, tgt_key_padding_mask))))
-        tgt = _ln(self.norm2, CF.add(tgt, _drop(self.dropout2, _mha(self.multihead_attn, _with_pos(tgt, query_pos), mem_k, memory,
-                                                                    memory_mask, memory_key_padding_mask))))
-        return _ln(self.norm3, CF.add(tgt, _drop(self.dropout3, self._ffn(tgt))))
+        tgt = _ln(self.norm1, _res(self.dropout1, tgt, _mha(self.self_attn, qk, qk, tgt, tgt_mask, tgt_key_padding_mask)))
+        tgt = _ln(self.norm2, _res(self.dropout2, tgt, _mha(self.multihead_attn, _with_pos(tgt, query_pos), mem_k, memory,
+                                                           memory_mask, memory_key_padding_mask)))
+        return _ln(self.norm3, _res(self.dropout3, tgt, self._ffn(tgt)))
 
 
 def _get_clones(module, n):

@@ -93,6 +93,7 @@ SIGNATURES = {
     "caphn_zero_f32": (C.c_int, [c_fp, C.c_size_t, c_fp]),
     "caphn_axpy_f32": (C.c_int, [C.c_size_t, C.c_float, c_fp, c_fp, c_fp]),
     "caphn_scale_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_add_dropout_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, C.c_float, C.c_uint64, C.c_uint64, c_fp, c_fp]),
     "caphn_dropout_f32": (C.c_int, [C.c_size_t, C.c_float, C.c_uint64, C.c_uint64, c_fp, c_fp, c_fp]),
     "caphn_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "caphn_linear_wgrad_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]),

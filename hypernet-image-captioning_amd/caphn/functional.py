@@ -298,23 +298,28 @@ def attention(q, k, v, nh: int, attn_mask=None, key_padding_mask=None, dropout_p
 
 
 class _AddFn(torch.autograd.Function):
-    """a + b (same shape, or b broadcast over dim 1 of a sequence-first tensor is NOT handled: expand first)."""
+    """a + dropout(b, p) (same shapes) in one pass; p = 0 is the plain residual sum."""
 
     @staticmethod
-    def forward(ctx, a, b):
-        out = a.detach().contiguous().clone()
-        ops.axpy_(out.view(-1), b.detach().contiguous().view(-1))
-        return out
+    def forward(ctx, a, b, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return ops.add_dropout(a.detach(), b.detach(), p, seed)
 
     @staticmethod
     def backward(ctx, g):
-        return g, g
+        return g, (ops.dropout(g, ctx.p, ctx.seed) if ctx.p > 0.0 else g), None, None
 
 
-def add(a, b):
+def add(a, b, dropout_p: float = 0.0, training: bool = True, seed=None):
+    """a + b, or a + dropout(b) when dropout_p > 0 and training (baseline/transformer.py's  x + self.dropoutN(branch))."""
+    if not a.is_cuda:
+        raise CaphnError("caphn add runs on libcaphn's HIP kernels only (no CPU fallback)")
     if a.shape != b.shape:
         b = b.expand_as(a)
-    return _AddFn.apply(a, b)
+    p = float(dropout_p) if training else 0.0
+    if p > 0.0 and seed is None:
+        seed = next_seed()
+    return _AddFn.apply(a.float(), b.float(), p, int(seed or 0))
 
 
 class _EmbeddingFn(torch.autograd.Function):

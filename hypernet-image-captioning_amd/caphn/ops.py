@@ -52,6 +52,17 @@ def zero_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def add_dropout(x: torch.Tensor, branch: torch.Tensor, p: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """x + dropout(branch, p) in one pass (p = 0: x + branch)."""
+    lib = L.load()
+    x, branch = x.contiguous(), branch.contiguous()
+    assert x.shape == branch.shape
+    out = torch.empty_like(x)
+    L.check(lib.caphn_add_dropout_f32(x.numel(), L.ptr(x), L.ptr(branch), float(p), int(seed) & (2 ** 64 - 1), 0, L.ptr(out),
+                                      L.stream_ptr()), "caphn_add_dropout_f32")
+    return out
+
+
 def scale_(x: torch.Tensor, scale_dev: torch.Tensor) -> torch.Tensor:
     """x *= scale_dev[0] in place (scale on the device)."""
     lib = L.load()

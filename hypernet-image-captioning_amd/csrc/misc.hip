@@ -169,6 +169,14 @@ __global__ __launch_bounds__(256) void dropout_kernel(size_t n, float p, float i
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = in[i] * caphn_keep_scale(seed, offset + i, p, inv_keep);
 }
 
+// out = x + branch * keep / (1 - p): a residual connection with dropout on the branch in one pass (p == 0: plain sum)
+__global__ __launch_bounds__(256) void add_dropout_kernel(size_t n, float p, float inv_keep, unsigned long long seed, unsigned long long offset,
+                                                          const float* __restrict__ x, const float* __restrict__ branch, float* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        out[i] = x[i] + branch[i] * (p > 0.f ? caphn_keep_scale(seed, offset + i, p, inv_keep) : 1.f);
+}
+
 // out = x * scale[0] (scale on the device: the upstream gradient of a scalar loss)
 __global__ __launch_bounds__(256) void scale_kernel(size_t n, const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ out) {
     const float c = scale[0];
@@ -605,6 +613,16 @@ extern "C" int caphn_dropout_f32(size_t n, float p, unsigned long long seed, uns
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), n, p, 1.0f / (1.0f - p), seed,
                        offset, in, out);
+    return caphn_launch_status();
+}
+extern "C" int caphn_add_dropout_f32(size_t n, const float* x, const float* branch, float p, unsigned long long seed,
+                                     unsigned long long offset, float* out, caphn_stream_t stream) {
+    if (n == 0) return CAPHN_OK;
+    if (!x || !branch || !out || !(p >= 0.f) || !(p < 1.f)) return CAPHN_EINVAL;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(add_dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), n, p, 1.0f / (1.0f - p), seed,
+                       offset, x, branch, out);
     return caphn_launch_status();
 }
 extern "C" int caphn_scale_f32(size_t n, const float* x, const float* scale_dev, float* out, caphn_stream_t stream) {

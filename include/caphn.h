@@ -68,6 +68,10 @@ int caphn_zero_f32(float* p, size_t n, caphn_stream_t stream);
    The mask is never stored: the same call on the gradient is the backward.  in may equal out.  0 <= p < 1. */
 int caphn_dropout_f32(size_t n, float p, unsigned long long seed, unsigned long long offset, const float* in, float* out,
                       caphn_stream_t stream);
+/* out[i] = x[i] + branch[i] * keep_i / (1 - p): residual connection with dropout on the branch (baseline/transformer.py:140,
+   :161 ...: src + self.dropout1(src2)); the mask is caphn_dropout_f32's for the same (seed, offset); p = 0 is a plain sum. */
+int caphn_add_dropout_f32(size_t n, const float* x, const float* branch, float p, unsigned long long seed,
+                          unsigned long long offset, float* out, caphn_stream_t stream);
 /* out[i] = x[i] * scale_dev[0]: the chain rule through a scalar loss whose upstream gradient lives on the device (x may equal out). */
 int caphn_scale_f32(size_t n, const float* x, const float* scale_dev, float* out, caphn_stream_t stream);
 /* y[0..n) += alpha * x[0..n): sums the gradients of parameters that are views of one theta range (utils.py:62-68: every

@@ -165,3 +165,20 @@ def test_ffn_with_inner_dropout_matches_torch_with_the_same_mask(ops):
     y.backward(gy.to(DEV)); ref.backward(gy.double())
     for a, b in zip(dev, r64):
         assert maxdiff(a.grad.cpu().double(), b.grad) < 1e-5
+
+
+def test_residual_add_with_branch_dropout(ops):
+    """x + dropout(branch) in one kernel: equals x + caphn_dropout(branch) for the same seed; gradients: identity for x,
+    the same mask for the branch; p = 0 is the plain sum."""
+    from caphn import functional as CF
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(7, 5, 33, generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn(7, 5, 33, generator=g).to(DEV).requires_grad_(True)
+    y = CF.add(x, b, 0.3, True, seed=55)
+    assert maxdiff(y.detach().cpu(), (x.detach() + ops.dropout(b.detach(), 0.3, 55)).cpu()) < 1e-6      # fused multiply-add: 1 ulp
+    gy = torch.randn(7, 5, 33, generator=g).to(DEV)
+    y.backward(gy)
+    assert torch.equal(x.grad, gy) and torch.equal(b.grad, ops.dropout(gy, 0.3, 55))
+    assert torch.equal(CF.add(x, b).detach(), x.detach() + b.detach())
+    assert torch.equal(CF.add(x, b, 0.3, False).detach(), x.detach() + b.detach())
+    assert float((y.detach() == x.detach()).float().mean()) > 0.2                  # ~30 % of the branch dropped
