@@ -77,6 +77,15 @@ def main():
     print(f"matrix work {flops/1e12:.2f} TFLOP per step (fp32) -> {flops/dt/1e12:.1f} TFLOP/s = {flops/dt/157.3e12:.2f} of the 157.3 TFLOP/s "
           f"fp32 MFMA peak (each fp32 product is 6 bf16 MFMA products here: {6*flops/dt/1e12:.0f} TFLOP/s of bf16 work, "
           f"{6*flops/dt/2.5e15:.2f} of the 2.5 PFLOP/s bf16 peak)")
+    import json
+    print(json.dumps({"metric": "training images/sec, CATR + hypernet-generated proj weights (BASELINE config 5), per-GPU share of bs=512 at DP=8",
+                      "value": bs / dt, "unit": "images/s", "n_gpus": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "f32",
+                      "data": "synthetic", "step": what,
+                      "config": {"workload": "Caption: generated 1x1 input_proj -> 6+6 pre-norm transformer (d 256, 8 heads, ff 2048) -> MLP head, "
+                                             "cross entropy, Adam", "per_gpu_batch": bs, "positions": hw * hw, "T": T, "V": cfg.vocab_size,
+                                 "dropout": cfg.dropout, "launch": "eager (module API)"},
+                      "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / dt / 157.3e12,
+                                   "traffic": None, "note": "whole step's fp32 matrix work over the fp32 MFMA peak; each fp32 product is six bf16 MFMA products"}}))
     print(f"bs {bs}, {hw}x{hw} positions, T {T}, dropout {cfg.dropout}: {what} {dt*1e3:.1f} ms = {bs/dt:.0f} img/s; loss {float(loss.detach()):.4f}; "
           f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
 
