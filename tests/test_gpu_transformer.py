@@ -182,3 +182,47 @@ def test_residual_add_with_branch_dropout(ops):
     assert torch.equal(CF.add(x, b).detach(), x.detach() + b.detach())
     assert torch.equal(CF.add(x, b, 0.3, False).detach(), x.detach() + b.detach())
     assert float((y.detach() == x.detach()).float().mean()) > 0.2                  # ~30 % of the branch dropped
+
+
+def test_edge_shapes_and_fully_masked_rows(ops):
+    """One query / one key, heads narrower than a float4, a single LayerNorm row of width 1, and a row whose keys are all
+    masked (zeros here; torch yields NaN, documented in include/caphn.h)."""
+    from caphn._lib import CaphnError
+    g = torch.Generator().manual_seed(77)
+    # 3 heads of 5
+    q, k, v = (torch.randn(t, 2, 15, generator=g).to(DEV) for t in (1, 1, 1))
+    o, lse = ops.attention_fwd(q, k, v, 3)
+    assert maxdiff(o.cpu(), v.cpu()) < 1e-6                      # one key: softmax = 1, o = v
+    q, k, v = (torch.randn(t, 2, 15, generator=g).to(DEV) for t in (4, 6, 6))
+    ref = _ref_attention(q.cpu().double(), k.cpu().double(), v.cpu().double(), 3, None, None)
+    o, lse = ops.attention_fwd(q, k, v, 3)
+    assert maxdiff(o.cpu().double(), ref) < 3e-6
+    # every key of sample 1 padded: zeros out, zero gradients, sample 0 untouched
+    kpm = torch.zeros(2, 6, dtype=torch.uint8); kpm[1] = 1
+    o2, lse2 = ops.attention_fwd(q, k, v, 3, None, kpm.to(DEV))
+    assert torch.equal(o2[:, 1], torch.zeros_like(o2[:, 1])) and maxdiff(o2[:, 0].cpu(), o[:, 0].cpu()) < 1e-6
+    dq, dk, dv = ops.attention_bwd(q, k, v, 3, None, kpm.to(DEV), o2, lse2, torch.ones_like(o2))
+    for t in (dq, dk, dv):
+        assert torch.isfinite(t).all() and float(t[:, 1].abs().max()) == 0.0
+    # LayerNorm: one row, width 1 (variance 0 -> y = beta) and width 2
+    y, m, r = ops.layernorm_fwd(torch.tensor([[3.0]], device=DEV), torch.tensor([2.0], device=DEV), torch.tensor([0.5], device=DEV), 1e-5)
+    assert abs(float(y) - 0.5) < 1e-6
+    x2 = torch.tensor([[1.0, 3.0]], device=DEV)
+    y2, _, _ = ops.layernorm_fwd(x2, torch.ones(2, device=DEV), torch.zeros(2, device=DEV), 1e-5)
+    assert maxdiff(y2.cpu(), torch.nn.functional.layer_norm(x2.cpu(), (2,))) < 1e-6
+    with pytest.raises(CaphnError):
+        ops.layernorm_fwd(torch.zeros(2, 2000, device=DEV), torch.ones(2000, device=DEV), torch.zeros(2000, device=DEV), 1e-5)   # d > 1024
+    with pytest.raises(CaphnError):
+        ops.dropout(torch.ones(4, device=DEV), 1.0, 1)                       # p must be < 1
+    assert torch.equal(ops.dropout(torch.ones(4, device=DEV), 0.0, 1), torch.ones(4, device=DEV))
+
+
+def test_embedding_node_padding_row_gets_no_gradient():
+    from caphn import functional as CF
+    table = torch.randn(9, 6, device=DEV, requires_grad=True)
+    idx = torch.tensor([[0, 3, 3], [8, 0, 1]], device=DEV)
+    out = CF.embedding(idx, table, padding_idx=0)
+    assert torch.equal(out.detach(), table.detach()[idx])
+    out.sum().backward()
+    want = torch.zeros(9, 6); want[3] = 2.0; want[8] = 1.0; want[1] = 1.0
+    assert torch.equal(table.grad.cpu(), want)
