@@ -22,7 +22,12 @@ for rot in (0, 1):
       grads = {n: torch.empty(s, device=dev) for n, s in dims.param_shapes().items()}
       ops.decoder_backward(dims, p, feats, caps, dl, grads, ws)
   torch.cuda.synchronize()
-  prof = ws[-64 * 4:].view(torch.int64).cpu().tolist()
+  # workspace tail (csrc/decoder.hip, layout()): ... | prof: 64 floats | rowmap: up4(B*T + 4) ints |
+  tail = ((128 * 20 + 4 + 3) // 4) * 4
+  wsf = ws.view(torch.float32)
+  prof = wsf[wsf.numel() - tail - 64: wsf.numel() - tail].contiguous().view(torch.int64).cpu().tolist()
+  if not any(prof[:16]):
+      print("all counters are zero: build csrc/recurrent_gru.hip with -DCAPHN_REC_PROFILE (phase stamps are compiled out by default)")
   fw, bw = prof[:8], prof[8:16]
   names_f = ["A matvec W_hh,U_a", "B scores", "C softmax", "D1 alpha.G partial", "D2 gates"]
   names_b = ["P1 cell pointwise", "P2 dalpha=G.dgi", "P3 softmax bwd", "P4 d(uah) partial", "P4b sum", "P5 matvec^T", "P6 sum"]
