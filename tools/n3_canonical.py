@@ -97,6 +97,16 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         bpp = 28 if prefetch else 32
+        if prefetch:
+            import json
+            print(json.dumps({"metric": "training images/sec, hypernet.py HyperNet(200, 150, 9684, vocab, 2, 'gru') (BASELINE config 2 as literally named)",
+                              "value": B / dt, "unit": "images/s", "n_gpus": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "f32",
+                              "data": "synthetic", "config": {"workload": "fused step: hypernet forward (in the Adam pass), DecoderGRU 2 layers, cross "
+                                                                          "entropy, backward, Adam; dead heads skipped", "per_gpu_batch": B, "T": T,
+                                                              "hypernet_params": nparam, "live_second_layer_params": live},
+                              "roofline": {"bound": "hbm", "achieved": live * 28 / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                           "frac": live * 28 / dt / 8e12, "traffic": None,
+                                           "note": "whole step over the 28 B per live second-layer parameter it must move (VJP 4 + Adam 24)"}}))
         print(f"fused step ({'next theta in the Adam pass' if prefetch else 'separate forward GEMV'}): {dt*1e3:.2f} ms = "
               f"{B/dt:.0f} img/s; live second-layer parameters {live/1e9:.3f} G of {nparam/1e9:.3f} G, "
               f"{bpp} B each -> {live*bpp/dt/1e12:.2f} TB/s;  loss {float(out[0]):.4f}")
