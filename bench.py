@@ -2,7 +2,8 @@
 """bench.py -- training images/sec of the hypernet-conditioned captioning step on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` it is one rank;
+   started bare, it launches those N ranks itself before touching the GPU and passes rank 0's line through)
 
 One "step" = hypernet forward -> decoder forward -> cross entropy -> backward -> gradient exchange
 -> global-norm clip -> Adam on one synthetic Flickr30k-shaped minibatch already resident in HBM
@@ -79,8 +80,9 @@ def usable_cores():
 
 
 def cpu_baseline(B, T, P, budget_s=25.0, max_steps=5):
-    """Oracle (port of the reference's path) on the host cores: forward, backward, clip, Adam.
-    Bounded: stops after max_steps timed steps or budget_s seconds."""
+    """Oracle (port of the reference's path) on the host cores: 2 warm-up steps, then up to
+    max_steps timed full steps (forward, backward, clip, Adam; the median is `value`), then 3 steps without the
+    optimiser (forward + backward only, reported beside it).  Bounded by budget_s seconds."""
     from oracle import caphn_oracle as O
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -89,18 +91,81 @@ def cpu_baseline(B, T, P, budget_s=25.0, max_steps=5):
     batch = O.synth_batch(dims, B, T, P, seed=2)
     state = {}
     t_start = time.perf_counter()
-    O.train_step(dims, p, state, 1, None, batch["features"], batch["captions"], lr=1e-3, style_token=4)  # warm-up
+    for w in range(2):
+        O.train_step(dims, p, state, w + 1, None, batch["features"], batch["captions"], lr=1e-3, style_token=4)
     ts = []
     for s in range(max_steps):
         t0 = time.perf_counter()
-        O.train_step(dims, p, state, s + 2, None, batch["features"], batch["captions"], lr=1e-3, style_token=4)
+        O.train_step(dims, p, state, s + 3, None, batch["features"], batch["captions"], lr=1e-3, style_token=4)
         ts.append(time.perf_counter() - t0)
         if time.perf_counter() - t_start > budget_s:
             break
-    med = float(np.median(ts))
+    tn = []
+    for s in range(3):
+        t0 = time.perf_counter()
+        O.forward_backward(dims, p, None, batch["features"], batch["captions"], style_token=4)
+        tn.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s + 8.0:
+            break
+    med, medn = float(np.median(ts)), float(np.median(tn))
     return {"value": B / med, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{len(ts)} full steps (fwd+bwd+clip+Adam) at B={B}, T={T}, fp32, after 1 warm-up; "
-                      f"median {med * 1e3:.0f} ms/step"}
+            "value_without_adam": B / medn,
+            "sample": f"{len(ts)} full steps (fwd+bwd+clip+Adam) at B={B}, T={T}, fp32, after 2 warm-ups; "
+                      f"median {med * 1e3:.0f} ms/step; {len(tn)} steps without the optimiser: median {medn * 1e3:.0f} ms"}
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: this process -- which has made NO GPU call (counting devices does not
+    initialise the GPU) and makes none -- starts N ranks through torch.distributed.run as a child process, passes their
+    output through (rank 0 prints the JSON line) and returns the child's exit code."""
+    import socket
+    import subprocess
+    dry = os.environ.get("CAPHN_BENCH_DRYRUN") == "1"
+    if not dry and os.environ.get("CAPHN_BENCH_REHEARSAL") != "1":
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} GPUs on this node, {have} visible", file=sys.stderr)
+            return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for ln in proc.stdout:                       # only the result line goes to stdout; anything else is noise
+        if ln.startswith('{"metric"'):
+            sys.stdout.write(ln); sys.stdout.flush(); lines += 1
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: the ranks printed {lines} result lines, expected 1", file=sys.stderr)
+        return 3
+    return rc
+
+
+def dryrun(world, rank, args):
+    """CAPHN_BENCH_DRYRUN=1: the launcher / rendezvous / max-over-ranks / one-line control flow with no GPU in it
+    (tests/test_bench_launcher.py runs it here on CPU).  Never a measurement."""
+    import torch.distributed as dist
+    if os.environ.get("CAPHN_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+        raise SystemExit(7)
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dryrun": True, "max_over_ranks_s": float(dt)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -128,11 +193,21 @@ def main():
                     "precompute beside the optimiser")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the ranks ourselves, before anything touches the GPU in this process
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
+    if os.environ.get("CAPHN_BENCH_DRYRUN") == "1":
+        return dryrun(world, rank, args)
+    # stdout carries ONE line, the result.  Native libraries write there too (RCCL prints a version banner from C when
+    # its communicator is created): until the result is ready, file descriptor 1 points at stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     # rehearsal on a one-GPU box (never the measured configuration): CAPHN_BENCH_REHEARSAL=1 puts every rank on
     # device 0 and moves the collectives over gloo, so the N>1 control flow can be exercised without a second GPU
     rehearsal = os.environ.get("CAPHN_BENCH_REHEARSAL") == "1"
@@ -141,12 +216,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    # CAPHN_FORCE_COLLECTIVES=1: a one-rank RCCL group still goes through every collective call of the exchange (side
+    # measurement / test of the nccl code path on a one-GPU box)
+    forced = world == 1 and os.environ.get("CAPHN_FORCE_COLLECTIVES") == "1"
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced and "MASTER_PORT" not in os.environ:
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
         if rehearsal:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from hypernet_attention import HyperNet
     from caphn.engine import FusedTrainer
@@ -305,7 +386,8 @@ def main():
         phase_report(tr, batches, style)
 
     if rank == 0:
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[:cnt["i"]]])) if cnt["i"] else float("nan")
+        kts = [a.elapsed_time(b) for a, b in ev[:cnt["i"]]]
+        kern_ms = float(np.mean(kts)) if kts else float("nan")
         k0, w0 = tr.shape.heads[0]
         kbytes = 24.0 * k0 * w0
         achieved = kbytes / (kern_ms * 1e-3) / 1e9 if cnt["i"] else None
@@ -329,7 +411,8 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "T": T, "P": P, "D": D, "F": F, "E": E, "H": H,
                        "V": V, "hypernet_params": int(sum(q.numel() for q in net.hn_base.parameters()) +
                                                       sum(q.numel() for q in net.hn_heads.parameters())),
-                       "parallelism": f"dp{world}" + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else ""), "launch": "hipGraph" if use_graph else "eager",
+                       "parallelism": f"dp{world}" + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else "") +
+                                      (" (one-rank RCCL group, collectives forced)" if forced else ""), "launch": "hipGraph" if use_graph else "eager",
                        "next_theta_in_adam_pass": not (use_graph or args.no_prefetch),
                        "next_precompute_beside_adam": not (use_graph or args.no_prefetch or args.no_overlap),
                        "spinup_steps": spin["steps"],
@@ -337,13 +420,17 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "adam_rank_kernel(hn_heads.0.2.weight)",
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": (achieved / (HBM_PEAK / 1e9)) if achieved else None, "traffic": traffic,
-                         "kernel_ms": kern_ms, "algorithmic_bytes": kbytes,
+                         "kernel_ms": kern_ms, "kernel_ms_median": float(np.median(kts)) if kts else None,
+                         "kernel_ms_min": float(np.min(kts)) if kts else None, "algorithmic_bytes": kbytes,
                          "step_frac": STEP_ALGO_BYTES / (ms_step * 1e-3) / HBM_PEAK if B == 128 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B, T, P)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -115,6 +115,7 @@ SIGNATURES = {
     "caphn_decoder_hyper_backward": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
                                                c_fp, c_fp, C.POINTER(DecoderGrads), c_fp,
                                                C.POINTER(HyperDesc), c_fp, C.POINTER(HyperGrads), c_fp, c_fp]),
+    "caphn_decoder_backward_milestone": (C.c_int, [C.c_int, c_fp]),
     "caphn_decoder_search_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDims), C.POINTER(SearchCfg)]),
     "caphn_decoder_search_begin": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), C.POINTER(SearchCfg),
                                              c_fp, c_fp, c_fp, c_fp]),

@@ -48,7 +48,10 @@ class FusedTrainer:
             raise NotImplementedError("fused step supports num_layers=1, dropout p=0")
         d0 = self.cap.dec_dims(1, 1, 1)
         self._cell_names = d0.cell_names()
-        self._dec_names = [n for n in d0.names() if n not in self._cell_names]
+        # arena order of the decoder's parameters = the order their gradients are finished by the backward, so that
+        # the data-parallel all-reduce can go bucket by bucket: vocabulary projection, embedding table, the rest
+        front = ["fc.weight", "fc.bias", "embed.weight"]
+        self._dec_names = front + [n for n in d0.names() if n not in self._cell_names and n not in front]
         self._vcache = {}
         self._invalidate_caches()
         self._build_arena()
@@ -82,6 +85,11 @@ class FusedTrainer:
         self._loss_done = torch.cuda.Event()
         self._loss_pending = False
         self._pre_done = torch.cuda.Event()
+        # data-parallel exchange: collectives are issued from this stream, which waits on the backward's milestones
+        self._comm_stream = torch.cuda.Stream(device=dev)
+        self._works = []
+        self._gfac_all = None
+        self._acts_all = None
         self.overlap_after_head = 0      # the side stream forks after this head's Adam pass (-1: before the first)
         self.overlap_level = 1           # 2: also G / embedding / x-side gates once the next W_ih exists (measured: no gain,
                                          # the extra side-stream work slows the concurrent Adam pass by as much)
@@ -117,6 +125,11 @@ class FusedTrainer:
             o = _up4(o + p.numel())
         self.n_dense = o
         self.offs = offs
+        # all-reduce buckets (float ranges of the arena), in the order the backward completes them
+        e_fc = offs["captioner.embed.weight"][0]
+        e_emb = _up4(e_fc + offs["captioner.embed.weight"][1])
+        self._buckets = {"hyper": (0, self._hyper_small_end), "fc": (self._hyper_small_end, e_fc),
+                         "embed": (e_fc, e_emb), "rest": (e_emb, o)}
         dev = self.dev
         self.flat_p = torch.zeros(o, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(o, dtype=torch.float32, device=dev)
@@ -238,6 +251,9 @@ class FusedTrainer:
         if (x_style is None) == (style_token is None):
             raise CaphnError("pass exactly one of x_style / style_token")
         self._sync_params()
+        if self._works:                 # a previous forward_backward whose optimizer_step never came: its collectives
+            dp.wait_all(self._works)    # still own the gradient arena
+            self._works = []
         B, P, _ = features.shape
         T = captions.shape[1]
         buf = self._buffers(B, T, P)
@@ -317,38 +333,66 @@ class FusedTrainer:
         gx = ops.decoder_hyper_backward(dims, params, features, captions, dlogits, grads, buf["ws"],
                                         self.shape, hp, self._acts, hg, self._hyper_ws,
                                         want_x=style_token is not None)
-        work = None
-        if style_token is None:
-            work = dp.all_reduce_dense(self.flat_g[self._hyper_small_end:], self.group, async_op=True)
+        tok = None
         if style_token is not None:
-            # Flickr path: the style row of the embedding also feeds the hypernet -- add its VJP to the
+            # Flickr path: the style row of the embedding also feeds the hypernet -- its VJP is added to the
             # embedding gradient before that gradient is reduced
             tok = self._toks.get(int(style_token))
             if tok is None:
                 tok = self._toks[int(style_token)] = torch.full((1,), int(style_token), dtype=torch.int64, device=self.dev)
+        if dp.active(self.group):
+            self._issue_exchange(gx, tok)
+        elif tok is not None:
             ops.embedding_scatter_add(gx.view(1, -1), tok, self._view(self.flat_g, "captioner.embed.weight"))
-            work = dp.all_reduce_dense(self.flat_g[self._hyper_small_end:], self.group, async_op=True)
-        self._pending = work
         if self._loss_pending:       # whoever reads the returned loss on the current stream sees the finished value
             torch.cuda.current_stream().wait_event(self._loss_done)
             self._loss_pending = False
         return buf["loss"]
 
-    def _exchange(self):
-        """All-gather the rank-1 factors, finish the dense all-reduce.  Returns (gfac [R,theta], acts_all [R,L])."""
+    def _issue_exchange(self, gx, tok):
+        """Data-parallel exchange, started while the backward is still running: the collectives are issued
+        from a side stream that waits for the backward's milestones (caphn_decoder_backward_milestone), in the order the
+        backward reaches them; RCCL runs them on its own stream beside the attention / feature_fc chain and the hypernet's
+        576 MB transposed GEMV.  Nothing is allocated or packed per step: dtheta is gathered straight out of the gradient
+        arena, the activation factors out of the acts buffer, into two preallocated [R, .] buffers.
+          after dL/dtheta          all-gather of the rank-1 row factors (dtheta) and column factors (acts)
+          after the vocab wgrad    all-reduce of fc.weight / fc.bias                       (7.8 MB)
+          after the hypernet VJP   all-reduce of [second-layer biases | hn_base | first layers]  (1.9 MB)
+          after the scatter-add    all-reduce of embed.weight (+ the style row's VJP, Flickr path)   (7.7 MB)
+          after the whole call     all-reduce of the rest (feature_fc, attention, init_h)  (2 MB)"""
         R = dp.world(self.group)
-        L_acts = self._acts.numel()
-        if R == 1:
+        g, th = self.flat_g, self.theta_size
+        if self._gfac_all is None or self._gfac_all.shape[0] != R:
+            self._gfac_all = torch.empty(R, th, dtype=torch.float32, device=self.dev)
+            self._acts_all = torch.empty(R, self._acts.numel(), dtype=torch.float32, device=self.dev)
+        main = torch.cuda.current_stream()
+        cs = self._comm_stream
+        bk = self._buckets
+        w = self._works
+        with torch.cuda.stream(cs):
+            ops.backward_milestone_wait(ops.MS_DTHETA)
+            w.append(dp.all_gather_factors(g[:th], self._gfac_all, self.group, async_op=True)[1])
+            w.append(dp.all_gather_factors(self._acts, self._acts_all, self.group, async_op=True)[1])
+            ops.backward_milestone_wait(ops.MS_VOCAB)
+            w.append(dp.all_reduce_dense(g[bk["fc"][0]:bk["fc"][1]], self.group, async_op=True))
+            ops.backward_milestone_wait(ops.MS_HYPER)
+            w.append(dp.all_reduce_dense(g[bk["hyper"][0]:bk["hyper"][1]], self.group, async_op=True))
+            ops.backward_milestone_wait(ops.MS_EMBED)
+            if tok is not None:
+                gx.record_stream(cs)        # allocated on the main stream, consumed here
+                ops.embedding_scatter_add(gx.view(1, -1), tok, self._view(g, "captioner.embed.weight"))
+            w.append(dp.all_reduce_dense(g[bk["embed"][0]:bk["embed"][1]], self.group, async_op=True))
+            cs.wait_stream(main)
+            w.append(dp.all_reduce_dense(g[bk["rest"][0]:bk["rest"][1]], self.group, async_op=True))
+
+    def _exchange(self):
+        """Joins the exchange _issue_exchange started.  Returns (gfac [R,theta], acts_all [R,L])."""
+        if not dp.active(self.group):
             return self.flat_g[:self.theta_size].view(1, -1), self._acts.view(1, -1)
-        pack = torch.cat([self.flat_g[:self.theta_size], self._acts])
-        allp = dp.all_gather_factors(pack, group=self.group)                    # [R, theta + L]
-        hs = dp.all_reduce_dense(self.flat_g[:self._hyper_small_end], self.group, async_op=True)
-        if self._pending is not None:
-            self._pending.wait()
-        if hs is not None:
-            hs.wait()
-        self._pending = None
-        return allp[:, :self.theta_size], allp[:, self.theta_size:self.theta_size + L_acts]
+        dp.wait_all(self._works)
+        torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._works = []
+        return self._gfac_all, self._acts_all
 
     def _begin_step(self):
         self.step_count += 1

@@ -600,6 +600,15 @@ def decoder_hyper_backward(dims: DecDims, params, features, captions, dlogits, g
     return gx
 
 
+MS_DTHETA, MS_VOCAB, MS_EMBED, MS_HYPER = 0, 1, 2, 3
+
+
+def backward_milestone_wait(which: int) -> None:
+    """The CURRENT stream waits until the last decoder backward enqueued on this device has finished part `which`
+    (include/caphn.h: CAPHN_MS_*), not for the rest of it."""
+    L.check(L.load().caphn_decoder_backward_milestone(int(which), L.stream_ptr()), "caphn_decoder_backward_milestone")
+
+
 def clip_coef(partial: torch.Tensor, extra: Optional[torch.Tensor], max_norm: float, scale: float,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = L.load()

@@ -11,6 +11,7 @@
 #include "decoder_internal.h"
 #include "gemm_internal.h"
 #include <algorithm>
+#include <mutex>
 
 int g_tune_rec_rotate = 1;
 int g_tune_fork = 1;        // 0: one stream; 1 (default): independent branches on side streams, the dW_fc branch starting
@@ -19,26 +20,36 @@ int g_tune_fork = 1;        // 0: one stream; 1 (default): independent branches 
 
 namespace {
 
-// Side streams for the independent branches of one composite call.  Created on first use (outside any
-// graph capture); fork/join is expressed with events, so a capturing caller stream captures the branches too.
-// Not thread-safe: one host thread drives one device (as the reference's training loop does).
+// Side streams for the independent branches of one composite call: ONE set per device (include/caphn.h, "Hidden
+// state"), created on that device's first composite call (outside any graph capture); fork/join is expressed with
+// events, so a capturing caller stream captures the branches too.  Creation is serialised by a mutex; USE is not
+// thread-safe: one host thread drives one device (as the reference's training loop does).
 struct Side {
     hipStream_t st[3];
     hipEvent_t fork, join[3], x[6];
+    hipEvent_t ms[CAPHN_MS_COUNT];     // milestones of the last backward composite (caphn_decoder_backward_milestone)
     bool ready = false, on = false;
     hipStream_t main = nullptr;
     int init() {
+        if (ready) return CAPHN_OK;
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
         if (ready) return CAPHN_OK;
         for (auto& s : st) if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return CAPHN_ELAUNCH;
         if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
         for (auto& e : join) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
         for (auto& e : x) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
+        for (auto& e : ms) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
         ready = true;
         return CAPHN_OK;
     }
+    // milestone k is reached once everything enqueued on `from` so far has run
+    int milestone(int k, hipStream_t from) {
+        if (init() != CAPHN_OK) return CAPHN_ELAUNCH;
+        return hipEventRecord(ms[k], from) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+    }
     int begin(hipStream_t m, bool enable) {
         main = m; on = enable;
-        if (!on) return CAPHN_OK;
         return init();
     }
     hipStream_t s(int i) const { return on ? st[i] : main; }
@@ -70,7 +81,14 @@ struct Side {
         return hipStreamWaitEvent(to, x[k], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
     }
 };
-Side g_side;
+constexpr int MAX_DEVICES = 64;
+Side g_sides[MAX_DEVICES];
+// the current device's set (HIP's current device is per host thread; torch sets it before calling in)
+inline Side* side_here() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    return &g_sides[dev];
+}
 
 struct Ws {   // float offsets into the workspace
     size_t Y1, f, meanf, h0, c0, Waf, G, Xe, Xg, Hs, Hprev, gates, hn, Cs, Cprev, uah, alphas, idx;
@@ -222,7 +240,9 @@ static int decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_p
                            CAPHN_GEMM_BIAS | CAPHN_GEMM_RELU, 1, s));
         RUN(caphn_gemm_f32(0, 1, BP, F, F, ws + w.Y1, F, p->fc2_w, F, ws + w.f, F, p->fc2_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
     }
-    Side& sd = g_side;
+    Side* sdp = side_here();
+    if (!sdp) return CAPHN_ELAUNCH;
+    Side& sd = *sdp;
     RUN(sd.begin(s, g_tune_fork != 0 && (parts & 1)));
     if (parts & 1) {
         RUN(sd.forkto(0)); RUN(sd.forkto(1));
@@ -410,7 +430,9 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     float* dgi = ws + w.dgi;
     float* dgh = lstm ? dgi : ws + w.dgh;          // LSTM: d(gi) == d(gh)
 
-    Side& sd = g_side;
+    Side* sdp = side_here();
+    if (!sdp) return CAPHN_ELAUNCH;
+    Side& sd = *sdp;
     RUN(sd.begin(s, g_tune_fork != 0));
     void* cw0 = ws + w.colws_s[0]; void* cw1 = ws + w.colws_s[1]; void* cw2 = ws + w.colws_s[2];
 
@@ -422,6 +444,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     if (!late) {
         RUN(sd.forkto(0));
         RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, sd.s(0), gz));
+        RUN(sd.milestone(CAPHN_MS_VOCAB, sd.s(0)));
     }
     if (rmap) {   // rows of ignored targets have d logits == 0: dHs of those rows is zero, the others are gathered
         RUN(caphn_zero_f32(ws + w.dHs, (size_t)BT * H, s));
@@ -456,6 +479,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     if (late) RUN(sd.forkto(0));
     if (late && !hold_big) {   // the optimiser-only vocab gradients
         RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0, gz));
+        RUN(sd.milestone(CAPHN_MS_VOCAB, b0));
     }
     if (!raw) {
         if (!g->fc0_w || !g->fc0_b || !g->fc2_w || !g->fc2_b) return CAPHN_EINVAL;
@@ -481,15 +505,20 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, b2));
     if (!gz) RUN(caphn_zero_f32(g->embed_w, (size_t)V * E, b2));
     RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, b2));
+    RUN(sd.milestone(CAPHN_MS_EMBED, b2));
     // b1 -- recurrent weights dW_hh = dgh^T Hprev, dU_a = duah^T Hprev, biases by column sums; init_h / init_c
     RUN(wgrad_bias(GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, g->b_hh, nullptr, cw1, b1, gz));
     if (lstm) RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cw1, b1));      // dgh aliases dgi: db_ih == db_hh
+    // dL/dtheta = [dW_ih | dW_hh | db_ih | db_hh] is complete once E3 has fired on top of b1's own work so far: a
+    // data-parallel caller starts its all-gather of the rank-1 row factors here (CAPHN_MS_DTHETA)
+    RUN(sd.wait(3, b1));
+    RUN(sd.milestone(CAPHN_MS_DTHETA, b1));
     if (hook && !hold_big) {
-        // dL/dtheta = [dW_ih | dW_hh | db_ih | db_hh] is complete once E3 has fired: the hypernet VJP (HBM-bound
-        // transposed GEMV over the 576 MB of second-layer weights) runs here, beside the main chain
-        RUN(sd.wait(3, b1));
+        // the hypernet VJP (HBM-bound transposed GEMV over the 576 MB of second-layer weights) runs here, beside
+        // the main chain
         RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, b1));
     }
+    if (!hold_big) RUN(sd.milestone(CAPHN_MS_HYPER, b1));
     RUN(wgrad_bias(H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, g->Ua_b, nullptr, cw1, b1, gz));
     RUN(wgrad_bias(H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, g->inith_b, nullptr, cw1, b1, gz));
     if (lstm) RUN(wgrad_bias(H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, g->initc_b, nullptr, cw1, b1, gz));
@@ -504,10 +533,12 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
             // vocab gradients (b0) and the hypernet VJP (b1) start here, beside the two remaining chain GEMMs.
             RUN(sd.wait(4, b0));
             RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0, gz));
+            RUN(sd.milestone(CAPHN_MS_VOCAB, b0));
             if (hook) {
-                RUN(sd.wait(3, b1)); RUN(sd.wait(4, b1));
+                RUN(sd.wait(4, b1));
                 RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, b1));
             }
+            RUN(sd.milestone(CAPHN_MS_HYPER, b1));
         }
         RUN(caphn_gemm_f32(0, 0, BP, F, F, ws + w.df, F, p->fc2_w, F, ws + w.dY1, F, nullptr, ws + w.Y1, F, CAPHN_GEMM_MASK, 1, s));
         RUN(wgrad_bias(F, D, BP, ws + w.dY1, F, features, D, g->fc0_w, D, g->fc0_b, nullptr, cw0, s, gz));
@@ -525,6 +556,14 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     RUN(sd.jointo(0)); RUN(sd.jointo(1)); RUN(sd.jointo(2));
     (void)captions;
     return caphn_launch_status();
+}
+
+extern "C" int caphn_decoder_backward_milestone(int which, caphn_stream_t waiter) {
+    if (which < 0 || which >= CAPHN_MS_COUNT) return CAPHN_EINVAL;
+    Side* sd = side_here();
+    if (!sd) return CAPHN_ELAUNCH;
+    if (!sd->ready) return CAPHN_OK;      // no backward composite has run on this device: nothing to wait for
+    return hipStreamWaitEvent(static_cast<hipStream_t>(waiter), sd->ms[which], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
 }
 
 // Free-running / scheduled-sampling forward (no backward state kept: validation and inference).

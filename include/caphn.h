@@ -12,8 +12,17 @@
  *  - every pointer is a DEVICE pointer to fp32 (or int64 where stated) unless marked host;
  *    matrices are row-major with explicit leading dimensions (in elements);
  *  - every function enqueues work on `stream` and returns immediately: 0 on success,
- *    a negative CAPHN_E* code otherwise; nothing throws, nothing allocates, nothing
+ *    a negative CAPHN_E* code otherwise; nothing throws, nothing allocates device memory, nothing
  *    synchronises (graph-capture safe); scratch comes from the caller (`*_workspace_bytes`);
+ *  - Hidden state: the decoder composites (caphn_decoder_precompute / _forward / _backward /
+ *    _hyper_backward) run independent branches on side streams.  The library keeps ONE set of three
+ *    non-blocking streams and their fork/join/milestone events PER DEVICE, created lazily by the first
+ *    composite call made with that device current (creation is mutex-guarded; create it outside graph
+ *    capture by running one eager step first) and never destroyed.  Branches are forked from and
+ *    joined to `stream` with events, so the call is still "everything is ordered after `stream` so far,
+ *    and `stream` is ordered after everything" -- and a capturing stream captures the branches too.
+ *    USE of a device's set is not thread-safe: one host thread drives one device.  caphn_tune values
+ *    are process-global.  Nothing else is kept between calls;
  *  - parameter tensors keep the reference's layout: nn.Linear weight [out,in], GRUCell
  *    weight_ih [3H,E+F] / weight_hh [3H,H], gate order r,z,n.
  */
@@ -236,6 +245,22 @@ int caphn_decoder_hyper_backward(const caphn_decoder_dims* d, const caphn_decode
                                  const caphn_decoder_grads* g, void* ws,
                                  const caphn_hyper_desc* hd, const float* acts, const caphn_hyper_grads* hg, void* hyper_ws,
                                  caphn_stream_t stream);
+
+/* Milestones inside the LAST caphn_decoder_backward / caphn_decoder_hyper_backward enqueued on the current device: makes
+ * `waiter` wait (hipStreamWaitEvent) until that part of the backward has run, without waiting for the rest.  A
+ * data-parallel trainer starts its gradient exchange from these while the tail of the backward is still executing
+ * (SURVEY.md 8e "launched as soon as BPTT finishes each tensor"); `stream` of the composite itself is ordered after all
+ * of them.  Call from the thread that enqueued the composite, after it returned.
+ *   CAPHN_MS_DTHETA  g->w_ih, w_hh, b_ih, b_hh (= dL/dtheta, the row factors of the rank-1 second-layer gradients)
+ *   CAPHN_MS_VOCAB   g->out_w, out_b
+ *   CAPHN_MS_EMBED   g->embed_w (the caption tokens' rows)
+ *   CAPHN_MS_HYPER   everything caphn_hyper_backward writes (hg->*, g_x); equals CAPHN_MS_DTHETA without a hypernet hook */
+#define CAPHN_MS_DTHETA 0
+#define CAPHN_MS_VOCAB 1
+#define CAPHN_MS_EMBED 2
+#define CAPHN_MS_HYPER 3
+#define CAPHN_MS_COUNT 4
+int caphn_decoder_backward_milestone(int which, caphn_stream_t waiter);
 
 /* ---------------------------------------------------------------------------------------
  * Decoding (inference): beam search of HyperNet.test_step [hypernet_attention.py:251-306] and
