@@ -53,6 +53,7 @@ class FusedTrainer:
         front = ["fc.weight", "fc.bias", "embed.weight"]
         self._dec_names = front + [n for n in d0.names() if n not in self._cell_names and n not in front]
         self._vcache = {}
+        self._versions = {}
         self._invalidate_caches()
         self._build_arena()
         self._bufs: Dict[Tuple[int, int, int], dict] = {}
@@ -71,6 +72,7 @@ class FusedTrainer:
         # ring of pinned slots: the asynchronous H2D copy reads its slot when the GPU gets there, and the host may be
         # several steps ahead by then -- one slot per step (mod 64) instead of one buffer rewritten every step
         self._adam_host = torch.zeros(64, 2, dtype=torch.float32).pin_memory()
+        self._adam_copied = [None] * 64  # event after each slot's H2D copy: a slot is rewritten only once its copy has executed
         self._graph_scalars = False      # eager steps pass the Adam scalars by value (no copy, nothing to race with)
         self._graphs: Dict[tuple, object] = {}
         self._seen = set()
@@ -81,6 +83,8 @@ class FusedTrainer:
         # next-step feature_fc / init_hidden / W_a f issued on a side stream beside the small Adam passes
         self._pre_stream = torch.cuda.Stream(device=dev)
         self._pre_key = None
+        self._pre_hold = None
+        self._next_hold = None
         self._theta_pre = None
         self._loss_done = torch.cuda.Event()
         self._loss_pending = False
@@ -176,6 +180,7 @@ class FusedTrainer:
         hyper = self.net.hyper_named_tensors()
         dec = {"captioner." + n: t for n, t in self.cap._named_tensors().items() if n in self._dec_names}
         self._readopted = False
+        vers = self._versions
         for name in self.offs:
             cur = hyper.get(name, dec.get(name))
             o, n, shape = self.offs[name]
@@ -184,6 +189,14 @@ class FusedTrainer:
                     raise CaphnError(f"{name}: shape changed to {tuple(cur.shape)}, arena holds {shape}")
                 self._adopt(name, cur)
                 self._readopted = True
+            # torch-side writes into a parameter (load_state_dict, .copy_, an initialiser) bump its version counter;
+            # libcaphn's own updates go through raw pointers and do not.  A bump means anything derived from the old
+            # values -- the prefetched next theta, the side-stream precompute -- is stale.
+            v = cur._version
+            if vers.get(name) != v:
+                if name in vers:
+                    self._readopted = True
+                vers[name] = v
         for i in range(self._nh):
             w = hyper[f"hn_heads.{i}.2.weight"]
             if w is not self.W2[i] or not w.data.is_contiguous():
@@ -191,6 +204,11 @@ class FusedTrainer:
                 self.W2[i] = w
                 self._readopted = True
                 self._invalidate_caches()
+            v = w._version
+            if vers.get(i) != v:
+                if i in vers:
+                    self._readopted = True
+                vers[i] = v
 
     # ------------------------------------------------------------------ per-shape buffers
     def _buffers(self, B, T, P):
@@ -267,7 +285,7 @@ class FusedTrainer:
         theta = getattr(self, "_theta", None)
         if theta is None:
             theta = self._theta = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)
-        key = ("tok", int(style_token)) if style_token is not None else ("x", x_style.data_ptr())
+        key = ("tok", int(style_token)) if style_token is not None else ("x", x_style.data_ptr(), x_style._version)
         if self._next_key is not None and self._next_key == key and not self._readopted:
             # theta for this input was already produced by the previous optimiser pass
             self._theta, self._theta_next = self._theta_next, self._theta
@@ -282,9 +300,10 @@ class FusedTrainer:
         pre = 0
         if self._pre_key is not None:
             kf, kc, kB, kT, kP, level = self._pre_key
-            if (kf, kB, kT, kP) == (features.data_ptr(), B, T, P) and not self._readopted:
-                pre = 7 if (level == 2 and kc == captions.data_ptr() and theta is self._theta_pre) else 1
+            if (kf, kB, kT, kP) == (_tkey(features), B, T, P) and not self._readopted:
+                pre = 7 if (level == 2 and kc == _tkey(captions) and theta is self._theta_pre) else 1
             self._pre_key = None
+            self._pre_hold = None
             if pre == 1 and validate is False:
                 # what does not depend on the side stream's work goes first, so it hides behind the wait
                 if dims.rows:
@@ -398,10 +417,17 @@ class FusedTrainer:
         self.step_count += 1
         a, b = ops.adam_scalars(self.lr, self.betas, self.step_count)
         if self._graph_scalars:
-            slot = self._adam_host[self.step_count % 64]
+            i = self.step_count % 64
+            ev = self._adam_copied[i]
+            if ev is not None:
+                ev.synchronize()         # 64 steps ago: the host only blocks here if it runs that far ahead of the GPU
+            slot = self._adam_host[i]
             slot[0] = a
             slot[1] = b
             self._adam_dev.copy_(slot, non_blocking=True)
+            if ev is None:
+                ev = self._adam_copied[i] = torch.cuda.Event()
+            ev.record()
 
     def _optimizer_impl(self, next_x_style=None, next_style_token=None, next_batch=None):
         R = dp.world(self.group)
@@ -430,7 +456,8 @@ class FusedTrainer:
                 self._next_key = ("tok", int(next_style_token))
             else:
                 xn = next_x_style.reshape(-1).to(device=self.dev, dtype=torch.float32)
-                self._next_key = ("x", next_x_style.data_ptr())
+                self._next_key = ("x", next_x_style.data_ptr(), next_x_style._version)
+                self._next_hold = next_x_style        # the announced tensor stays alive: its address cannot be recycled
             ops.hyper_forward_acts(self.shape, hp, xn, self._acts_next)
             if self._theta_next is None:
                 self._theta_next = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)
@@ -480,8 +507,8 @@ class FusedTrainer:
                 ops.decoder_precompute(dims, params, features, buf["ws"])
             self._pre_done.record(self._pre_stream)
         self._theta_pre = theta if level == 2 else None
-        self._pre_key = (features.data_ptr(), captions.data_ptr() if (level == 2 and captions is not None) else None,
-                         B, T, P, level)
+        self._pre_key = (_tkey(features), _tkey(captions) if (level == 2 and captions is not None) else None, B, T, P, level)
+        self._pre_hold = (features, captions)         # announced tensors stay alive: their addresses cannot be recycled
 
     def optimizer_step(self, next_x_style=None, next_style_token=None, next_batch=None):
         """clip_grad_norm_(max_norm) over ALL gradients + Adam, on device, no host sync.
@@ -524,6 +551,12 @@ class FusedTrainer:
             g = self._graphs.get(key)
             if g is None:
                 self._sync_params()
+                # nothing from outside the capture may be pending inside it: a side-stream precompute announced by an
+                # earlier eager step (its event would be waited on by a capturing stream), a prefetched theta
+                if self._pre_key is not None:
+                    torch.cuda.current_stream().wait_event(self._pre_done)
+                self._pre_key = self._pre_hold = self._next_key = self._next_hold = None
+                torch.cuda.current_stream().wait_stream(self._pre_stream)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     loss = self.forward_backward(features, captions, x_style, style_token)
@@ -535,6 +568,73 @@ class FusedTrainer:
             self._graph_scalars = False
         return loss
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def optimizer_param_names(self) -> List[str]:
+        """Parameter order of the reference's optimiser (hypernet_attention.py:124-130 / cc_train_hypernet.py:110-118):
+        hn_heads, hn_base, captioner.feature_fc, .embed, .fc, .attention, .init_h (+ init_c for the LSTM configuration)."""
+        names = []
+        for i in range(self._nh):
+            names += [f"hn_heads.{i}.0.weight", f"hn_heads.{i}.0.bias", f"hn_heads.{i}.2.weight", f"hn_heads.{i}.2.bias"]
+        names += ["hn_base.0.weight", "hn_base.0.bias", "hn_base.2.weight", "hn_base.2.bias"]
+        dec = ["feature_fc.0.weight", "feature_fc.0.bias", "feature_fc.2.weight", "feature_fc.2.bias", "embed.weight",
+               "fc.weight", "fc.bias", "attention.W_a.weight", "attention.W_a.bias", "attention.U_a.weight",
+               "attention.U_a.bias", "attention.v_a.weight", "attention.v_a.bias", "init_h.weight", "init_h.bias",
+               "init_c.weight", "init_c.bias"]
+        names += ["captioner." + n for n in dec if n in self._dec_names]
+        return names
+
+    def _moments(self, name):
+        if name.startswith("hn_heads.") and name.endswith(".2.weight"):
+            i = int(name.split(".")[1])
+            return self.W2_m[i], self.W2_v[i]
+        return self._view(self.flat_m, name), self._view(self.flat_v, name)
+
+    def state_dict(self) -> dict:
+        """Optimiser state in torch.optim.Adam's state_dict layout (what Lightning checkpoints for the reference,
+        cc_train_hypernet.py:393): state[i] = {step, exp_avg, exp_avg_sq} with i the parameter's position in the reference's
+        optimiser list, one param_group; `param_names` (extra key) spells that order out.  Parameters themselves are
+        ordinary module state (net.state_dict())."""
+        names = self.optimizer_param_names()
+        state = {}
+        for i, n in enumerate(names):
+            m, v = self._moments(n)
+            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.detach().clone(),
+                        "exp_avg_sq": v.detach().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group], "param_names": names, "max_norm": self.max_norm}
+
+    def load_state_dict(self, sd: dict) -> None:
+        """Inverse of state_dict (also accepts a torch.optim.Adam state_dict built over the reference's parameter list).
+        Call after the module's own load_state_dict."""
+        names = self.optimizer_param_names()
+        if "param_names" in sd and list(sd["param_names"]) != names:
+            raise CaphnError("optimiser state was saved for a different parameter list")
+        st = sd["state"]
+        if len(st) not in (0, len(names)):
+            raise CaphnError(f"optimiser state holds {len(st)} entries, this trainer has {len(names)} parameters")
+        steps = set()
+        for i, n in enumerate(names):
+            if i not in st:
+                continue
+            m, v = self._moments(n)
+            m.copy_(st[i]["exp_avg"].to(device=self.dev, dtype=torch.float32).view_as(m))
+            v.copy_(st[i]["exp_avg_sq"].to(device=self.dev, dtype=torch.float32).view_as(v))
+            steps.add(int(st[i]["step"]))
+        if len(steps) > 1:
+            raise CaphnError(f"per-parameter step counts differ ({sorted(steps)}): one fused step counter cannot represent them")
+        self.step_count = steps.pop() if steps else 0
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+        if "max_norm" in sd:
+            self.max_norm = sd["max_norm"]
+        # whatever was derived from the previous state is stale
+        self._next_key = self._next_hold = None
+        if self._pre_key is not None:
+            torch.cuda.current_stream().wait_event(self._pre_done)
+        self._pre_key = self._pre_hold = None
+        self._graphs.clear(); self._seen.clear()
+
     # ------------------------------------------------------------------ introspection for tests
     def grad(self, name):
         return self._view(self.flat_g, name)
@@ -545,6 +645,12 @@ class FusedTrainer:
         k, w = self.shape.heads[i]
         ao, an = self._acts_layout[f"a{i}"]
         return ops.outer(self.flat_g[o:o + w].contiguous(), self._acts[ao:ao + an].contiguous())
+
+
+def _tkey(t):
+    """Identity of an announced input: its address AND its version counter (an in-place refill of the same buffer, or a
+    new tensor that the caching allocator placed at a freed address, is a different input)."""
+    return (t.data_ptr(), t._version)
 
 
 def L_sumsq_blocks(n):

@@ -236,6 +236,59 @@ class FusedPlainTrainer:
         return loss
 
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def optimizer_param_names(self) -> List[str]:
+        """hypernet.py:116-123: hn_heads (ALL heads, also the ones whose output nothing reads), hn_base, captioner.embed,
+        image_encoder.fc."""
+        names = []
+        for i in range(len(self.net._shape.heads)):
+            names += [f"hn_heads.{i}.0.weight", f"hn_heads.{i}.0.bias", f"hn_heads.{i}.2.weight", f"hn_heads.{i}.2.bias"]
+        return names + ["hn_base.0.weight", "hn_base.0.bias", "hn_base.2.weight", "hn_base.2.bias", "captioner.embed.weight",
+                        "image_encoder.fc.weight", "image_encoder.fc.bias"]
+
+    def _moments(self, name):
+        if name.startswith("hn_heads."):
+            i = int(name.split(".")[1])
+            if i >= self.n_live:
+                return None                      # never receives a gradient: torch's Adam keeps no state for it either
+            if name.endswith(".2.weight"):
+                return self.W2_m[i], self.W2_v[i]
+        return self._view(self.flat_m, name), self._view(self.flat_v, name)
+
+    def state_dict(self) -> dict:
+        """torch.optim.Adam's state_dict layout over the reference's parameter list (see FusedTrainer.state_dict)."""
+        names = self.optimizer_param_names()
+        state = {}
+        for i, n in enumerate(names):
+            mv = self._moments(n)
+            if mv is not None and self.step_count > 0:
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": mv[0].detach().clone(),
+                            "exp_avg_sq": mv[1].detach().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group], "param_names": names}
+
+    def load_state_dict(self, sd: dict) -> None:
+        names = self.optimizer_param_names()
+        if "param_names" in sd and list(sd["param_names"]) != names:
+            raise CaphnError("optimiser state was saved for a different parameter list")
+        steps = set()
+        for i, n in enumerate(names):
+            mv = self._moments(n)
+            if mv is None or i not in sd["state"]:
+                continue
+            e = sd["state"][i]
+            mv[0].copy_(e["exp_avg"].to(device=self.dev, dtype=torch.float32).view_as(mv[0]))
+            mv[1].copy_(e["exp_avg_sq"].to(device=self.dev, dtype=torch.float32).view_as(mv[1]))
+            steps.add(int(e["step"]))
+        if len(steps) > 1:
+            raise CaphnError(f"per-parameter step counts differ ({sorted(steps)})")
+        self.step_count = steps.pop() if steps else 0
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+        self._next_token = None                  # a theta prefetched from the previous weights is stale
+
+
 def _numel(shape) -> int:
     n = 1
     for s in shape:

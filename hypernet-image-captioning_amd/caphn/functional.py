@@ -14,22 +14,29 @@ class _DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dims, features, captions, *tensors):
+        if features.requires_grad:
+            raise NotImplementedError("no gradient flows to the encoder's feature map: the reference freezes its encoder "
+                                      "(models/encoder.py:11-13); detach the features")
         params = {n: t.detach().contiguous() for n, t in zip(dims.names(), tensors)}
         features = features.detach().contiguous()
         captions = captions.contiguous()
         ws = ops.decoder_workspace(dims, features.device)
         logits, alphas = ops.decoder_forward(dims, params, features, captions, ws)
-        ctx.dims, ctx.ws, ctx.params, ctx.features, ctx.captions = dims, ws, params, features, captions
+        # saved through autograd: a parameter updated in place between forward and backward is detected (version check)
+        ctx.save_for_backward(features, captions, *tensors)
+        ctx.dims, ctx.ws = dims, ws
         return logits, alphas
 
     @staticmethod
     def backward(ctx, dlogits, dalphas):
         dims = ctx.dims
-        dev = ctx.features.device
+        features, captions, *tensors = ctx.saved_tensors
+        params = {n: t.detach().contiguous() for n, t in zip(dims.names(), tensors)}
+        dev = features.device
         if dlogits is None:
             dlogits = torch.zeros(dims.B, dims.T, dims.V, device=dev)
         grads = {n: torch.empty(s, dtype=torch.float32, device=dev) for n, s in dims.param_shapes().items()}
-        ops.decoder_backward(dims, ctx.params, ctx.features, ctx.captions, dlogits.contiguous(), grads, ctx.ws,
+        ops.decoder_backward(dims, params, features, captions, dlogits.contiguous(), grads, ctx.ws,
                              dalphas.contiguous() if dalphas is not None else None)
         ctx.ws = None
         return (None, None, None) + tuple(grads[n] for n in dims.names())

@@ -68,3 +68,33 @@ class FusedAdam:
             if not p.data.is_contiguous():
                 raise CaphnError("FusedAdam needs contiguous parameters")
             ops.adam_dense(p.data.view(-1), m.view(-1), v.view(-1), g.view(-1), coef, self.lr, self.step_count, self.betas, self.eps)
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self) -> dict:
+        """torch.optim.Adam's state_dict layout (state[i] = {step, exp_avg, exp_avg_sq} for the i-th parameter given to the
+        constructor; parameters that never received a gradient have no entry, as in torch)."""
+        state = {}
+        if self.step_count > 0:
+            for i, (m, v) in enumerate(zip(self.m, self.v)):
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.detach().clone(),
+                            "exp_avg_sq": v.detach().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group], "max_norm": self.max_norm}
+
+    def load_state_dict(self, sd: dict) -> None:
+        st = sd["state"]
+        steps = set()
+        for i, (m, v) in enumerate(zip(self.m, self.v)):
+            if i not in st:
+                continue
+            m.copy_(st[i]["exp_avg"].to(device=m.device, dtype=torch.float32).view_as(m))
+            v.copy_(st[i]["exp_avg_sq"].to(device=v.device, dtype=torch.float32).view_as(v))
+            steps.add(int(st[i]["step"]))
+        if len(steps) > 1:
+            raise CaphnError(f"per-parameter step counts differ ({sorted(steps)}): FusedAdam keeps one step counter")
+        self.step_count = steps.pop() if steps else 0
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+        if "max_norm" in sd:
+            self.max_norm = sd["max_norm"]

@@ -29,6 +29,7 @@ struct Side {
     hipEvent_t fork, join[3], x[6];
     hipEvent_t ms[CAPHN_MS_COUNT];     // milestones of the last backward composite (caphn_decoder_backward_milestone)
     bool ready = false, on = false;
+    bool forked[3] = {false, false, false};
     hipStream_t main = nullptr;
     int init() {
         if (ready) return CAPHN_OK;
@@ -57,14 +58,24 @@ struct Side {
     int forkto(int i) {
         if (!on) return CAPHN_OK;
         if (hipEventRecord(fork, main) != hipSuccess) return CAPHN_ELAUNCH;
-        return hipStreamWaitEvent(st[i], fork, 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+        if (hipStreamWaitEvent(st[i], fork, 0) != hipSuccess) return CAPHN_ELAUNCH;
+        forked[i] = true;
+        return CAPHN_OK;
     }
     // main continues only after branch i's work so far
     int jointo(int i) {
         if (!on) return CAPHN_OK;
+        forked[i] = false;
         if (hipEventRecord(join[i], st[i]) != hipSuccess) return CAPHN_ELAUNCH;
         return hipStreamWaitEvent(main, join[i], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
     }
+    // A composite that returns early (a failed launch) must not leave a branch forked: inside a stream capture an
+    // unjoined branch makes hipStreamEndCapture fail (hipErrorStreamCaptureUnjoined) -- every composite holds a Scope.
+    struct Scope {
+        Side& s;
+        explicit Scope(Side& side) : s(side) {}
+        ~Scope() { for (int i = 0; i < 3; ++i) if (s.on && s.forked[i]) (void)s.jointo(i); }
+    };
     // cross-branch dependency in two halves: record slot k at the producer's current tail, wait later on the consumer
     int record(int k, hipStream_t from) {
         if (!on) return CAPHN_OK;
@@ -244,6 +255,7 @@ static int decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_p
     if (!sdp) return CAPHN_ELAUNCH;
     Side& sd = *sdp;
     RUN(sd.begin(s, g_tune_fork != 0 && (parts & 1)));
+    Side::Scope scope(sd);
     if (parts & 1) {
         RUN(sd.forkto(0)); RUN(sd.forkto(1));
         // branch 0 -- init_hidden: mean over positions -> Linear(F,H) (and init_c for the LSTM)      :122-135 / :255-260
@@ -424,6 +436,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     const int RG = caphn_rec_resident_gates(P, H, w.NG);
     if (RG < 0) return CAPHN_ELIMIT;
     if (lstm && (!g->initc_w || !g->initc_b)) return CAPHN_EINVAL;
+    if (!raw && (!g->fc0_w || !g->fc0_b || !g->fc2_w || !g->fc2_b)) return CAPHN_EINVAL;    // before any branch is forked
     void* cws = ws + w.colws;
     const int64_t* idx = reinterpret_cast<const int64_t*>(ws + w.idx);
     const float* f = raw ? features : ws + w.f;
@@ -434,6 +447,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     if (!sdp) return CAPHN_ELAUNCH;
     Side& sd = *sdp;
     RUN(sd.begin(s, g_tune_fork != 0));
+    Side::Scope scope(sd);
     void* cw0 = ws + w.colws_s[0]; void* cw1 = ws + w.colws_s[1]; void* cw2 = ws + w.colws_s[2];
 
     // vocab projection.  dHs = dlogits W feeds BPTT (main); dW = dlogits^T Hs and db = colsum(dlogits) are only
@@ -482,7 +496,6 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
         RUN(sd.milestone(CAPHN_MS_VOCAB, b0));
     }
     if (!raw) {
-        if (!g->fc0_w || !g->fc0_b || !g->fc2_w || !g->fc2_b) return CAPHN_EINVAL;
         // The chain's own small inputs stay on the chain's stream: waiting on a side-stream event here stalled
         // the chain for ~275 us in the kernel trace although the producers had long finished.
         RUN(caphn_gemm_f32(0, 0, BT, F, GH, dgi, GH, p->w_ih + E, EF, ws + w.dctx, F, nullptr, nullptr, 0, 0, 1, s));

@@ -7,6 +7,9 @@ restart (utils.py:68): every extra layer re-reads theta from offset 0, so its he
 The reference file cannot be imported in the reference itself (hypernet.py:11 names classes that only exist in the
 import-less later.py); image encoder (ResNet-101 download), metrics and GloVe loading are out of scope.
 """
+import warnings
+
+import numpy as np
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -99,6 +102,12 @@ class HyperNet(_Base):
         style_embed = self.captioner.embed(style)
         self.forward(style_embed)
         img_feats = self.image_encoder(imgs.float())
+        # hypernet.py:134-137 draws np.random.binomial(1, teacher_forcing_proba) and, on a 0, runs the sampled branch
+        # (torch.multinomial per step, later.py:424-426).  The draw is made (same RNG consumption); the sampled branch is
+        # not fused, so such a step is teacher forced here -- said out loud, not silently.
+        if not np.random.binomial(1, self.teacher_forcing_proba):
+            warnings.warn("hypernet.HyperNet.training_step: the reference would have taken the sampled (torch.multinomial) "
+                          "branch for this step; this build teacher-forces it", RuntimeWarning, stacklevel=2)
         caps_pred = self.captioner(img_feats, caps.long(), True)
         loss = F.cross_entropy(caps_pred.view(-1, self.hparams['vocab_size']), caps.view(-1).long())
         if self.teacher_forcing_proba > 0.25:

@@ -1,0 +1,104 @@
+"""BASELINE config 1: the call pattern of train_gru.py on its bs = 8 plumbing case.
+
+train_gru.py:45 builds `GruNet(2048, features, embed, hidden, vocab, num_layers=num_layers, p=0.0)` (a name its own
+models/decoderlstm.py never defines; AttentionGru's constructor) and uses the result of `captioner(img_feats,
+caps.long(), prob)` as ONE tensor: `.view(-1, vocab_size)` into F.cross_entropy(ignore_index=<pad>) (:84-86, :104-108),
+Adam over `captioner.parameters()` (:65-66).  The image encoder is out of scope (synthetic [8, 49, 2048] feature maps).
+Checked against the oracle's logits / loss / gradients; the product path is libcaphn (there is no CPU backend)."""
+import pytest
+import torch
+from torch.nn import functional as F
+
+from helpers import maxdiff
+from oracle import caphn_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(seed=0, V=300):
+    from models.decoderlstm import GruNet
+    torch.manual_seed(seed)
+    net = GruNet(2048, 64, 48, 56, V, num_layers=1, p=0.0)       # train_gru.py:45
+    dims = O.Dims(D=2048, F=64, E=48, H=56, V=V, he=48)
+    return net, dims
+
+
+def _oracle_view(net):
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    p = {"captioner." + k: v for k, v in sd.items() if not k.startswith("gru.")}
+    cellw = {k[4:]: v for k, v in sd.items() if k.startswith("gru.")}
+    return p, cellw
+
+
+def test_grunet_training_step_pattern_bs8():
+    net, dims = _build()
+    p, cellw = _oracle_view(net)
+    batch = O.synth_batch(dims, B=8, T=12, P=49, seed=5)
+    feats, caps = batch["features"], batch["captions"].float()       # the collate yields float captions (data_loader.py:368-383)
+    net = net.to(DEV).train()
+    caps_pred = net(feats.to(DEV), caps.to(DEV).long(), 0.0)                         # :85 (the 0.0 call)
+    assert isinstance(caps_pred, torch.Tensor) and caps_pred.shape == (8, 12, dims.V)
+    loss = F.cross_entropy(caps_pred.view(-1, dims.V), caps.to(DEV).view(-1).long(), ignore_index=0)
+    loss.backward()
+    # oracle
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    cw = {k: v.clone().requires_grad_(True) for k, v in cellw.items()}
+    ref, _ = O.decoder_forward(dims, q, cw, feats, caps.long())
+    ref_loss = O.caption_loss(ref, caps.long())
+    ref_loss.backward()
+    assert maxdiff(caps_pred.detach().cpu(), ref.detach()) < 5e-6
+    assert abs(float(loss) - float(ref_loss)) < 2e-6
+    got = dict(net.named_parameters())
+    for k, v in q.items():
+        assert maxdiff(got[k[len("captioner."):]].grad.cpu(), v.grad) < 5e-6, k
+    for k, v in cw.items():
+        assert maxdiff(got["gru." + k].grad.cpu(), v.grad) < 5e-6, k
+    # token argmax agrees wherever the oracle's own top-2 margin is not a rounding tie
+    top2 = ref.detach().topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 2e-5
+    assert torch.equal(caps_pred.detach().cpu().argmax(-1)[clear], ref.detach().argmax(-1)[clear])
+
+
+def test_grunet_adam_steps_follow_the_oracle():
+    """configure_optimizers (:65-66): torch.optim.Adam over captioner.parameters(); three steps of the call pattern."""
+    net, dims = _build(seed=1)
+    p, cellw = _oracle_view(net)
+    batch = O.synth_batch(dims, B=8, T=10, P=49, seed=6)
+    feats, caps = batch["features"], batch["captions"]
+    net = net.to(DEV).train()
+    opt = torch.optim.Adam(list(net.parameters()), lr=5e-3)                          # lr of train_gru.py:115
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    cw = {k: v.clone().requires_grad_(True) for k, v in cellw.items()}
+    ropt = torch.optim.Adam(list(q.values()) + list(cw.values()), lr=5e-3)
+    for step in range(3):
+        opt.zero_grad()
+        out = net(feats.to(DEV), caps.to(DEV), 0.0)
+        loss = F.cross_entropy(out.view(-1, dims.V), caps.to(DEV).view(-1), ignore_index=0)
+        loss.backward()
+        ropt.zero_grad()
+        ref, _ = O.decoder_forward(dims, q, cw, feats, caps)
+        rl = O.caption_loss(ref, caps)
+        rl.backward()
+        assert abs(float(loss) - float(rl)) < 1e-5 * (step + 1), step
+        # identical gradients into both optimisers would hide nothing here: the two paths run their own Adam on their own
+        # gradients, so only the loss trajectory is compared tightly (Adam amplifies rounding noise of ~0 gradients)
+        opt.step(); ropt.step()
+    assert float(loss) < 5.8
+
+
+def test_grunet_validation_step_pattern():
+    """validation_step (:95-97) runs the 0.0 call without gradients; the 1.0 (free-running) call of training_step (:84)
+    returns a single tensor too."""
+    net, dims = _build(seed=2)
+    p, cellw = _oracle_view(net)
+    batch = O.synth_batch(dims, B=8, T=9, P=49, seed=7)
+    feats, caps = batch["features"], batch["captions"]
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        a = net(feats.to(DEV), caps.to(DEV), 0.0)
+        b = net(feats.to(DEV), caps.to(DEV), 1.0)
+    ra, _ = O.decoder_forward(dims, p, cellw, feats, caps)
+    rb, _ = O.decoder_forward(dims, p, cellw, feats, caps, use_sampling=[True] * 9)
+    assert maxdiff(a.cpu(), ra) < 5e-6
+    assert maxdiff(b.cpu(), rb) < 2e-5 and torch.equal(b.cpu().argmax(-1), rb.argmax(-1))
