@@ -61,6 +61,7 @@ class FusedTrainer:
         self._acc = torch.zeros(1, dtype=torch.float64, device=dev)
         self._coef = torch.zeros(2, dtype=torch.float32, device=dev)
         self._part = torch.empty(L_sumsq_blocks(self.n_dense), dtype=torch.float64, device=dev)
+        self._gradnorm = {}
         self._acts_layout = ops.hyper_acts_layout(self.shape)
         self._acts = torch.zeros(self._acts_layout["_total"][1], dtype=torch.float32, device=dev)
         self._hyper_ws = None
@@ -327,14 +328,9 @@ class FusedTrainer:
         ops.cross_entropy_rows(buf["logits"], captions, 0, buf["logits"], buf["ce_ws"], leave_ignored_rows=dims.rows,
                                n_valid_ptr=cnt)
         dlogits = buf["logits"]
-        if torch.cuda.is_current_stream_capturing():
-            ops.cross_entropy_finish(B * T, buf["ce_ws"], buf["loss"], cnt)
-        else:
-            self._pre_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._pre_stream):
-                ops.cross_entropy_finish(B * T, buf["ce_ws"], buf["loss"], cnt)
-                self._loss_done.record(self._pre_stream)
-            self._loss_pending = True
+        # (the reduction of the per-row losses used to run on the side stream; the two events that took -- a record on
+        #  this stream, a wait at the end of the backward -- cost the chain more than the 6 us kernel does in line)
+        ops.cross_entropy_finish(B * T, buf["ce_ws"], buf["loss"], cnt)
         dtheta = self.flat_g[:self.theta_size]
         grads = self._dec_tensors(dtheta, grads=True)
         hg = self._hg_cache
@@ -432,8 +428,6 @@ class FusedTrainer:
     def _optimizer_impl(self, next_x_style=None, next_style_token=None, next_batch=None):
         R = dp.world(self.group)
         gfac, acts_all = self._exchange()
-        part = ops.sumsq_partials(self.flat_g, self._part)
-        self._acc.zero_()
         o = 0
         segs = []
         for i, (k, w) in enumerate(self.shape.heads):
@@ -441,8 +435,12 @@ class FusedTrainer:
             gi, ai = gfac[:, o:o + w], acts_all[:, ao:ao + an]
             segs.append((gi, ai, o, w, ao, an))
             o += w
-        ops.rank_sumsq_multi([(s[0], s[1]) for s in segs], self._acc)
-        ops.clip_coef(part, self._acc, self.max_norm, 1.0 / R, out=self._coef)
+        # global gradient norm (dense arena + Gram-matrix norm of the rank-R second-layer gradients) and the clip
+        # coefficient, one launch
+        gn = self._gradnorm.get(R)
+        if gn is None:
+            gn = self._gradnorm[R] = ops.GradNorm(self.n_dense, R, len(segs), self.dev)
+        gn(self.flat_g, [(s[0], s[1]) for s in segs], self.max_norm, 1.0 / R, self._coef)
         step = max(self.step_count, 1)
         ops.adam_dense(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self._coef, self.lr, step,
                        self.betas, self.eps, dev_scalars=self._adam_dev if self._graph_scalars else None)

@@ -570,6 +570,37 @@ def rank_sumsq_multi(pairs, acc: torch.Tensor, ws: Optional[torch.Tensor] = None
                                            L.ptr(ws, torch.float64), L.stream_ptr()), "caphn_rank_sumsq_multi_f32")
 
 
+class GradNorm:
+    """clip_grad_norm_'s coefficient in one launch (caphn_grad_norm_coef): sum of squares of a flat gradient arena plus the
+    norm of rank-R gradients given by their factors.  Holds the (zero-initialised) workspace and the argument arrays, which
+    are rebuilt only when a pointer or a stride changes."""
+
+    def __init__(self, n: int, R: int, njobs: int, device):
+        lib = L.load()
+        self.n, self.R, self.njobs = n, R, njobs
+        self.ws = torch.zeros(lib.caphn_grad_norm_workspace_bytes(n, R, njobs), dtype=torch.uint8, device=device)
+        self._key = None
+
+    def __call__(self, flat_g: torch.Tensor, pairs, max_norm: float, scale: float, out: torch.Tensor) -> torch.Tensor:
+        lib = L.load()
+        n = len(pairs)
+        assert flat_g.numel() == self.n and n == self.njobs and (n == 0 or pairs[0][0].shape[0] == self.R)
+        key = (flat_g.data_ptr(),) + tuple((g.data_ptr(), g.stride(0), g.shape[1], a.data_ptr(), a.stride(0), a.shape[1]) for g, a in pairs)
+        if key != self._key:
+            self._args = ((C.c_int * n)(*[g.shape[1] for g, _ in pairs]), (C.c_int * n)(*[a.shape[1] for _, a in pairs]),
+                          (C.c_void_p * n)(*[g.data_ptr() for g, _ in pairs]), (C.c_size_t * n)(*[g.stride(0) for g, _ in pairs]),
+                          (C.c_void_p * n)(*[a.data_ptr() for _, a in pairs]), (C.c_size_t * n)(*[a.stride(0) for _, a in pairs]))
+            for g, a in pairs:
+                assert g.stride(1) == 1 and a.stride(1) == 1 and g.dtype == torch.float32 and a.dtype == torch.float32
+            L.ptr(flat_g)
+            self._key = key
+        rows, ks, gp, ldg, ap, lda = self._args
+        L.check(lib.caphn_grad_norm_coef(self.n, C.c_void_p(flat_g.data_ptr()), self.R, n, rows, ks, gp, ldg, ap, lda,
+                                         float(max_norm), float(scale), L.ptr(out), C.c_void_p(self.ws.data_ptr()),
+                                         L.stream_ptr()), "caphn_grad_norm_coef")
+        return out
+
+
 def decoder_hyper_backward(dims: DecDims, params, features, captions, dlogits, grads, ws,
                            shape: HyperShape, hyper_params, acts, hyper_grads, hyper_ws, want_x: bool = False):
     """decoder_backward + hyper_backward in one call; the hypernet VJP overlaps the decoder's tail.

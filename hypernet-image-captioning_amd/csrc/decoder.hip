@@ -11,6 +11,7 @@
 #include "decoder_internal.h"
 #include "gemm_internal.h"
 #include <algorithm>
+#include <initializer_list>
 #include <mutex>
 
 int g_tune_rec_rotate = 1;
@@ -60,6 +61,17 @@ struct Side {
         if (hipEventRecord(fork, main) != hipSuccess) return CAPHN_ELAUNCH;
         if (hipStreamWaitEvent(st[i], fork, 0) != hipSuccess) return CAPHN_ELAUNCH;
         forked[i] = true;
+        return CAPHN_OK;
+    }
+    // several branches start at the same point of main: ONE event record (a record costs the recording stream ~5-7 us of
+    // queue time -- three of them sat between the BPTT kernel and the first kernel of the chain behind it)
+    int fork_many(std::initializer_list<int> ids) {
+        if (!on) return CAPHN_OK;
+        if (hipEventRecord(fork, main) != hipSuccess) return CAPHN_ELAUNCH;
+        for (int i : ids) {
+            if (hipStreamWaitEvent(st[i], fork, 0) != hipSuccess) return CAPHN_ELAUNCH;
+            forked[i] = true;
+        }
         return CAPHN_OK;
     }
     // main continues only after branch i's work so far
@@ -175,6 +187,13 @@ __global__ __launch_bounds__(1024) void valid_rows_kernel(int n, const int64_t* 
     if (tid == 0) map[0] = base_s;
 }
 
+// src[0..n) -> a, src[n] -> b
+__global__ void copy2_kernel(const float* __restrict__ src, int n, float* __restrict__ a, float* __restrict__ b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = src[i];
+    else if (i == n) b[0] = src[n];
+}
+
 __global__ void build_idx_kernel(int B, int T, const int64_t* __restrict__ caps, int64_t* __restrict__ idx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * T) return;
@@ -257,7 +276,7 @@ static int decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_p
     RUN(sd.begin(s, g_tune_fork != 0 && (parts & 1)));
     Side::Scope scope(sd);
     if (parts & 1) {
-        RUN(sd.forkto(0)); RUN(sd.forkto(1));
+        RUN(sd.fork_many({0, 1}));
         // branch 0 -- init_hidden: mean over positions -> Linear(F,H) (and init_c for the LSTM)      :122-135 / :255-260
         RUN(caphn_launch_init_state(B, P, F, H, f, p->inith_w, p->inith_b, lstm ? p->initc_w : nullptr, lstm ? p->initc_b : nullptr,
                                     ws + w.meanf, ws + w.h0, lstm ? ws + w.c0 : nullptr, sd.s(0)));
@@ -488,9 +507,8 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     // product is a leaf of it.  Leaves run on branches 0-2; E0..E4 are record/wait events between streams.
     //   E2 dWaf ready (main)   E3 dW_ih ready (b2)   E4 df ready (main)
     hipStream_t b0 = sd.s(0), b1 = sd.s(1), b2 = sd.s(2);
-    RUN(sd.forkto(1)); RUN(sd.forkto(2));
     const bool hold_big = late && !raw && g_tune_fork == 3;   // 3: release the two big leaves only once df exists (measured: no gain)
-    if (late) RUN(sd.forkto(0));
+    if (late) RUN(sd.fork_many({0, 1, 2})); else RUN(sd.fork_many({1, 2}));
     if (late && !hold_big) {   // the optimiser-only vocab gradients
         RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0, gz));
         RUN(sd.milestone(CAPHN_MS_VOCAB, b0));
@@ -559,8 +577,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     // b2 (leaves of the chain) -- d v_a, d b_va, dW_a, db_Wa once dWaf exists; fc2 gradients once df exists
     RUN(sd.wait(2, b2));
     RUN(caphn_colsum_f32(B * (ang > 0 ? ang : w.npc), H + 1, ws + w.apart, H + 1, ws + w.vtmp, cw2, b2));
-    if (hipMemcpyAsync(g->va_w, ws + w.vtmp, sizeof(float) * H, hipMemcpyDeviceToDevice, b2) != hipSuccess) return CAPHN_ELAUNCH;
-    if (hipMemcpyAsync(g->va_b, ws + w.vtmp + H, sizeof(float), hipMemcpyDeviceToDevice, b2) != hipSuccess) return CAPHN_ELAUNCH;
+    hipLaunchKernelGGL(copy2_kernel, dim3((H + 256) / 256), dim3(256), 0, b2, ws + w.vtmp, H, g->va_w, g->va_b);   // one launch, no runtime blits
     RUN(wgrad_bias(H, F, BP, ws + w.dWaf, H, f, F, g->Wa_w, F, g->Wa_b, nullptr, cw2, b2, gz));
     if (!raw) {
         RUN(sd.wait(4, b2));

@@ -18,6 +18,7 @@ struct GemvJob {
     const float* W; const float* b; const float* x; float* y;
     int rows, k, act, vec;   // act: 1 = LeakyReLU; vec: 16-byte loads legal
     int block0, nblocks;
+    float* xcopy;            // optional: the job's first block also stores x[0..k) here (the saved input of the backward)
 };
 struct GemvJobs { GemvJob j[CAPHN_MAX_HEADS]; int n; };
 
@@ -152,6 +153,8 @@ __global__ __launch_bounds__(256) void gemv_fwd_kernel(GemvJobs jobs) {
     for (int i = 1; i < jobs.n; ++i) if ((int)blockIdx.x >= jobs.j[i].block0) ji = i;
     const GemvJob& J = jobs.j[ji];
     const int lb = blockIdx.x - J.block0, tid = threadIdx.x;
+    if (J.xcopy && lb == 0)
+        for (int i = tid; i < J.k; i += 256) J.xcopy[i] = J.x[i];
     if (J.vec && J.k >= 128 && J.k <= 256 * QMAX) {
         const int wave_g = lb * 4 + (tid >> 6), nwaves = J.nblocks * 4, lane = tid & 63;
         gemv_rows_wave<QMAX, RB, NTL>(J, wave_g, nwaves, lane);
@@ -398,23 +401,23 @@ static int hyper_forward_impl(const caphn_hyper_desc* d, const float* x, float* 
     if (!desc_ok(d) || !x || !acts) return CAPHN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const ActsLayout L = acts_layout(d);
-    if (hipMemcpyAsync(acts + L.x, x, sizeof(float) * d_in(d), hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return CAPHN_ELAUNCH;
-    auto one = [&](const float* W, const float* b, const float* in, float* out, int rows, int k, int act) {
+    // (x is kept in acts for the backward: the first GEMV's first block stores it -- a hipMemcpyAsync here cost a
+    //  runtime blit kernel plus ~10-30 us of queue bubble in front of the optimiser's rank-1 passes)
+    auto one = [&](const float* W, const float* b, const float* in, float* out, int rows, int k, int act, float* xcopy) {
         GemvJobs jobs; jobs.n = 1;
         GemvJob& J = jobs.j[0];
-        J.W = W; J.b = b; J.x = in; J.y = out; J.rows = rows; J.k = k; J.act = act;
+        J.W = W; J.b = b; J.x = in; J.y = out; J.rows = rows; J.k = k; J.act = act; J.xcopy = xcopy;
         J.vec = vec_ok(W, in, k); J.block0 = 0; J.nblocks = gemv_blocks(rows, k, J.vec);
         launch_gemv_fwd(jobs, J.nblocks, s);
     };
-    one(d->base_w0, d->base_b0, acts + L.x, acts + L.a0, d_mid(d), d_in(d), 1);
-    one(d->base_w2, d->base_b2, acts + L.a0, acts + L.base, d->he, d_mid(d), 1);
+    one(d->base_w0, d->base_b0, x, acts + L.a0, d_mid(d), d_in(d), 1, x == acts + L.x ? nullptr : acts + L.x);
+    one(d->base_w2, d->base_b2, acts + L.a0, acts + L.base, d->he, d_mid(d), 1, nullptr);
     {   // first layers of all heads in one launch
         GemvJobs jobs; jobs.n = d->n_heads; int b0 = 0;
         for (int i = 0; i < d->n_heads; ++i) {
             GemvJob& J = jobs.j[i];
             J.W = d->w1[i]; J.b = d->b1[i]; J.x = acts + L.base; J.y = acts + L.a[i];
-            J.rows = d->k[i]; J.k = d->he; J.act = 1; J.vec = vec_ok(J.W, J.x, J.k);
+            J.rows = d->k[i]; J.k = d->he; J.act = 1; J.vec = vec_ok(J.W, J.x, J.k); J.xcopy = nullptr;
             J.block0 = b0; J.nblocks = gemv_blocks(J.rows, J.k, J.vec); b0 += J.nblocks;
         }
         launch_gemv_fwd(jobs, b0, s);
@@ -424,7 +427,7 @@ static int hyper_forward_impl(const caphn_hyper_desc* d, const float* x, float* 
         for (int i = 0; i < d->n_heads; ++i) {
             GemvJob& J = jobs.j[i];
             J.W = d->w2[i]; J.b = d->b2[i]; J.x = acts + L.a[i]; J.y = theta + off; off += d->w[i];
-            J.rows = d->w[i]; J.k = d->k[i]; J.act = 0; J.vec = vec_ok(J.W, J.x, J.k);
+            J.rows = d->w[i]; J.k = d->k[i]; J.act = 0; J.vec = vec_ok(J.W, J.x, J.k); J.xcopy = nullptr;
             J.block0 = b0; J.nblocks = gemv_blocks(J.rows, J.k, J.vec); b0 += J.nblocks;
         }
         launch_gemv_fwd(jobs, b0, s);

@@ -300,6 +300,80 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(int nparts, const double
     }
 }
 
+// The whole clip coefficient in two launches: (1) partial sums -- sum of squares of the dense gradient arena and the dot
+// products behind the Gram-matrix norm of the rank-R second-layer gradients -- one slot per block, no atomics, fixed
+// summation order; (2) one block reduces the slots and writes clip_grad_norm_'s coefficient.  Was six launches (sumsq,
+// two fills, gram, gram finish, clip_coef) with 10-40 us of idle chip between them in front of the optimiser.  (A
+// single launch whose last-arriving block finishes the job -- ticket counter + agent-scope release / acquire -- measured
+// 33 us: 754 fences and tickets cost more than the kernel boundary they replace.)
+//   blocks [0, nb_s): one SUMSQ_CHUNK of x each                      -> part[blk]
+//   then per (job, which, pair, chunk): one chunk of one dot product -> gram slot
+constexpr int NORM_CHUNKS = 16;
+__global__ __launch_bounds__(256) void grad_norm_partials_kernel(size_t n, const float* __restrict__ x, int vec, int nb_s, int R,
+                                                                 GramJobs jobs, double* __restrict__ part) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x;
+    double mine = 0.0;
+    if (bid < nb_s) {
+        const size_t base = (size_t)bid * SUMSQ_CHUNK;
+        float s = 0.f;
+        if (vec && base + SUMSQ_CHUNK <= n) {
+            const f32x4* x4 = reinterpret_cast<const f32x4*>(x + base);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { f32x4 v = x4[tid + 256 * i]; s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+        } else {
+            for (size_t i = base + tid; i < n && i < base + SUMSQ_CHUNK; i += 256) s += x[i] * x[i];
+        }
+        mine = (double)s;
+    } else {
+        int q = bid - nb_s;
+        const int chunk = q % NORM_CHUNKS; q /= NORM_CHUNKS;
+        const int pair = q % (R * R); q /= (R * R);
+        const int which = q & 1, job = q >> 1;
+        const GramJob& J = jobs.j[job];
+        const int r = pair / R, sidx = pair % R;
+        const float* u = which ? J.afac + (size_t)r * J.lda : J.gfac + (size_t)r * J.ldg;
+        const float* v = which ? J.afac + (size_t)sidx * J.lda : J.gfac + (size_t)sidx * J.ldg;
+        const int len = which ? J.k : J.rows;
+        const int per = (len + NORM_CHUNKS - 1) / NORM_CHUNKS;
+        const int i0 = chunk * per, i1 = min(len, i0 + per);
+        for (int i = i0 + tid; i < i1; i += 256) mine += (double)u[i] * (double)v[i];
+    }
+    mine = wave_sum_d(mine);
+    if ((tid & 63) == 0) red[tid >> 6] = mine;
+    __syncthreads();
+    if (tid == 0) part[bid] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void grad_norm_finish_kernel(int nb_s, int R, int njobs, const double* __restrict__ part,
+                                                               double max_norm, double scale, float* __restrict__ coef_out) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const double* gram = part + nb_s;            // [job][which][pair][chunk]
+    double tot = 0.0;
+    for (int i = tid; i < nb_s; i += 256) tot += part[i];
+    const int npair = njobs * R * R;
+    for (int i = tid; i < npair; i += 256) {
+        const int job = i / (R * R), pair = i % (R * R);
+        const double* gg = gram + (((size_t)job * 2 + 0) * R * R + pair) * NORM_CHUNKS;
+        const double* aa = gram + (((size_t)job * 2 + 1) * R * R + pair) * NORM_CHUNKS;
+        double sg = 0.0, sa = 0.0;
+        for (int c = 0; c < NORM_CHUNKS; ++c) { sg += gg[c]; sa += aa[c]; }
+        tot += sg * sa;
+    }
+    tot = wave_sum_d(tot);
+    if ((tid & 63) == 0) red[tid >> 6] = tot;
+    __syncthreads();
+    if (tid == 0) {
+        const double t = red[0] + red[1] + red[2] + red[3];
+        const double norm = scale * sqrt(t);
+        double c = max_norm / (norm + 1e-6);          // torch.nn.utils.clip_grad_norm_
+        if (c > 1.0) c = 1.0;
+        coef_out[0] = (float)(scale * c);
+        coef_out[1] = (float)norm;
+    }
+}
+
 // ------------------------------------------------------------------ Adam (torch.optim.Adam, single-tensor form)
 struct AdamK { float lr_bc1, b1, b2, eps, sqrt_bc2; const float* dev; };
 __device__ __forceinline__ float adam_elem(float p, float g, float& m, float& v, const AdamK& k) {
@@ -684,6 +758,28 @@ extern "C" int caphn_rank_sumsq_multi_f32(int R, int n, const int* rows, const i
     if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * R * R * n, s) != hipSuccess) return CAPHN_ELAUNCH;
     hipLaunchKernelGGL(rank_gram_kernel, dim3(R * R, 2 * n, GRAM_CHUNKS), dim3(256), 0, s, R, jobs, ws);
     hipLaunchKernelGGL(rank_gram_finish_kernel, dim3(1), dim3(64), 0, s, R, n, ws, acc);
+    return caphn_launch_status();
+}
+extern "C" size_t caphn_grad_norm_workspace_bytes(size_t n, int R, int njobs) {
+    if (R <= 0 || R > RMAX || njobs < 0 || njobs > CAPHN_MAX_HEADS) return 0;
+    return sizeof(double) * ((size_t)caphn_sumsq_blocks(n) + (size_t)njobs * 2 * R * R * NORM_CHUNKS);
+}
+extern "C" int caphn_grad_norm_coef(size_t n, const float* x, int R, int njobs, const int* rows, const int* k,
+                                    const float* const* gfac, const size_t* ldg, const float* const* afac, const size_t* lda,
+                                    double max_norm, double scale, float* coef_out, void* ws, caphn_stream_t stream) {
+    if (n == 0 || !x || R <= 0 || R > RMAX || njobs < 0 || njobs > CAPHN_MAX_HEADS || !coef_out || !ws) return CAPHN_EINVAL;
+    GramJobs jobs; jobs.n = njobs;
+    for (int i = 0; i < njobs; ++i) {
+        if (!rows || !k || !gfac || !ldg || !afac || !lda || rows[i] <= 0 || k[i] <= 0 || !gfac[i] || !afac[i]) return CAPHN_EINVAL;
+        jobs.j[i] = GramJob{gfac[i], ldg[i], afac[i], lda[i], rows[i], k[i]};
+    }
+    const int nb_s = caphn_sumsq_blocks(n);
+    const unsigned nb = (unsigned)nb_s + (unsigned)(njobs * 2 * R * R * NORM_CHUNKS);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(grad_norm_partials_kernel, dim3(nb), dim3(256), 0, s, n, x, (int)caphn_aligned16(x), nb_s, R, jobs,
+                       static_cast<double*>(ws));
+    hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(256), 0, s, nb_s, R, njobs, static_cast<const double*>(ws), max_norm,
+                       scale, coef_out);
     return caphn_launch_status();
 }
 extern "C" int caphn_clip_coef(int nparts, const double* partial, const double* extra, double max_norm, double scale,

@@ -373,6 +373,14 @@ int caphn_rank_sumsq_multi_f32(int R, int n, const int* rows, const int* k, cons
 int caphn_clip_coef(int nparts, const double* partial, const double* extra, double max_norm, double scale,
                     float* coef_out, caphn_stream_t stream);
 
+/* All of the above in two back-to-back launches (the fused trainers' path): coef_out[0] / [1] as caphn_clip_coef would give
+ * for sum(x[0..n)^2) + sum over the njobs (gfac, afac) pairs of || sum_r g_r (x) a_r ||_F^2   (host arrays of length njobs;
+ * njobs may be 0).  Fixed summation order (no atomics).  ws: caphn_grad_norm_workspace_bytes(n, R, njobs) bytes. */
+size_t caphn_grad_norm_workspace_bytes(size_t n, int R, int njobs);
+int caphn_grad_norm_coef(size_t n, const float* x, int R, int njobs, const int* rows, const int* k,
+                         const float* const* gfac, const size_t* ldg, const float* const* afac, const size_t* lda,
+                         double max_norm, double scale, float* coef_out, void* ws, caphn_stream_t stream);
+
 typedef struct caphn_adam_hparams {
     float lr, beta1, beta2, eps;
     int step;                          /* 1-based, bias corrections computed from it */

@@ -426,3 +426,30 @@ def test_cross_entropy_in_place_reads_target_logit_before_overwrite(ops):
         lg = logits.to(DEV).clone()
         out, _ = ops.cross_entropy_fwd_bwd(lg, tgt.to(DEV), 0, dlogits=lg)
         assert abs(float(out[0]) - ref) < 2e-5
+
+
+@pytest.mark.parametrize("R", [1, 3, 8])
+def test_grad_norm_coef_one_launch_matches_dense_reference(R):
+    """caphn_grad_norm_coef: clip_grad_norm_'s total norm over a dense arena plus rank-R gradients given by their factors
+    (|| sum_r g_r (x) a_r ||_F^2 by the Gram identity), and the clip coefficient."""
+    torch.manual_seed(R)
+    n = 70001
+    flat = torch.randn(n, device=DEV)
+    th = 5000
+    gfull = torch.randn(R, th + 7, device=DEV)[:, 3:3 + th]          # strided rows, unaligned start
+    afull = torch.randn(R, 96, device=DEV)
+    segs = [(gfull[:, 0:3000], afull[:, 0:40]), (gfull[:, 3000:5000], afull[:, 40:96])]
+    from caphn import ops as cops
+    gn = cops.GradNorm(n, R, len(segs), DEV)
+    out = torch.zeros(2, device=DEV)
+    dense = [torch.einsum("rm,rk->mk", g.double(), a.double()) for g, a in segs]
+    tot = float((flat.double() ** 2).sum() + sum((d ** 2).sum() for d in dense)) ** 0.5
+    for max_norm in (1e9, 0.5, 3.0):
+        gn(flat, segs, max_norm, 1.0 / R, out)
+        norm = tot / R
+        want = (1.0 / R) * min(1.0, max_norm / (norm + 1e-6))
+        assert abs(float(out[1]) - norm) < 1e-5 * norm
+        assert abs(float(out[0]) - want) < 1e-6 * want
+    # bit-identical from launch to launch (fixed summation order)
+    a = out.clone(); gn(flat, segs, 3.0, 1.0 / R, out)
+    assert torch.equal(a, out)
