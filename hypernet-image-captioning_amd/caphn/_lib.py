@@ -90,6 +90,10 @@ SIGNATURES = {
     "caphn_device_arch": (C.c_int, [C.c_char_p, C.c_int]),
     "caphn_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_int,
                                  c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
+    "caphn_split3_bf16": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_size_t, C.c_int, c_fp]),
+    "caphn_gemm_planes_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_int, C.c_size_t,
+                                        c_fp, C.c_int, c_fp, C.c_int, C.c_size_t, c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, c_fp]),
     "caphn_zero_f32": (C.c_int, [c_fp, C.c_size_t, c_fp]),
     "caphn_axpy_f32": (C.c_int, [C.c_size_t, C.c_float, c_fp, c_fp, c_fp]),
     "caphn_scale_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp, c_fp]),

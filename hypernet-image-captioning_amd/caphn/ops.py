@@ -45,6 +45,44 @@ def gemm(a: torch.Tensor, b: torch.Tensor, ta: bool = False, tb: bool = False,
     return out
 
 
+class Planes:
+    """The three bf16 planes (hi, mid, lo; x == hi + mid + lo exactly) of a 2-D fp32 matrix, split once for repeated use as a
+    GEMM operand (caphn_split3_bf16).  `zero_rows`: rows of zeros appended (K rounded up to 8 for a K-slow operand)."""
+
+    def __init__(self, x: torch.Tensor, zero_rows: int = 0):
+        lib = L.load()
+        assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+        rows, cols = x.shape
+        self.src, self.rows, self.cols = x, rows, cols
+        self.ldp = (cols + 7) & ~7
+        self.ps = ((rows + zero_rows + 7) & ~7) * self.ldp
+        self.buf = torch.empty(3 * self.ps, dtype=torch.bfloat16, device=x.device)
+        L.check(lib.caphn_split3_bf16(C.c_void_p(x.data_ptr()), rows, cols, x.stride(0), C.c_void_p(self.buf.data_ptr()), self.ldp,
+                                      self.ps, zero_rows, L.stream_ptr()), "caphn_split3_bf16")
+
+    def plane(self, p: int) -> torch.Tensor:
+        return self.buf[p * self.ps:(p + 1) * self.ps].view(-1, self.ldp)[:self.rows, :self.cols]
+
+
+def gemm_planes(a: Planes, b: Planes, ta: bool = False, tb: bool = False, bias: Optional[torch.Tensor] = None,
+                relu: bool = False, out: Optional[torch.Tensor] = None, splitk: int = 1, kp: int = 0) -> torch.Tensor:
+    """ops.gemm on pre-split operands."""
+    lib = L.load()
+    A, B = a.src, b.src
+    M, K = (A.shape[1], A.shape[0]) if ta else (A.shape[0], A.shape[1])
+    N, Kb = (B.shape[0], B.shape[1]) if tb else (B.shape[1], B.shape[0])
+    if K != Kb:
+        raise L.CaphnError(f"gemm inner dims differ: {K} vs {Kb}")
+    if out is None:
+        out = torch.zeros(M, N, dtype=torch.float32, device=A.device) if splitk > 1 else _f32(M, N, device=A.device)
+    flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_RELU if relu else 0)
+    L.check(lib.caphn_gemm_planes_f32(int(ta), int(tb), M, N, K, A.data_ptr(), A.stride(0), a.buf.data_ptr(), a.ldp, a.ps,
+                                      B.data_ptr(), B.stride(0), b.buf.data_ptr(), b.ldp, b.ps, out.data_ptr(), out.stride(0),
+                                      bias.data_ptr() if bias is not None else None, None, 0, flags, splitk, kp, L.stream_ptr()),
+            "caphn_gemm_planes_f32")
+    return out
+
+
 def zero_(t: torch.Tensor) -> torch.Tensor:
     """Zero-fill a contiguous fp32 CUDA tensor with libcaphn's dwordx4 store kernel."""
     lib = L.load()

@@ -14,6 +14,7 @@ static inline int caphn_launch_status() {
     return hipGetLastError() == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
 }
 static inline bool caphn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+__device__ __forceinline__ bool caphn_aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline size_t caphn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- device math: transcendental forms with absolute error ~1e-7 (v_exp_f32 / v_rcp_f32) ----

@@ -13,47 +13,13 @@
 // operand (80-byte row pitch: conflict-free ds_read_b128 fragments).
 #include "common.h"
 #include "gemm_internal.h"
+#include "split3.h"
 #include <type_traits>
 
 namespace {
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 constexpr int BK = 32;
 constexpr int PITCH = 40;          // bf16 elements per LDS row (32 + 8 pad): 80 B = 5 x 16 B
-
-// The three planes by TRUNCATION on the bit pattern (exact: 24 significand bits = 8 + 8 + 8, so hi + mid + lo == x
-// with no rounding anywhere): hi = x & 0xffff0000, mid = (x - hi) & 0xffff0000, lo = x - hi - mid.  Per element pair
-// that is 4 v_and, 2 v_pk_add_f32 and 3 v_perm_b32 (packing the upper halves of two dwords) -- 4.5 vector
-// instructions per element instead of the 7.5 of the convert / convert-back / subtract formulation, in a kernel
-// whose main loop is bound by vector-instruction issue, not by the MFMA pipe (rocprofv3 SQ counters).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-struct Split4 { bf16x4 hi, mid, lo; };
-__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) {      // {a[31:16], b[31:16]} -> one dword, a low
-    return __builtin_amdgcn_perm(b, a, 0x07060302u);
-}
-__device__ __forceinline__ Split4 split3(f32x4 v) {
-    union U2 { f32x2 f; u32x2 u; };
-    union Out { unsigned u[2]; bf16x4 b; };
-    Out hi, mid, lo;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        U2 x, a, r1, m, r2;
-        x.f = f32x2{v[2 * h], v[2 * h + 1]};
-        a.u = x.u & 0xffff0000u;
-        r1.f = x.f - a.f;
-        m.u = r1.u & 0xffff0000u;
-        r2.f = r1.f - m.f;
-        hi.u[h] = pack_hi16(x.u[0], x.u[1]);
-        mid.u[h] = pack_hi16(r1.u[0], r1.u[1]);
-        lo.u[h] = pack_hi16(r2.u[0], r2.u[1]);
-    }
-    Split4 s;
-    s.hi = hi.b; s.mid = mid.b; s.lo = lo.b;
-    return s;
-}
 
 // LDS image of one operand tile: three bf16 planes.
 //  KC (K contiguous in memory): [BMN rows][PITCH] -- a fragment is one ds_read_b128 of a row.
@@ -167,6 +133,52 @@ struct TileS {
             }
         }
     }
+    // ---- pre-split operands (GemmArgs::Ap / Bp): a thread moves NVP 16-byte chunks (8 bf16) per plane per slab, global ->
+    // registers -> LDS, no arithmetic.  KC: 4 chunks per row; !KC: BMN / 8 chunks per k-row.
+    static constexpr int NVP = BMN / 64;
+    __device__ static __forceinline__ void phys_rows_p(int (&pr)[NVP], int rows, int r0, int tid, const int* __restrict__ rmap) {
+#pragma unroll
+        for (int i = 0; i < NVP; ++i) {
+            const int row = min(r0 + ((tid + 256 * i) >> 2), rows - 1);
+            pr[i] = rmap ? rmap[row] : row;
+        }
+    }
+    __device__ static __forceinline__ void load_p(bf16x8 (&r)[NVP][3], const __bf16* __restrict__ P, int ldp, size_t ps,
+                                                  int rows, int K, int r0, int k0, int tid, const int (&pr)[NVP],
+                                                  const int* kl, int kbase) {
+#pragma unroll
+        for (int i = 0; i < NVP; ++i) {
+            const int idx = tid + 256 * i;
+            size_t off;
+            if (KC) {               // memory [rows, K]; pr[] is clamped (and mapped)
+                const int kc = min(k0 + (idx & 3) * 8, K - 8);
+                off = (size_t)pr[i] * ldp + kc;
+            } else {                // memory [K, rows]; the last chunk of a row may reach into the pad of the leading dimension
+                const int m = min(r0 + (idx % (BMN / 8)) * 8, ((rows + 7) & ~7) - 8);
+                int kc = min(k0 + idx / (BMN / 8), K - 1);
+                if (kl) kc = kl[kc - kbase];
+                off = (size_t)kc * ldp + m;
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) r[i][pl] = *reinterpret_cast<const bf16x8*>(P + pl * ps + off);
+        }
+    }
+    __device__ static __forceinline__ void store_p(const bf16x8 (&r)[NVP][3], __bf16* __restrict__ S, int tid, int k0, int K) {
+#pragma unroll
+        for (int i = 0; i < NVP; ++i) {
+            const int idx = tid + 256 * i;
+            const int k = KC ? k0 + (idx & 3) * 8 : k0 + idx / (BMN / 8);
+            const bool dead = k >= K;                 // K tail of the last slab: zeros (K % 8 == 0, so whole chunks)
+            __bf16* p = KC ? S + (idx >> 2) * PITCH + (idx & 3) * 8
+                           : S + (idx / (BMN / 8)) * PITCHM + (idx % (BMN / 8)) * 8;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                bf16x8 v = r[i][pl];
+                if (dead) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<bf16x8*>(p + pl * PLANE) = v;
+            }
+        }
+    }
     // MFMA operand of lane l (r = l&31, h = l>>5) for k-step ks: elements k = 16 ks + 8 h + (0..7) of row `row0 + r`
     __device__ static __forceinline__ bf16x8 frag(const __bf16* __restrict__ S, int plane, int row0, int ks, int lane) {
         if (KC) {
@@ -186,7 +198,9 @@ struct TileS {
     }
 };
 
-template <int BM, int BN, bool TA, bool TB>
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+template <int BM, int BN, bool TA, bool TB, bool PL>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     using TileA = TileS<BM, !TA>;
     using TileB = TileS<BN, TB>;
@@ -358,9 +372,82 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             }
         }
     };
-    if (fast) mainloop(std::true_type{}); else mainloop(std::false_type{});
+    // fused bias gradient from the planes: x = hi + mid + lo
+    float csum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (PL) {
+        // pre-split operands: same two-slab look-ahead, registers hold 16-byte bf16 chunks of the three planes
+        const __bf16* Ap = static_cast<const __bf16*>(g.Ap);
+        const __bf16* Bp = static_cast<const __bf16*>(g.Bp);
+        bf16x8 pa0[TileA::NVP][3], pb0[TileB::NVP][3], pa1[TileA::NVP][3], pb1[TileB::NVP][3];
+        int ppa[TileA::NVP], ppb[TileB::NVP];
+        TileA::phys_rows_p(ppa, g.M, m0, tid, rmapA);
+        TileB::phys_rows_p(ppb, g.N, n0, tid, nullptr);
+        auto pload = [&](bf16x8 (&ra)[TileA::NVP][3], bf16x8 (&rb)[TileB::NVP][3], int slab) {
+            TileA::load_p(ra, Ap, g.ldap, g.psa, g.M, g.K, m0, slab * BK, tid, ppa, kl, kbase);
+            TileB::load_p(rb, Bp, g.ldbp, g.psb, g.N, g.K, n0, slab * BK, tid, ppb, kl, kbase);
+        };
+        auto pstage = [&](const bf16x8 (&ra)[TileA::NVP][3], const bf16x8 (&rb)[TileB::NVP][3], int slab) {
+            if constexpr (TA) {
+                if (do_cs) {
+#pragma unroll
+                    for (int i = 0; i < TileA::NVP; ++i) {
+                        const int k = slab * BK + (tid + 256 * i) / (BM / 8);
+                        if (k < g.K) {
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) {
+                                union { bf16x8 v; unsigned short u[8]; } c; c.v = ra[i][pl];
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) csum8[e] += bf16_bits_to_f32(c.u[e]);
+                            }
+                        }
+                    }
+                }
+            }
+            TileA::store_p(ra, As, tid, slab * BK, g.K);
+            TileB::store_p(rb, Bs, tid, slab * BK, g.K);
+        };
+        const int last = slab1 - 1;
+        pload(pa0, pb0, slab0);
+        pload(pa1, pb1, min(slab0 + 1, last));
+        pstage(pa0, pb0, slab0);
+        __syncthreads();
+        for (int slab = slab0; slab < slab1; slab += 2) {
+            pload(pa0, pb0, min(slab + 2, last));
+            multiply(slab);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (slab + 1 >= slab1) break;
+            pstage(pa1, pb1, slab + 1);
+            __syncthreads();
+            pload(pa1, pb1, min(slab + 3, last));
+            multiply(slab + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (slab + 2 < slab1) {
+                pstage(pa0, pb0, slab + 2);
+                __syncthreads();
+            }
+        }
+    } else {
+        if (fast) mainloop(std::true_type{}); else mainloop(std::false_type{});
+    }
 
-    if constexpr (TA) {
+    if constexpr (TA && PL) {
+        if (do_cs) {        // workgroup-uniform; the main loop ended on a barrier, LDS is free
+            constexpr int CG = BM / 8, RG = 256 / CG;      // column groups of 8, threads per group
+            float* red = reinterpret_cast<float*>(lds);
+            const int cg = tid % CG, rg = tid / CG;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[rg * BM + cg * 8 + e] = csum8[e];
+            __syncthreads();
+            if (tid < BM && m0 + tid < g.M) {
+                float v = 0.f;
+                for (int r = 0; r < RG; ++r) v += red[r * BM + tid];
+                atomicAdd(g.colsum_a + m0 + tid, v);
+            }
+        }
+    }
+    if constexpr (TA && !PL) {
         if (do_cs) {        // workgroup-uniform; the main loop ended on a barrier, LDS is free
             constexpr int CG = BM / 4, RG = 256 / CG;      // column groups, threads per group
             float* red = reinterpret_cast<float*>(lds);
@@ -405,7 +492,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         }
 }
 
-template <int BM, int BN, bool TA, bool TB>
+template <int BM, int BN, bool TA, bool TB, bool PL>
 int launch_one(const GemmArgs& g, hipStream_t s) {
     using TileA = TileS<BM, !TA>;
     using TileB = TileS<BN, TB>;
@@ -414,29 +501,44 @@ int launch_one(const GemmArgs& g, hipStream_t s) {
     if (g.kmap_lds > 0) lds += sizeof(int) * (size_t)g.kmap_lds;
     static bool attr_set = false;          // one flag per instantiation; one host thread drives one device
     if (lds_tiles + 16384 > 48 * 1024 && !attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<BM, BN, TA, TB>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<BM, BN, TA, TB, PL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_tiles + 16384)) != hipSuccess) return CAPHN_ELAUNCH;
         attr_set = true;
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk > 1 ? g.splitk : 1);
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB>), grid, dim3(256), lds, s, g);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, PL>), grid, dim3(256), lds, s, g);
     return caphn_launch_status();
 }
-template <int BM, int BN>
+template <int BM, int BN, bool PL>
 int launch_cfg(const GemmArgs& g, int ta, int tb, hipStream_t s) {
-    if (!ta && tb) return launch_one<BM, BN, false, true>(g, s);
-    if (!ta && !tb) return launch_one<BM, BN, false, false>(g, s);
-    if (ta && !tb) return launch_one<BM, BN, true, false>(g, s);
-    return launch_one<BM, BN, true, true>(g, s);
+    if (!ta && tb) return launch_one<BM, BN, false, true, PL>(g, s);
+    if (!ta && !tb) return launch_one<BM, BN, false, false, PL>(g, s);
+    if (ta && !tb) return launch_one<BM, BN, true, false, PL>(g, s);
+    if constexpr (PL) return CAPHN_EINVAL;      // TT is never pre-split (no caller)
+    else return launch_one<BM, BN, true, true, false>(g, s);
 }
 
 }  // namespace
 
+extern int g_tune_gemm_planes;
 int g_tune_gemm_xcd = 1;      // 1 (default): XCD-aware tile order
 int g_tune_gemm_fast = 1;     // 1 (default): branch-free loads (static vmcnt) where alignment allows
 // Tile choice: 128x128 when that alone gives >= 512 workgroups, else 64x64 (five workgroups per CU).  Measured and
 // dropped: 64x256 / 256x64 tiles spanning the whole short side of the N = 200 problems (the long operand is read once,
 // but two workgroups per CU hide far less latency: 1.3-2x slower) and 128x64 (no change).
+// pre-split operands: usable when every 16-byte chunk is aligned and whole (K % 8 == 0; K-slow extents may end inside
+// the padding of their leading dimension) and, with a K map, when its slice fits the LDS (the branch-free path)
+bool caphn_gemm_planes_ok(const GemmArgs& g, int ta, int tb) {
+    bool pl = g_tune_gemm_planes && g.Ap && g.Bp && !(ta && tb) && (g.K % 8) == 0 && g.K >= 8 && (g.ldap % 8) == 0 && (g.ldbp % 8) == 0 &&
+              (g.psa % 8) == 0 && (g.psb % 8) == 0 && caphn_aligned16(g.Ap) && caphn_aligned16(g.Bp);
+    if (pl && ta && (((g.M + 7) & ~7) > g.ldap || g.M < 8)) pl = false;
+    if (pl && !tb && (((g.N + 7) & ~7) > g.ldbp || g.N < 8)) pl = false;
+    if (pl && g.map_mode == 2) {
+        const int nslab = (g.K + 31) / 32, sk = g.splitk > 1 ? g.splitk : 1;
+        if (!(ta && !tb) || ((nslab + sk - 1) / sk) * 32 > 4096) pl = false;
+    }
+    return pl;
+}
 int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
     if (g_tune_gemm_xcd) g.flags |= 1 << 20;
     g.kmap_lds = 0;
@@ -447,6 +549,63 @@ int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
     }
     if (!g_tune_gemm_fast) g.flags |= 1 << 21;
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.splitk;
-    if (tiles128 >= 512) return launch_cfg<128, 128>(g, ta, tb, s);
-    return launch_cfg<64, 64>(g, ta, tb, s);
+    const bool pl = caphn_gemm_planes_ok(g, ta, tb);
+    if (pl) {
+        if (tiles128 >= 512) return launch_cfg<128, 128, true>(g, ta, tb, s);
+        return launch_cfg<64, 64, true>(g, ta, tb, s);
+    }
+    if (tiles128 >= 512) return launch_cfg<128, 128, false>(g, ta, tb, s);
+    return launch_cfg<64, 64, false>(g, ta, tb, s);
+}
+
+// ---------------------------------------------------------------------------------------------- operand splitting
+namespace {
+struct SplitJobs { SplitJob j[8]; int n; long block0[9]; };
+// one workgroup = 256 threads x 8 elements of one row-major matrix; a row's tail chunk is padded with zeros up to ldp
+__global__ __launch_bounds__(256) void split3_kernel(SplitJobs jobs) {
+    int ji = 0;
+    for (int i = 1; i < jobs.n; ++i) if ((long)blockIdx.x >= jobs.block0[i]) ji = i;
+    const SplitJob& J = jobs.j[ji];
+    const int cpr = (J.cols + 7) >> 3;                        // chunks per row
+    const long nchunk = (long)(J.rows + J.zero_rows) * cpr;
+    const long stride = (jobs.block0[ji + 1] - jobs.block0[ji]) * 256;
+    __bf16* dst = static_cast<__bf16*>(J.dst);
+    const bool vec = (J.ld & 3) == 0 && caphn_aligned16_dev(J.src);
+    for (long c = ((long)blockIdx.x - jobs.block0[ji]) * 256 + threadIdx.x; c < nchunk; c += stride) {
+        const int row = (int)(c / cpr), col = (int)(c % cpr) * 8;
+        const float* sp = J.src + (size_t)row * J.ld + col;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        if (row >= J.rows) { }                      // padding rows: zeros (a K extent rounded up to 8)
+        else if (vec && col + 8 <= J.cols) { v0 = *reinterpret_cast<const f32x4*>(sp); v1 = *reinterpret_cast<const f32x4*>(sp + 4); }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { if (col + e < J.cols) v0[e] = sp[e]; if (col + 4 + e < J.cols) v1[e] = sp[4 + e]; }
+        }
+        const Split4 a = split3(v0), b = split3(v1);
+        __bf16* dp = dst + (size_t)row * J.ldp + col;
+        *reinterpret_cast<bf16x8*>(dp) = __builtin_shufflevector(a.hi, b.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<bf16x8*>(dp + J.ps) = __builtin_shufflevector(a.mid, b.mid, 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<bf16x8*>(dp + 2 * J.ps) = __builtin_shufflevector(a.lo, b.lo, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+}  // namespace
+int g_tune_gemm_planes = 1;      // 1 (default): use pre-split operands where the caller provides them
+int caphn_split3_launch(const SplitJob* jobs, int n, hipStream_t s) {
+    if (n <= 0) return CAPHN_OK;
+    if (n > 8 || !jobs) return CAPHN_EINVAL;
+    SplitJobs J; J.n = n;
+    long b = 0;
+    for (int i = 0; i < n; ++i) {
+        const SplitJob& j = jobs[i];
+        if (!j.src || !j.dst || j.rows <= 0 || j.cols <= 0 || (j.ldp % 8) || (j.ps % 8) || j.ldp < ((j.cols + 7) & ~7) ||
+            !caphn_aligned16(j.dst)) return CAPHN_EINVAL;
+        J.j[i] = j;
+        J.block0[i] = b;
+        long nb = ((long)(j.rows + j.zero_rows) * ((j.cols + 7) / 8) + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        b += nb;
+    }
+    J.block0[n] = b;
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)b), dim3(256), 0, s, J);
+    return caphn_launch_status();
 }

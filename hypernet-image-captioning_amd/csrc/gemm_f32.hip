@@ -200,6 +200,7 @@ int caphn_gemm_mapped(int ta, int tb, int M, int N, int K, const float* A, int l
     g.vecA = caphn_aligned16(A) && (lda % 4 == 0);
     g.vecB = caphn_aligned16(B) && (ldb % 4 == 0);
     g.row_map = row_map; g.dev_count = dev_count; g.map_mode = map_mode; g.colsum_a = nullptr; g.kmap_lds = 0;
+    g.Ap = nullptr; g.Bp = nullptr; g.ldap = g.ldbp = 0; g.psa = g.psb = 0;
     return caphn_gemm_bf16x3_launch(g, ta, tb, s);      // the row subset lives in the split-bf16 back end
 }
 
@@ -228,7 +229,63 @@ int caphn_gemm_tn_colsum(int M, int N, int K, const float* A, int lda, const flo
     g.vecB = caphn_aligned16(B) && (ldb % 4 == 0);
     g.row_map = rowmap ? rowmap + 4 : nullptr; g.dev_count = rowmap; g.map_mode = rowmap ? 2 : 0;
     g.colsum_a = colsum_out; g.kmap_lds = 0;
+    g.Ap = nullptr; g.Bp = nullptr; g.ldap = g.ldbp = 0; g.psa = g.psb = 0;
     return caphn_gemm_bf16x3_launch(g, 1, 0, s);
+}
+
+// Operands that may carry pre-split planes.  Falls back to the plain entry points whenever the split-bf16 back end is off
+// or an operand has no planes.  The caller has zero-filled C when splitk > 1 or a row map is used.
+int caphn_gemm_x(int ta, int tb, int M, int N, int K, const Opnd& A, const Opnd& B, float* C, int ldc, const GemmX& x, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A.f || !B.f || !C) return CAPHN_EINVAL;
+    if ((x.flags & CAPHN_GEMM_BIAS) && !x.bias) return CAPHN_EINVAL;
+    if ((x.flags & CAPHN_GEMM_MASK) && !x.mask) return CAPHN_EINVAL;
+    if (g_tune_gemm != 1) {      // fp32 MFMA back end: no planes, no row maps, no fused column sums
+        if (x.rowmap || x.colsum) return CAPHN_EINVAL;
+        return caphn_gemm_f32(ta, tb, M, N, K, A.f, A.ld, B.f, B.ld, C, ldc, x.bias, x.mask, x.ldmask, x.flags, x.splitk, s);
+    }
+    int splitk = x.splitk;
+    if (splitk > 1 && (x.flags & 0xFFFF & ~CAPHN_GEMM_BIAS)) return CAPHN_EINVAL;
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K; g.A = A.f; g.lda = A.ld; g.B = B.f; g.ldb = B.ld; g.C = C; g.ldc = ldc;
+    g.bias = x.bias; g.mask = x.mask; g.ldmask = x.ldmask; g.flags = x.flags;
+    const int nslab = (K + 31) / 32;
+    if (splitk > nslab) splitk = nslab;
+    g.splitk = splitk > 1 ? splitk : 1;
+    g.slabs_per_split = (nslab + g.splitk - 1) / g.splitk;
+    g.vecA = caphn_aligned16(A.f) && (A.ld % 4 == 0);
+    g.vecB = caphn_aligned16(B.f) && (B.ld % 4 == 0);
+    g.row_map = x.rowmap ? x.rowmap + 4 : nullptr; g.dev_count = x.rowmap; g.map_mode = x.rowmap ? x.map_mode : 0;
+    g.colsum_a = ta ? x.colsum : nullptr; g.kmap_lds = 0;
+    const bool both = A.p && B.p;
+    g.Ap = both ? A.p : nullptr; g.ldap = A.ldp; g.psa = A.ps;
+    g.Bp = both ? B.p : nullptr; g.ldbp = B.ldp; g.psb = B.ps;
+    if (both && x.Kp > K) {          // K not a multiple of 8: the planes are zero-padded to Kp
+        g.K = x.Kp;
+        if (!caphn_gemm_planes_ok(g, ta, tb)) g.K = K;
+        else {
+            const int ns = (g.K + 31) / 32;
+            g.slabs_per_split = (ns + g.splitk - 1) / g.splitk;
+        }
+    }
+    if (g.K == K && (K % 8) != 0) { g.Ap = nullptr; g.Bp = nullptr; }
+    return caphn_gemm_bf16x3_launch(g, ta, tb, s);
+}
+
+extern "C" int caphn_split3_bf16(const float* src, int rows, int cols, int ld, void* planes, int ldp, size_t plane_stride,
+                                 int zero_rows, caphn_stream_t stream) {
+    if (!src || !planes || rows <= 0 || cols <= 0 || ld < cols || zero_rows < 0) return CAPHN_EINVAL;
+    SplitJob j{src, ld, planes, ldp, plane_stride, rows, cols, zero_rows};
+    return caphn_split3_launch(&j, 1, static_cast<hipStream_t>(stream));
+}
+extern "C" int caphn_gemm_planes_f32(int ta, int tb, int M, int N, int K,
+                                     const float* A, int lda, const void* Ap, int ldap, size_t psa,
+                                     const float* B, int ldb, const void* Bp, int ldbp, size_t psb,
+                                     float* C, int ldc, const float* bias, const float* mask, int ldmask, int flags, int splitk,
+                                     int Kp, caphn_stream_t stream) {
+    GemmX x;
+    x.bias = bias; x.mask = mask; x.ldmask = ldmask; x.flags = flags; x.splitk = splitk; x.Kp = Kp;
+    return caphn_gemm_x(ta, tb, M, N, K, Opnd(A, lda, Ap, ldap, psa), Opnd(B, ldb, Bp, ldbp, psb), C, ldc, x,
+                        static_cast<hipStream_t>(stream));
 }
 
 extern "C" int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
@@ -244,6 +301,7 @@ extern "C" int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.mask = mask; g.ldmask = ldmask; g.flags = flags;
     g.row_map = nullptr; g.dev_count = nullptr; g.map_mode = 0; g.colsum_a = nullptr; g.kmap_lds = 0;
+    g.Ap = nullptr; g.Bp = nullptr; g.ldap = g.ldbp = 0; g.psa = g.psb = 0;
     if (g_tune_gemm == 1) {          // split-bf16 back end: three bf16 planes per operand, 6 MFMAs per K=16
         const int nslab = (K + 31) / 32;
         if (splitk > nslab) splitk = nslab;

@@ -559,6 +559,7 @@ extern int g_tune_rec_rotate;
 extern int g_tune_fork;
 extern int g_tune_gemm_xcd;
 extern int g_tune_gemm_fast;
+extern int g_tune_gemm_planes;
 extern "C" int caphn_tune(int key, int value) {
     if (key == 0) { g_tune_gemv = value; return CAPHN_OK; }
     if (key == 1) { g_tune_adam = value; return CAPHN_OK; }
@@ -567,5 +568,6 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 4) { g_tune_fork = value; return CAPHN_OK; }
     if (key == 6) { g_tune_gemm_xcd = value; return CAPHN_OK; }
     if (key == 7) { g_tune_gemm_fast = value; return CAPHN_OK; }
+    if (key == 8) { g_tune_gemm_planes = value; return CAPHN_OK; }
     return CAPHN_EINVAL;
 }

@@ -70,6 +70,25 @@ int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
                    const float* mask, int ldmask, int flags, int splitk,
                    caphn_stream_t stream);
 
+/* Pre-split operands.  The split-bf16 back end multiplies every fp32 operand as three bf16 planes x = hi + mid + lo (exact:
+ * 8 + 8 + 8 significand bits, bf16 has fp32's exponent range).  caphn_gemm_f32 makes the planes tile by tile, on every use
+ * of a tile; an operand that is used more than once (a weight matrix, an activation that feeds the forward and two
+ * gradient contractions) can be split ONCE instead:
+ *   caphn_split3_bf16: planes[p][r][c], p = 0..2 (hi, mid, lo), as bf16 matrices with leading dimension ldp (elements,
+ *     multiple of 8, >= cols rounded up to 8: row tails are zero-filled) and plane_stride elements between planes (multiple
+ *     of 8, >= (rows + zero_rows) * ldp); zero_rows rows of zeros are appended (a K extent rounded up to 8).  planes must be
+ *     16-byte aligned.
+ *   caphn_gemm_planes_f32: caphn_gemm_f32 with the planes of A and B beside the fp32 matrices (same logical layouts).  The
+ *     planes are used when both are given, 16-byte aligned, and K % 8 == 0 -- or Kp = K rounded up to 8 is passed and both
+ *     operands' planes hold zeros for k in [K, Kp); otherwise the fp32 matrices are (always a correct result). */
+int caphn_split3_bf16(const float* src, int rows, int cols, int ld, void* planes, int ldp, size_t plane_stride, int zero_rows,
+                      caphn_stream_t stream);
+int caphn_gemm_planes_f32(int ta, int tb, int M, int N, int K,
+                          const float* A, int lda, const void* Ap, int ldap, size_t psa,
+                          const float* B, int ldb, const void* Bp, int ldbp, size_t psb,
+                          float* C, int ldc, const float* bias, const float* mask, int ldmask, int flags, int splitk,
+                          int Kp, caphn_stream_t stream);
+
 /* p[0..n) = 0 with dwordx4 stores (hipMemsetAsync's fill kernel is ~8x slower on large buffers). */
 int caphn_zero_f32(float* p, size_t n, caphn_stream_t stream);
 /* nn.Dropout in training mode: out[i] = in[i] * keep_i / (1 - p), keep_i decided by a counter-based hash of (seed, offset + i)
@@ -408,7 +427,7 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
 /* Tuning knob used by tools/microbench_stream.py to A/B kernel variants in one process
  * (key 0: forward-GEMV variant, key 1: rank-Adam variant, key 2: GEMM back end -- 0 fp32 MFMA, 1 split-bf16 MFMA,
  * key 3: row rotation in the recurrent kernels, key 4: side-stream forking of the decoder composites, key 6: XCD-aware
- * GEMM tile order, key 7: branch-free GEMM loads).  Defaults are the measured-fastest. */
+ * GEMM tile order, key 7: branch-free GEMM loads, key 8: pre-split GEMM operands -- 0 off (every tile split on use), 1 on).  Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
 /* ---------------------------------------------------------------------------------------

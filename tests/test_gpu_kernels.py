@@ -453,3 +453,45 @@ def test_grad_norm_coef_one_launch_matches_dense_reference(R):
     # bit-identical from launch to launch (fixed summation order)
     a = out.clone(); gn(flat, segs, 3.0, 1.0 / R, out)
     assert torch.equal(a, out)
+
+
+def test_split3_planes_are_exact():
+    """hi + mid + lo == x bit for bit (8 + 8 + 8 significand bits), row tails and appended rows are zero."""
+    from caphn import ops as cops
+    torch.manual_seed(0)
+    x = (torch.randn(37, 83, device=DEV) * torch.logspace(-20, 20, 83, device=DEV))[:, :77]        # strided view, wide exponent range
+    x[3, 5] = 0.0; x[4, 6] = -0.0; x[5, 7] = 1e-41                                                 # zeros and a subnormal
+    p = cops.Planes(x, zero_rows=3)
+    s = p.plane(0).float() + p.plane(1).float() + p.plane(2).float()
+    # exact for every normal number; a plane keeps the upper 16 bits of its residual, so fp32 subnormals whose bits all sit
+    # in the lower half (|x| < 2^-133) come out as 0 -- as in the split-on-use kernel
+    assert float(s[5, 7]) == 0.0
+    s[5, 7] = x[5, 7]
+    assert torch.equal(s, x)
+    full = p.buf.view(3, -1, p.ldp)
+    assert float(full[:, :37, 77:].float().abs().max()) == 0.0 and float(full[:, 37:40].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K", [(False, True, 300, 77, 200), (False, False, 129, 200, 96), (True, False, 200, 72, 1000),
+                                          (False, True, 1664, 9684, 200), (True, False, 64, 264, 6272), (False, False, 70, 200, 9684)])
+def test_gemm_on_presplit_operands_equals_split_on_use(ta, tb, M, N, K):
+    """The pre-split path multiplies the same bf16 planes as the split-on-use kernel: identical products, same accumulation
+    order inside a tile -> results equal to rounding of the (different) K-slab schedule at most; checked against fp64 too."""
+    from caphn import ops as cops
+    torch.manual_seed(1)
+    A = torch.randn((K, M) if ta else (M, K), device=DEV)
+    B = torch.randn((N, K) if tb else (K, N), device=DEV)
+    bias = torch.randn(N, device=DEV)
+    kp = (K + 7) & ~7
+    # K % 8 != 0: a K-contiguous operand's row tails are zero-filled by the split, a K-slow operand gets zero rows appended
+    pa = cops.Planes(A, zero_rows=(kp - K) if ta else 0)
+    pb = cops.Planes(B, zero_rows=(kp - K) if not tb else 0)
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double()) + bias.double()
+    got = cops.gemm_planes(pa, pb, ta, tb, bias=bias, kp=kp if K % 8 else 0)
+    base = cops.gemm(A, B, ta, tb, bias=bias)
+    scale = float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) < 3e-6 * scale
+    assert float((got - base).abs().max()) < 2e-6 * scale
+    if ta:                                   # split-K with atomics into a zeroed C
+        got2 = cops.gemm_planes(pa, pb, ta, tb, splitk=4, kp=kp if K % 8 else 0)
+        assert float((got2.double() - (ref - bias.double())).abs().max()) < 3e-6 * scale
