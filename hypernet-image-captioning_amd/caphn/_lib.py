@@ -140,6 +140,7 @@ SIGNATURES = {
     "caphn_ce_workspace_bytes": (C.c_size_t, [C.c_int]),
     "caphn_cross_entropy_rows": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, C.c_int64, c_fp, C.c_int, c_fp, c_fp, c_fp]),
     "caphn_cross_entropy_finish": (C.c_int, [C.c_int, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_decoder_profile_ptr": (C.c_void_p, [C.POINTER(DecoderDims), c_fp]),
     "caphn_decoder_rowcount_ptr": (C.c_void_p, [C.POINTER(DecoderDims), c_fp]),
     "caphn_cross_entropy_fwd_bwd": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, C.c_int64, c_fp, c_fp, C.c_int, c_fp, c_fp]),
     "caphn_embedding_gather": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),

@@ -14,6 +14,7 @@
 #include <initializer_list>
 #include <mutex>
 
+int g_tune_rec_pair = 1;     // 1 (default): two workgroups per caption in the recurrent kernels (recurrent_pair.hip)
 int g_tune_rec_rotate = 1;
 int g_tune_fork = 1;        // 0: one stream; 1 (default): independent branches on side streams, the dW_fc branch starting
                             // after BPTT (measured 1-2 % better than 2: beside BPTT, where both fight for the same CUs)
@@ -116,9 +117,16 @@ inline Side* side_here() {
 struct Ws {   // float offsets into the workspace
     size_t Y1, f, meanf, h0, c0, Waf, G, Xe, Xg, Hs, Hprev, gates, hn, Cs, Cprev, uah, alphas, idx;
     size_t dHs, dgi, dgh, duah, de, dh0, dc0, ctx, dctx, dXe, dWaf, dmeanf, df, dY1, apart, vtmp, colws, colws_s[3], prof, rowmap;
+    size_t xch, xch_floats;     // exchange areas of the pair kernels: forward, then backward (xch_floats each)
+    size_t wp;                  // packed recurrent weights of the pair kernels
     size_t total;
-    int npc, pchunk, NG;
+    int npc, pchunk, NG, arows;
 };
+// the recurrent kernels run two workgroups per caption when the shape allows it (teacher-forced launches only)
+inline bool use_pair(const caphn_decoder_dims* d) {
+    const int NG = d->cell == CAPHN_CELL_LSTM ? 4 : 3;
+    return g_tune_rec_pair && d->T > 1 && caphn_rec_pair_resident_gates(d->P, d->H, NG) >= 0;
+}
 
 inline size_t up4(size_t v) { return (v + 3) & ~(size_t)3; }
 
@@ -142,7 +150,10 @@ inline Ws layout(const caphn_decoder_dims* d) {
     w.dXe = take(B * T * E); w.dWaf = take(B * P * H); w.dmeanf = take(raw ? 0 : B * F); w.df = take(raw ? 0 : B * P * F);
     w.dY1 = take(raw ? 0 : B * P * F);
     w.pchunk = 1; w.npc = (int)((P + w.pchunk - 1) / w.pchunk);     // one workgroup per (caption, position)
-    const size_t arows = std::max<size_t>(w.npc, (size_t)caphn_rec_bwd_groups((int)P, (int)H));   // per caption: positions, or thread groups when fused
+    // per caption: positions, or thread groups when the BPTT kernel fuses the attention parameter gradients
+    const size_t arows = std::max<size_t>(std::max<size_t>(w.npc, (size_t)caphn_rec_bwd_groups((int)P, (int)H)),
+                                          (size_t)caphn_rec_pair_bwd_groups((int)P, (int)H));
+    w.arows = (int)arows;
     w.apart = take(B * arows * (H + 1)); w.vtmp = take(H + 1);
     size_t cs = 0;
     auto need = [&](size_t M, size_t N) { cs = std::max(cs, caphn_colsum_workspace_bytes((int)M, (int)N) / sizeof(float)); };
@@ -157,6 +168,10 @@ inline Ws layout(const caphn_decoder_dims* d) {
     }
     w.prof = take(64);        // 2 x 8 uint64 phase counters (forward, backward) of the recurrent kernels
     w.rowmap = take(B * T + 4);   // int: [0] = number of valid rows, [4..] = their physical (b*T+t) indices
+    w.xch_floats = caphn_rec_pair_xch_bytes((int)B, (int)P, (int)H) / sizeof(float);
+    w.xch = take(2 * w.xch_floats);
+    o = (o + 31) & ~(size_t)31;                                  // 128-byte aligned
+    w.wp = take(caphn_rec_pair_wp_floats((int)H, (int)NG));     // [U_a; W_hh] at the aligned row pitch
     w.total = o;
     (void)D;
     return w;
@@ -328,6 +343,11 @@ extern "C" const int* caphn_decoder_rowcount_ptr(const caphn_decoder_dims* d, vo
     return reinterpret_cast<const int*>(static_cast<float*>(ws_) + layout(d).rowmap);
 }
 
+extern "C" unsigned long long* caphn_decoder_profile_ptr(const caphn_decoder_dims* d, void* ws_) {
+    if (!dims_ok(d) || !ws_) return nullptr;
+    return reinterpret_cast<unsigned long long*>(static_cast<float*>(ws_) + layout(d).prof);
+}
+
 extern "C" int caphn_decoder_prepare_rows(const caphn_decoder_dims* d, const int64_t* targets, int64_t ignore_index,
                                           void* ws_, caphn_stream_t stream) {
     if (!dims_ok(d) || !targets || !ws_) return CAPHN_EINVAL;
@@ -382,7 +402,8 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     const int B = d->B, T = d->T, P = d->P, D = d->D, F = d->F, E = d->E, H = d->H, V = d->V;
     const bool lstm = d->cell == CAPHN_CELL_LSTM, raw = d->raw_features != 0;
     const int BP = B * P, BT = B * T, GH = w.NG * H, EF = E + F;
-    const int RG = caphn_rec_resident_gates(P, H, w.NG);
+    const bool pair = use_pair(d);
+    const int RG = pair ? caphn_rec_pair_resident_gates(P, H, w.NG) : caphn_rec_resident_gates(P, H, w.NG);
     if (RG < 0) return CAPHN_ELIMIT;
     if (lstm && (!p->initc_w || !p->initc_b)) return CAPHN_EINVAL;
     if (!raw && (!p->fc0_w || !p->fc0_b || !p->fc2_w || !p->fc2_b)) return CAPHN_EINVAL;
@@ -403,6 +424,13 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     a.vecS = (H % 4 == 0) && caphn_aligned16(ws);
     a.prof = reinterpret_cast<unsigned long long*>(ws + w.prof);
     a.rotate = g_tune_rec_rotate;
+    if (pair) {
+        a.xch = reinterpret_cast<unsigned long long*>(ws + w.xch);
+        a.WP = ws + w.wp; a.wp_pitch = caphn_rec_pair_pitch(H);
+        RUN(caphn_launch_rec_pair_prep(a.xch, 2 * w.xch_floats * sizeof(float) / sizeof(unsigned long long), p->Ua_w, p->w_hh, H, w.NG,
+                                       ws + w.wp, s));
+        RUN(caphn_launch_rec_pair_fwd(a, lstm, s));
+    } else
     RUN(caphn_launch_rec_fwd(a, lstm, s));
 
     // vocab projection for all (b,t) at once      decoderlstm.py:105
@@ -452,7 +480,8 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     const int B = d->B, T = d->T, P = d->P, D = d->D, F = d->F, E = d->E, H = d->H, V = d->V;
     const bool lstm = d->cell == CAPHN_CELL_LSTM, raw = d->raw_features != 0;
     const int BP = B * P, BT = B * T, GH = w.NG * H, EF = E + F;
-    const int RG = caphn_rec_resident_gates(P, H, w.NG);
+    const bool pair = use_pair(d);
+    const int RG = pair ? caphn_rec_pair_resident_gates(P, H, w.NG) : caphn_rec_resident_gates(P, H, w.NG);
     if (RG < 0) return CAPHN_ELIMIT;
     if (lstm && (!g->initc_w || !g->initc_b)) return CAPHN_EINVAL;
     if (!raw && (!g->fc0_w || !g->fc0_b || !g->fc2_w || !g->fc2_b)) return CAPHN_EINVAL;    // before any branch is forked
@@ -499,8 +528,14 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     a.rotate = g_tune_rec_rotate;
     // attention parameter gradients (dWaf, partial d v_a / d b_va) come out of the BPTT kernel itself when its thread
     // map can carry them (it evaluates the same tanh for d(U_a h)): one ~50 us kernel less on the chain
-    const int ang = caphn_rec_bwd_groups(P, H);
+    const int ang = pair ? caphn_rec_pair_bwd_groups(P, H) : caphn_rec_bwd_groups(P, H);
     if (ang > 0) { a.dWaf = ws + w.dWaf; a.apart = ws + w.apart; }
+    if (pair) {
+        a.xch = reinterpret_cast<unsigned long long*>(ws + w.xch) + w.xch_floats * sizeof(float) / sizeof(unsigned long long);
+        a.apart_rows = ang;
+        a.WP = ws + w.wp; a.wp_pitch = caphn_rec_pair_pitch(H);
+        RUN(caphn_launch_rec_pair_bwd(a, lstm, s));
+    } else
     RUN(caphn_launch_rec_bwd(a, lstm, s));
 
     // ---- after BPTT.  Only  attn_param_grads -> df -> dY1 -> dW_fc0  is a true chain (main stream); every other

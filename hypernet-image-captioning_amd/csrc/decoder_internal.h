@@ -23,6 +23,10 @@ struct RecFwdArgs {
     unsigned long long* prof;               // 8 counters: per-phase shader-clock sums of workgroup 0 (tuning aid)
     int vecW, vecS, rotate;
     int slab_div = 1;   // rows b share the image slab b / slab_div of Waf and G (beam search: beams of one image)
+    // two-workgroups-per-caption kernels (recurrent_pair.hip)
+    unsigned long long* xch = nullptr;   // exchange area, caphn_rec_pair_xch_bytes, zero at launch
+    const float* WP = nullptr; int wp_pitch = 0;   // [U_a; W_hh] packed to a 128-byte-aligned row pitch (caphn_launch_rec_pair_prep)
+    int t0 = 0, t1 = 0;                  // time-step window [t0, t1) of this launch (t1 == 0: T); t0 > 0 continues from Hs / Cs
 };
 struct RecBwdArgs {
     int B, T, P, H;
@@ -43,6 +47,9 @@ struct RecBwdArgs {
     // attention parameter gradients accumulated across t inside the kernel (the tanh of the d(U_a h) phase is the same
     // one): dWaf [B,P,H] and the d v_a / d b_va partials part [B*ng, H+1] (ng = caphn_rec_bwd_groups(H)); null = not fused
     float* dWaf = nullptr; float* apart = nullptr;
+    unsigned long long* xch = nullptr;   // pair kernels: exchange area (zero at launch)
+    const float* WP = nullptr; int wp_pitch = 0;
+    int apart_rows = 0;                  // pair kernels: rows of `apart` per caption
 };
 struct AttnGradArgs {
     int T, P, H, pchunk;
@@ -56,6 +63,17 @@ size_t caphn_rec_bwd_lds_bytes(int P, int H, int NG, int RG);
 int caphn_rec_resident_gates(int P, int H, int NG);       // largest RG whose fwd and bwd kernels fit 160 KB; -1 if none
 int caphn_launch_rec_fwd(const RecFwdArgs& a, bool lstm, hipStream_t s);
 int caphn_launch_rec_bwd(const RecBwdArgs& a, bool lstm, hipStream_t s);
+// recurrent_pair.hip: the same loops with two workgroups per caption (B captions on 2 B CUs)
+bool caphn_rec_pair_ok(int P, int H, int NG, int RG);
+int caphn_rec_pair_resident_gates(int P, int H, int NG);
+size_t caphn_rec_pair_xch_bytes(int B, int P, int H);
+int caphn_rec_pair_bwd_groups(int P, int H);
+int caphn_rec_pair_pitch(int H);
+size_t caphn_rec_pair_wp_floats(int H, int NG);
+int caphn_launch_rec_pair_prep(unsigned long long* xch, size_t nxch, const float* U_a, const float* W_hh, int H, int NG, float* WP,
+                               hipStream_t s);
+int caphn_launch_rec_pair_fwd(const RecFwdArgs& a, bool lstm, hipStream_t s);
+int caphn_launch_rec_pair_bwd(const RecBwdArgs& a, bool lstm, hipStream_t s);
 int caphn_rec_bwd_groups(int P, int H);     // > 0: the backward kernel can fuse the attention parameter gradients (rows of `apart` per caption)
 int caphn_launch_attn_param_grads(const AttnGradArgs& a, int B, int npc, hipStream_t s);
 int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const float* f, float* ctx, hipStream_t s);

@@ -560,6 +560,8 @@ extern int g_tune_fork;
 extern int g_tune_gemm_xcd;
 extern int g_tune_gemm_fast;
 extern int g_tune_gemm_planes;
+extern int g_tune_rec_pair;
+int caphn_rec_pair_debug_skip(int v);
 extern "C" int caphn_tune(int key, int value) {
     if (key == 0) { g_tune_gemv = value; return CAPHN_OK; }
     if (key == 1) { g_tune_adam = value; return CAPHN_OK; }
@@ -569,5 +571,7 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 6) { g_tune_gemm_xcd = value; return CAPHN_OK; }
     if (key == 7) { g_tune_gemm_fast = value; return CAPHN_OK; }
     if (key == 8) { g_tune_gemm_planes = value; return CAPHN_OK; }
+    if (key == 9) { g_tune_rec_pair = value; return CAPHN_OK; }
+    if (key == 10) return caphn_rec_pair_debug_skip(value);
     return CAPHN_EINVAL;
 }

