@@ -95,6 +95,7 @@ SIGNATURES = {
                                         c_fp, C.c_int, c_fp, C.c_int, C.c_size_t, c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int,
                                         C.c_int, C.c_int, c_fp]),
     "caphn_zero_f32": (C.c_int, [c_fp, C.c_size_t, c_fp]),
+    "caphn_lrelu_bwd_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp, c_fp]),
     "caphn_axpy_f32": (C.c_int, [C.c_size_t, C.c_float, c_fp, c_fp, c_fp]),
     "caphn_scale_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp, c_fp]),
     "caphn_add_dropout_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, C.c_float, C.c_uint64, C.c_uint64, c_fp, c_fp]),

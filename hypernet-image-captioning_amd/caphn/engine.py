@@ -28,9 +28,19 @@ def _up4(n: int) -> int:
 
 class FusedTrainer:
     def __init__(self, hypernet, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 max_norm: float = 5.0, group=None):
-        """hypernet: a hypernet_attention.HyperNet (this package's) already on a CUDA device."""
+                 max_norm: float = 5.0, group=None, frontend=None, frontend_mode: Optional[str] = None):
+        """hypernet: a hypernet_attention.HyperNet (this package's) already on a CUDA device.
+        frontend / frontend_mode: HyperNetCC's trainable domain front-end `self.embed` and its `embedding` mode
+        (cc_train_hypernet.py:93-109: 'embedding', 'histograme', 'histograme log', 'histograme tfidf', 'JSD'; 'one hot' has
+        no parameters and needs none of this): its parameters join the arena and the Adam pass, the hypernet's input row is
+        computed from `domain_input` by libcaphn GEMMs with a LeakyReLU epilogue, and the row's gradient is pushed back
+        through it (from_cc() builds the trainer from a HyperNetCC)."""
         self.net = hypernet
+        self.frontend = frontend
+        self.fe_mode = frontend_mode
+        if frontend is not None and frontend_mode not in ("embedding", "histograme", "histograme log", "histograme tfidf", "JSD"):
+            raise CaphnError(f"front-end mode {frontend_mode!r} has no trainable parameters or is unknown")
+        self._fe_slot, self._fe_slot_next = {}, {}
         self.cap = hypernet.captioner
         self.shape: ops.HyperShape = hypernet._shape
         self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
@@ -128,6 +138,10 @@ class FusedTrainer:
             p = dec[n]
             offs["captioner." + n] = (o, p.numel(), tuple(p.shape))
             o = _up4(o + p.numel())
+        fe = self._frontend_tensors()
+        for n, prm in fe.items():                      # at the end of the arena: their gradients are the last to complete
+            offs[n] = (o, prm.numel(), tuple(prm.shape))
+            o = _up4(o + prm.numel())
         self.n_dense = o
         self.offs = offs
         # all-reduce buckets (float ranges of the arena), in the order the backward completes them
@@ -145,12 +159,26 @@ class FusedTrainer:
             self._adopt(n, p)
         for n in self._dec_names:
             self._adopt("captioner." + n, dec[n])
+        for n, prm in fe.items():
+            self._adopt(n, prm)
         # rank-1 group
         self.W2 = [hyper[f"hn_heads.{i}.2.weight"] for i in range(nh)]
         for w in self.W2:
             w.data = w.data.contiguous()
         self.W2_m = [torch.zeros_like(w.data) for w in self.W2]
         self.W2_v = [torch.zeros_like(w.data) for w in self.W2]
+
+    def _frontend_tensors(self):
+        if self.frontend is None:
+            return {}
+        return {"embed." + n: prm for n, prm in self.frontend.named_parameters()}
+
+    @classmethod
+    def from_cc(cls, net_cc, **kw):
+        """Trainer for a cc_train_hypernet.HyperNetCC: its hypernet, and its domain front-end unless the mode is 'one hot'."""
+        if net_cc.embedding == "one hot":
+            return cls(net_cc.hypernet, **kw)
+        return cls(net_cc.hypernet, frontend=net_cc.embed, frontend_mode=net_cc.embedding, **kw)
 
     def _view(self, flat, name):
         cache = self._vcache.setdefault(id(flat), {})
@@ -180,6 +208,8 @@ class FusedTrainer:
         sub-module transplant :424-428).  Re-adopt any parameter whose storage left the arena."""
         hyper = self.net.hyper_named_tensors()
         dec = {"captioner." + n: t for n, t in self.cap._named_tensors().items() if n in self._dec_names}
+        if self.frontend is not None:
+            dec.update(self._frontend_tensors())
         self._readopted = False
         vers = self._versions
         for name in self.offs:
@@ -261,14 +291,64 @@ class FusedTrainer:
         return hp
 
     # ------------------------------------------------------------------ the step
+    # ------------------------------------------------------------------ domain front-end (cc_train_hypernet.py:93-109, :136-149)
+    def _fe_forward(self, inp, slot):
+        """The hypernet's input row from `inp` (an index for 'embedding', the domain's feature vector otherwise); keeps what
+        the backward needs in `slot`."""
+        if self.fe_mode == "embedding":
+            slot["idx"] = int(inp)
+            return self._view(self.flat_p, "embed.weight")[int(inp)]
+        inp = inp.reshape(1, -1).to(device=self.dev, dtype=torch.float32).contiguous()
+        slot["inp"] = inp
+        y0 = slot.get("y0")
+        W0, b0 = self._view(self.flat_p, "embed.0.weight"), self._view(self.flat_p, "embed.0.bias")
+        if y0 is None:
+            y0 = slot["y0"] = torch.empty(1, W0.shape[0], dtype=torch.float32, device=self.dev)
+        ops.gemm(inp, W0, tb=True, bias=b0, lrelu=True, out=y0)
+        if self.fe_mode == "JSD":
+            return y0.view(-1)
+        W2, b2 = self._view(self.flat_p, "embed.2.weight"), self._view(self.flat_p, "embed.2.bias")
+        x = slot.get("x")
+        if x is None:
+            x = slot["x"] = torch.empty(1, W2.shape[0], dtype=torch.float32, device=self.dev)
+        ops.gemm(y0, W2, tb=True, bias=b2, lrelu=True, out=x)
+        return x.view(-1)
+
+    def _fe_backward(self, gx, slot):
+        """d loss / d (front-end parameters) from the hypernet's input-row gradient gx, into the (zeroed) gradient arena."""
+        g = lambda n: self._view(self.flat_g, n)
+        if self.fe_mode == "embedding":
+            i = slot["idx"]
+            tok = self._toks.get(("emb", i))
+            if tok is None:
+                tok = self._toks[("emb", i)] = torch.full((1,), i, dtype=torch.int64, device=self.dev)
+            ops.embedding_scatter_add(gx.view(1, -1), tok, g("embed.weight"))
+            return
+        y0 = slot["y0"]
+        if self.fe_mode == "JSD":
+            dz0 = ops.lrelu_bwd(gx.view(1, -1).contiguous(), y0)
+        else:
+            dz2 = ops.lrelu_bwd(gx.view(1, -1).contiguous(), slot["x"])
+            ops.outer(dz2.view(-1), y0.view(-1), out=g("embed.2.weight"))
+            ops.axpy_(g("embed.2.bias"), dz2.view(-1))
+            dy0 = ops.gemm(dz2, self._view(self.flat_p, "embed.2.weight"))
+            dz0 = ops.lrelu_bwd(dy0, y0)
+        ops.outer(dz0.view(-1), slot["inp"].view(-1), out=g("embed.0.weight"))
+        ops.axpy_(g("embed.0.bias"), dz0.view(-1))
+
+    def _fe_key(self, inp):
+        return ("emb", int(inp)) if self.fe_mode == "embedding" else ("fe", inp.data_ptr(), inp._version)
+
     def forward_backward(self, features, captions, x_style=None, style_token: Optional[int] = None,
-                         validate: bool = False):
+                         validate: bool = False, domain_input=None):
         """Fills the gradient arena (and the rank-1 factors) for one minibatch; returns the device
         tensor [loss, n_valid_targets] (a per-shape buffer the next call overwrites: .clone() or .item() it to keep a
         step's value).  Exactly one of x_style ([he] or [1,he]) / style_token (Flickr
         path: x = captioner.embed.weight[token], hypernet_attention.py:139-142)."""
-        if (x_style is None) == (style_token is None):
-            raise CaphnError("pass exactly one of x_style / style_token")
+        if (x_style is not None) + (style_token is not None) + (domain_input is not None) != 1:
+            raise CaphnError("pass exactly one of x_style / style_token / domain_input")
+        if domain_input is not None and self.frontend is None:
+            raise CaphnError("domain_input needs a trainer built with a front-end (FusedTrainer.from_cc)")
         self._sync_params()
         if self._works:                 # a previous forward_backward whose optimizer_step never came: its collectives
             dp.wait_all(self._works)    # still own the gradient arena
@@ -278,7 +358,10 @@ class FusedTrainer:
         buf = self._buffers(B, T, P)
         dims = buf["dims"]
         hp = self._hyper_params()
-        if style_token is not None:
+        if domain_input is not None:
+            key = self._fe_key(domain_input)
+            x = None                    # computed below unless the previous optimiser pass already did
+        elif style_token is not None:
             x = self._view(self.flat_p, "captioner.embed.weight")[style_token]
         else:
             x = x_style.reshape(-1).to(device=self.dev, dtype=torch.float32)
@@ -286,13 +369,17 @@ class FusedTrainer:
         theta = getattr(self, "_theta", None)
         if theta is None:
             theta = self._theta = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)
-        key = ("tok", int(style_token)) if style_token is not None else ("x", x_style.data_ptr(), x_style._version)
+        if domain_input is None:
+            key = ("tok", int(style_token)) if style_token is not None else ("x", x_style.data_ptr(), x_style._version)
         if self._next_key is not None and self._next_key == key and not self._readopted:
             # theta for this input was already produced by the previous optimiser pass
             self._theta, self._theta_next = self._theta_next, self._theta
             self._acts, self._acts_next = self._acts_next, self._acts
+            self._fe_slot, self._fe_slot_next = self._fe_slot_next, self._fe_slot
             theta = self._theta
         else:
+            if domain_input is not None:
+                x = self._fe_forward(domain_input, self._fe_slot)
             ops.hyper_forward(self.shape, hp, x, theta=theta, acts=self._acts)
         self._next_key = None
         params = self._dec_tensors(theta, grads=False)
@@ -347,7 +434,9 @@ class FusedTrainer:
         # complete and streams the 576 MB of second-layer weights beside the attention / feature_fc chain
         gx = ops.decoder_hyper_backward(dims, params, features, captions, dlogits, grads, buf["ws"],
                                         self.shape, hp, self._acts, hg, self._hyper_ws,
-                                        want_x=style_token is not None)
+                                        want_x=style_token is not None or domain_input is not None)
+        if domain_input is not None:    # the input row's gradient goes on through the front-end, before the exchange is issued
+            self._fe_backward(gx, self._fe_slot)
         tok = None
         if style_token is not None:
             # Flickr path: the style row of the embedding also feeds the hypernet -- its VJP is added to the
@@ -425,7 +514,7 @@ class FusedTrainer:
                 ev = self._adam_copied[i] = torch.cuda.Event()
             ev.record()
 
-    def _optimizer_impl(self, next_x_style=None, next_style_token=None, next_batch=None):
+    def _optimizer_impl(self, next_x_style=None, next_style_token=None, next_batch=None, next_domain_input=None):
         R = dp.world(self.group)
         gfac, acts_all = self._exchange()
         o = 0
@@ -444,12 +533,16 @@ class FusedTrainer:
         step = max(self.step_count, 1)
         ops.adam_dense(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self._coef, self.lr, step,
                        self.betas, self.eps, dev_scalars=self._adam_dev if self._graph_scalars else None)
-        prefetch = (next_x_style is not None) or (next_style_token is not None)
+        prefetch = (next_x_style is not None) or (next_style_token is not None) or (next_domain_input is not None)
         if prefetch:
-            # the small layers (and the style row of the embedding) are already updated: compute the next
+            # the small layers (and the style row of the embedding / the front-end) are already updated: compute the next
             # step's head activations, then let the rank-1 Adam pass emit theta_next = W2' a' + b2' row by row
             hp = self._hyper_params()
-            if next_style_token is not None:
+            if next_domain_input is not None:
+                xn = self._fe_forward(next_domain_input, self._fe_slot_next)
+                self._next_key = self._fe_key(next_domain_input)
+                self._next_hold = next_domain_input
+            elif next_style_token is not None:
                 xn = self._view(self.flat_p, "captioner.embed.weight")[int(next_style_token)]
                 self._next_key = ("tok", int(next_style_token))
             else:
@@ -508,25 +601,25 @@ class FusedTrainer:
         self._pre_key = (_tkey(features), _tkey(captions) if (level == 2 and captions is not None) else None, B, T, P, level)
         self._pre_hold = (features, captions)         # announced tensors stay alive: their addresses cannot be recycled
 
-    def optimizer_step(self, next_x_style=None, next_style_token=None, next_batch=None):
+    def optimizer_step(self, next_x_style=None, next_style_token=None, next_batch=None, next_domain_input=None):
         """clip_grad_norm_(max_norm) over ALL gradients + Adam, on device, no host sync.
         If the NEXT minibatch's style row is already known (the data loader is one batch ahead), pass it:
         the Adam pass over the big second-layer weights then also produces the next step's theta, saving that
         step's 576 MB forward read (the following forward_backward must be called with that same input)."""
         self._begin_step()
-        return self._optimizer_impl(next_x_style, next_style_token, next_batch)
+        return self._optimizer_impl(next_x_style, next_style_token, next_batch, next_domain_input)
 
     def step(self, features, captions, x_style=None, style_token=None, next_x_style=None, next_style_token=None,
-             next_features=None, next_captions=None, next_T=None):
+             next_features=None, next_captions=None, next_T=None, domain_input=None, next_domain_input=None):
         """next_features (+ next_captions, or next_T when only the length is known; default: this T): the NEXT
         minibatch when the loader is one batch ahead -- the front of its forward then overlaps this step's optimiser
         (the next call must pass those same tensors; captions as int64)."""
         self._begin_step()          # the Adam scalars' H2D copy goes in front of the forward, off the optimiser's tail
-        loss = self.forward_backward(features, captions, x_style, style_token)
+        loss = self.forward_backward(features, captions, x_style, style_token, domain_input=domain_input)
         if next_captions is not None:
             next_T = next_captions.shape[1]
         nb = None if next_features is None else (next_features, next_captions, captions.shape[1] if next_T is None else next_T)
-        self._optimizer_impl(next_x_style, next_style_token, nb)
+        self._optimizer_impl(next_x_style, next_style_token, nb, next_domain_input)
         return loss
 
     def step_graphed(self, features, captions, x_style=None, style_token=None):
@@ -573,6 +666,7 @@ class FusedTrainer:
         names = []
         for i in range(self._nh):
             names += [f"hn_heads.{i}.0.weight", f"hn_heads.{i}.0.bias", f"hn_heads.{i}.2.weight", f"hn_heads.{i}.2.bias"]
+        names += list(self._frontend_tensors())       # cc_train_hypernet.py:111-113: self.embed right after the heads
         names += ["hn_base.0.weight", "hn_base.0.bias", "hn_base.2.weight", "hn_base.2.bias"]
         dec = ["feature_fc.0.weight", "feature_fc.0.bias", "feature_fc.2.weight", "feature_fc.2.bias", "embed.weight",
                "fc.weight", "fc.bias", "attention.W_a.weight", "attention.W_a.bias", "attention.U_a.weight",

@@ -8,7 +8,7 @@ import torch
 
 from . import _lib as L
 
-GEMM_BIAS, GEMM_RELU, GEMM_ACCUM, GEMM_MASK = 1, 2, 4, 8
+GEMM_BIAS, GEMM_RELU, GEMM_ACCUM, GEMM_MASK, GEMM_LRELU = 1, 2, 4, 8, 16
 
 
 def _f32(*shape, device):
@@ -18,7 +18,7 @@ def _f32(*shape, device):
 # ------------------------------------------------------------------ dense contraction
 def gemm(a: torch.Tensor, b: torch.Tensor, ta: bool = False, tb: bool = False,
          bias: Optional[torch.Tensor] = None, relu: bool = False, out: Optional[torch.Tensor] = None,
-         accumulate: bool = False, mask: Optional[torch.Tensor] = None, splitk: int = 1) -> torch.Tensor:
+         accumulate: bool = False, mask: Optional[torch.Tensor] = None, splitk: int = 1, lrelu: bool = False) -> torch.Tensor:
     """out[M,N] = epilogue(op(a) @ op(b)) on the fp32 MFMA pipe (caphn_gemm_f32).
     a, b are 2-D row-major tensors whose last stride is 1 (leading stride = ld)."""
     lib = L.load()
@@ -33,7 +33,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, ta: bool = False, tb: bool = False,
             out.zero_()
     assert out.shape == (M, N) and out.stride(1) == 1
     flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_RELU if relu else 0) | \
-            (GEMM_ACCUM if accumulate else 0) | (GEMM_MASK if mask is not None else 0)
+            (GEMM_ACCUM if accumulate else 0) | (GEMM_MASK if mask is not None else 0) | (GEMM_LRELU if lrelu else 0)
     for t in (a, b, out, bias, mask):
         if t is not None and (not t.is_cuda or t.dtype != torch.float32):
             raise L.CaphnError("gemm needs fp32 CUDA tensors")
@@ -107,6 +107,16 @@ def scale_(x: torch.Tensor, scale_dev: torch.Tensor) -> torch.Tensor:
     L.check(lib.caphn_scale_f32(x.numel(), L.ptr(x), L.ptr(scale_dev.reshape(-1)[:1].contiguous()), L.ptr(x), L.stream_ptr()),
             "caphn_scale_f32")
     return x
+
+
+def lrelu_bwd(dy: torch.Tensor, post: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.LeakyReLU() backward from the layer's output: dy * (post > 0 ? 1 : 0.01)."""
+    lib = L.load()
+    assert dy.numel() == post.numel() and dy.is_contiguous() and post.is_contiguous()
+    if out is None:
+        out = torch.empty_like(dy)
+    L.check(lib.caphn_lrelu_bwd_f32(dy.numel(), L.ptr(dy), L.ptr(post), L.ptr(out), L.stream_ptr()), "caphn_lrelu_bwd_f32")
+    return out
 
 
 def axpy_(y: torch.Tensor, x: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:

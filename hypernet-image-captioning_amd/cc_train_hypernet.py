@@ -13,6 +13,8 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from caphn import functional as CF
+
 from hypernet_attention import HyperNet, _Base, pl
 from models.encoder import EncoderCNN
 from utils import get_hist_embedding
@@ -85,6 +87,19 @@ class HyperNetCC(_Base):
         feats = torch.tensor(self.dict_domain[domain], dtype=torch.float32, device=dev)
         return self.embed(feats)
 
+    def domain_input(self, domain):
+        """What FusedTrainer.from_cc(self).step(..., domain_input=...) takes for one domain name: the embedding index, or the
+        domain's feature vector on the device ('one hot' has no front-end: pass style_embedding(domain) as x_style)."""
+        if self.embedding == 'embedding':
+            return int(self.dict_domain[domain])
+        if self.embedding == 'one hot':
+            raise ValueError("'one hot' has no trainable front-end: use x_style=self.style_embedding(domain)")
+        cache = self.__dict__.setdefault('_domain_inputs', {})
+        t = cache.get(domain)
+        if t is None:
+            t = cache[domain] = torch.tensor(self.dict_domain[domain], dtype=torch.float32, device=self._device())
+        return t
+
     def configure_optimizers(self):
         """:110-122 (parameter order kept)."""
         params = list(self.hypernet.hn_heads.parameters())
@@ -101,8 +116,8 @@ class HyperNetCC(_Base):
         return [optimizer], [{'scheduler': scheduler, 'monitor': 'val_loss with TF', 'interval': 'epoch'}]
 
     def _loss(self, caps_pred, caps):
-        return F.cross_entropy(caps_pred.view(-1, self.hparams['vocab_size']), caps.view(-1).long(),
-                               ignore_index=self.vocab.w2i['<pad>'])
+        return CF.cross_entropy(caps_pred.view(-1, self.hparams['vocab_size']), caps.view(-1).long(),
+                                ignore_index=self.vocab.w2i['<pad>'])
 
     def training_step(self, train_batch, batch_idx):
         """:134-166 without the text metrics / logging."""

@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                 if (atomic) { atomicAdd(c, v); continue; }
                 if (g.flags & CAPHN_GEMM_ACCUM) v += *c;
                 if (g.flags & CAPHN_GEMM_RELU) v = fmaxf(v, 0.f);
+                if (g.flags & CAPHN_GEMM_LRELU) v = v > 0.f ? v : 0.01f * v;
                 if (g.flags & CAPHN_GEMM_MASK) v = (g.mask[(size_t)row * g.ldmask + col] > 0.f) ? v : 0.f;
                 *c = v;
             }

@@ -185,6 +185,9 @@ __global__ __launch_bounds__(256) void scale_kernel(size_t n, const float* __res
 }
 
 // y += alpha * x  (gradients of parameters that alias the same theta range: set_all_parameters' child-offset restart)
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(size_t n, const float* __restrict__ dy, const float* __restrict__ post, float* __restrict__ dx) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dx[i] = dy[i] * (post[i] > 0.f ? 1.f : 0.01f);
+}
 __global__ __launch_bounds__(256) void axpy_kernel(size_t n, float alpha, const float* __restrict__ x, float* __restrict__ y) {
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = fmaf(alpha, x[i], y[i]);
@@ -705,6 +708,14 @@ extern "C" int caphn_scale_f32(size_t n, const float* x, const float* scale_dev,
     size_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), n, x, scale_dev, out);
+    return caphn_launch_status();
+}
+extern "C" int caphn_lrelu_bwd_f32(size_t n, const float* dy, const float* post, float* dx, caphn_stream_t stream) {
+    if (n == 0) return CAPHN_OK;
+    if (!dy || !post || !dx) return CAPHN_EINVAL;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), n, dy, post, dx);
     return caphn_launch_status();
 }
 extern "C" int caphn_axpy_f32(size_t n, float alpha, const float* x, float* y, caphn_stream_t stream) {

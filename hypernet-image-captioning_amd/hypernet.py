@@ -109,7 +109,7 @@ class HyperNet(_Base):
             warnings.warn("hypernet.HyperNet.training_step: the reference would have taken the sampled (torch.multinomial) "
                           "branch for this step; this build teacher-forces it", RuntimeWarning, stacklevel=2)
         caps_pred = self.captioner(img_feats, caps.long(), True)
-        loss = F.cross_entropy(caps_pred.view(-1, self.hparams['vocab_size']), caps.view(-1).long())
+        loss = CF.cross_entropy(caps_pred.view(-1, self.hparams['vocab_size']), caps.view(-1).long())
         if self.teacher_forcing_proba > 0.25:
             self.teacher_forcing_proba = self.teacher_forcing_proba * 0.9995
         return loss

@@ -120,8 +120,8 @@ class HyperNet(_Base):
             caps_pred, _ = self.captioner(img_feats, caps.long(), self.teacher_forcing_proba)
         else:
             caps_pred, _ = self.captioner(caps.long(), img_feats, self.teacher_forcing_proba)
-        return F.cross_entropy(caps_pred.view(-1, self.hparams['vocab_size']), caps.view(-1).long(),
-                               ignore_index=self.vocab.w2i['<pad>'])
+        return CF.cross_entropy(caps_pred.view(-1, self.hparams['vocab_size']), caps.view(-1).long(),
+                                ignore_index=self.vocab.w2i['<pad>'])
 
     def beam_search(self, features, beam_size=None, max_step=50, end_token=None):
         """Beam search of test_step (hypernet_attention.py:251-306) for a batch of encoder outputs [B,P,2048]

@@ -64,6 +64,7 @@ int caphn_device_arch(char* buf, int buflen);
 #define CAPHN_GEMM_RELU 2
 #define CAPHN_GEMM_ACCUM 4   /* C += result (read-modify-write, no atomics) */
 #define CAPHN_GEMM_MASK 8
+#define CAPHN_GEMM_LRELU 16  /* nn.LeakyReLU() (slope 0.01) on the result: the domain front-ends of cc_train_hypernet.py:96-106 */
 int caphn_gemm_f32(int ta, int tb, int M, int N, int K,
                    const float* A, int lda, const float* B, int ldb,
                    float* C, int ldc, const float* bias,
@@ -102,6 +103,8 @@ int caphn_add_dropout_f32(size_t n, const float* x, const float* branch, float p
                           unsigned long long offset, float* out, caphn_stream_t stream);
 /* out[i] = x[i] * scale_dev[0]: the chain rule through a scalar loss whose upstream gradient lives on the device (x may equal out). */
 int caphn_scale_f32(size_t n, const float* x, const float* scale_dev, float* out, caphn_stream_t stream);
+/* nn.LeakyReLU() backward from the layer's OUTPUT: dx[i] = dy[i] * (post[i] > 0 ? 1 : 0.01)   (dx may equal dy). */
+int caphn_lrelu_bwd_f32(size_t n, const float* dy, const float* post, float* dx, caphn_stream_t stream);
 /* y[0..n) += alpha * x[0..n): sums the gradients of parameters that are views of one theta range (utils.py:62-68: every
    child module restarts at offset 0, so hypernet.py's extra layers alias the first cell's slices). */
 int caphn_axpy_f32(size_t n, float alpha, const float* x, float* y, caphn_stream_t stream);

@@ -549,17 +549,33 @@ TRAINABLE_DECODER = ("captioner.feature_fc.", "captioner.embed.", "captioner.fc.
 
 def trainable_names(p: Dict[str, Tensor]) -> List[str]:
     """Optimiser parameter list, hypernet_attention.py:124-130 /
-    cc_train_hypernet.py:110-118: hn_heads, hn_base, then the captioner's
-    feature_fc, embed, fc, attention, init_h (never captioner.gru)."""
+    cc_train_hypernet.py:110-118: hn_heads, [the domain front-end `embed`, unless one
+    hot], hn_base, then the captioner's feature_fc, embed, fc, attention, init_h (never
+    captioner.gru)."""
     heads = [k for k in p if k.startswith("hn_heads.")]
+    front = [k for k in p if k.startswith("embed.")]
     base = [k for k in p if k.startswith("hn_base.")]
     dec = [k for k in p if k.startswith(TRAINABLE_DECODER)]
-    return heads + base + dec
+    return heads + front + base + dec
+
+
+def frontend_forward(p: Dict[str, Tensor], mode: str, inp) -> Tensor:
+    """The hypernet's input row for one domain, cc_train_hypernet.py:136-149 with the modules of
+    :93-109: 'embedding' -> nn.Embedding(#domains, he) row `inp` (an index); the histogram modes ->
+    Linear(V+1, 4 he), LeakyReLU, Linear(4 he, he), LeakyReLU over the domain's word histogram;
+    'JSD' -> Linear(n_tsne, he), LeakyReLU over its t-SNE coordinates.  Parameters are the
+    reference's `self.embed` state_dict entries under the prefix 'embed.'."""
+    if mode == "embedding":
+        return p["embed.weight"][int(inp)]
+    x = F_.leaky_relu(F_.linear(inp, p["embed.0.weight"], p["embed.0.bias"]), LRELU_SLOPE)
+    if mode == "JSD":
+        return x
+    return F_.leaky_relu(F_.linear(x, p["embed.2.weight"], p["embed.2.bias"]), LRELU_SLOPE)
 
 
 def forward_backward(dims: Dims, p: Dict[str, Tensor], x_style: Tensor, features: Tensor,
                      captions: Tensor, style_token: Optional[int] = None,
-                     detach_theta: bool = False):
+                     detach_theta: bool = False, frontend: Optional[Tuple[str, object]] = None):
     """One forward + backward.  Returns (loss, logits, alphas, theta, grads) where
     grads holds (i) the literal quantities the reference's autograd yields -- grads
     of the non-generated captioner parameters and 'dtheta' = cat of the leaf grads of
@@ -571,6 +587,8 @@ def forward_backward(dims: Dims, p: Dict[str, Tensor], x_style: Tensor, features
     q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
     if style_token is not None:
         x = q["captioner.embed.weight"][style_token].unsqueeze(0)
+    elif frontend is not None:           # (mode, input): x comes out of the trainable domain front-end
+        x = frontend_forward(q, frontend[0], frontend[1])
     else:
         x = x_style
     theta = hyper_forward(q, x)
@@ -609,12 +627,12 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
 def train_step(dims: Dims, p: Dict[str, Tensor], state: Dict[str, Tensor], step: int,
                x_style: Optional[Tensor], features: Tensor, captions: Tensor,
                lr: float = 1e-3, max_norm: float = 5.0, style_token: Optional[int] = None,
-               grads_override: Optional[Dict[str, Tensor]] = None):
+               grads_override: Optional[Dict[str, Tensor]] = None, frontend: Optional[Tuple[str, object]] = None):
     """forward_backward -> clip -> Adam over trainable_names(p).  state holds
     'm.<name>' / 'v.<name>'.  p and state are updated in place.  grads_override lets
     the data-parallel tests inject already-averaged gradients."""
     loss, logits, alphas, theta, grads = forward_backward(dims, p, x_style, features, captions,
-                                                          style_token=style_token)
+                                                          style_token=style_token, frontend=frontend)
     if grads_override is not None:
         grads = grads_override
     names = [n for n in trainable_names(p) if grads.get(n) is not None]

@@ -115,6 +115,68 @@ def test_full_size_step_properties(full):
     assert bool(torch.isfinite(tr.flat_p).all()) and all(bool(torch.isfinite(w.data).all()) for w in tr.W2)
 
 
+def test_full_size_lstm_forward_backward():
+    """BASELINE config 3 at full size: HyperNet(cell='lstm') -- 257 M hypernet parameters generating an LSTMCell behind the
+    same feature_fc -- B=128, T=20, P=49, against tests/golden/lstm_full.npz (samples + checksums written by the oracle,
+    which tools/make_golden.py asserted equal to the reference's AttentionLstm on lstm_tiny in the same run; meta.json
+    records that).  Same checks as the GRU case: loss, sampled logits rows, attention rows, argmax tokens wherever the
+    top-2 margin is not a rounding tie, theta / dtheta samples and norms, every gradient's norm and 64 sampled entries."""
+    from hypernet_attention import HyperNet
+    from caphn.engine import FusedTrainer
+    from caphn import ops
+    import dataclasses
+    z = np.load(os.path.join(GOLDEN, "lstm_full.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "meta.json")))["lstm_full"]
+    assert "asserted equal to the reference" in meta["generated_by"]
+    assert max(meta["oracle_vs_reference_on_lstm_tiny_max_abs"].values()) < 2e-6
+    dims = O.Dims(cell="lstm")
+    seed, B, T, P = int(z["seed"]), int(z["B"]), int(z["T"]), int(z["P"])
+    p = O.init_params(dims, seed)
+    batch = O.synth_batch(dims, B, T, P, seed=seed + 1)
+    net = HyperNet(dims.F, dims.E, dims.H, dims.V, _Vocab(), cell="lstm")
+    sd = {k.replace("captioner.embed.", "captioner.embeddings."): v for k, v in p.items()}
+    res = net.load_state_dict(sd, strict=False)
+    assert all(k.startswith("captioner.lstm.") for k in res.missing_keys) and not res.unexpected_keys
+    del sd, p
+    net = net.to(DEV)
+    assert sum(q.numel() for q in net.hn_heads.parameters()) + sum(q.numel() for q in net.hn_base.parameters()) > 256_000_000
+    tr = FusedTrainer(net, lr=1e-3, max_norm=5.0)
+    feats, caps = batch["features"].to(DEV), batch["captions"].to(DEV)
+    loss = tr.forward_backward(feats, caps, style_token=int(z["style_token"]), validate=True)
+    assert abs(float(loss[0]) - float(z["loss"])) < 5e-6
+    buf = tr._buffers(B, T, P)
+    params = tr._dec_tensors(tr._theta, grads=False)
+    logits, alphas = ops.decoder_forward(dataclasses.replace(buf["dims"], rows=False), params, feats, caps, buf["ws"])
+    lg = logits.cpu().numpy()
+    for i, (b, t) in enumerate(z["logit_rows_bt"]):
+        assert np.abs(lg[b, t] - z["logit_rows"][i]).max() < 5e-6
+        assert np.abs(alphas[b, t].cpu().numpy() - z["alphas_rows"][i]).max() < 1e-6
+    assert abs(float((logits.double() ** 2).sum()) / float(z["logits_sumsq"]) - 1) < 1e-6
+    am = logits.argmax(-1).cpu().numpy()
+    safe = z["argmax_margin"] > 2e-5
+    assert safe.mean() > 0.99 and (am[safe] == z["argmax_tokens"][safe]).all()
+    th = tr._theta.cpu().numpy()
+    assert np.abs(th[z["theta_idx"]] - z["theta_vals"]).max() < 2e-6
+    dth = tr.flat_g[:tr.theta_size]
+    assert np.abs(dth.cpu().numpy()[z["theta_idx"]] - z["dtheta_vals"]).max() < 2e-6
+    assert abs(float((dth.double() ** 2).sum()) / float(z["dtheta_sumsq"]) - 1) < 1e-4
+    for k, n in meta["grad_norms"].items():
+        if k.startswith("hn_heads.") and k.endswith(".2.weight"):
+            got = tr.w2_grad_dense(int(k.split(".")[1]))
+        else:
+            got = tr.grad(k)
+        mine = float(got.double().norm())
+        assert abs(mine - n) < 1e-4 * max(n, 1e-3), (k, mine, n)
+        assert np.abs(got.flatten().cpu().numpy()[z["gidx/" + k]] - z["gval/" + k]).max() < 2e-6, k
+        del got
+    # a few optimiser steps run and lower the loss
+    l0 = float(loss[0])
+    tr.optimizer_step()
+    for _ in range(3):
+        l = tr.step(feats, caps, style_token=int(z["style_token"]))
+    assert float(l[0]) < l0 and bool(torch.isfinite(tr.flat_p).all())
+
+
 def test_catr_transformer_full_size_against_torch_modules():
     """N4 at BASELINE config 5's model size (d 256, 8 heads, ff 2048, 6+6 pre-norm layers, T = 128, 7x7 positions,
     vocabulary 30522 for the embeddings): the drop-in transformer keeps real nn.MultiheadAttention / nn.LayerNorm /

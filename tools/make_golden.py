@@ -298,6 +298,62 @@ def full_case(name, seed):
 
 
 
+def lstm_full_case(name, seed):
+    """BASELINE config 3 at full size: HyperNet(cell='lstm') -- a hypernet-generated LSTMCell behind the same feature_fc,
+    B=128, T=20, P=49, D=2048, F=E=H=200, V=9684, he=200 (257 M hypernet parameters).  The reference never wraps its
+    AttentionLstm in a hypernet and that class has no feature_fc, so no reference module exists at this configuration:
+    the vectors come from the ORACLE, after asserting here that the oracle reproduces the reference's own AttentionLstm +
+    flip/set_all_parameters run (tests/golden/lstm_tiny.npz, written by lstm_case above from the reference's class)."""
+    z = np.load(os.path.join(OUT, "lstm_tiny.npz"))
+    td = O.Dims(D=12, F=12, E=8, H=8, V=40, he=8, cell="lstm")
+    tp = {k[2:]: torch.from_numpy(np.asarray(z[k])) for k in z.files if k.startswith("p/")}
+    th = O.hyper_forward(tp, torch.from_numpy(z["x_style"]))
+    lg, al = O.decoder_forward(td, tp, O.split_theta(td, th), torch.from_numpy(z["features"]), torch.from_numpy(z["captions"]),
+                               use_feature_fc=False)
+    pin = {"theta": float((th - torch.from_numpy(z["theta"])).abs().max()),
+           "logits": float((lg - torch.from_numpy(z["logits"])).abs().max()),
+           "alphas": float((al - torch.from_numpy(z["alphas"])).abs().max())}
+    assert pin["theta"] < 2e-6 and pin["logits"] < 2e-6 and pin["alphas"] < 1e-6, pin
+    dims = O.Dims(cell="lstm")
+    B, T, P = 128, 20, 49
+    p = O.init_params(dims, seed)
+    batch = O.synth_batch(dims, B, T, P, seed=seed + 1)
+    feats, caps = batch["features"], batch["captions"]
+    style_token = 4 + batch["domain"]
+    loss, logits, alphas, theta, grads = O.forward_backward(dims, p, None, feats, caps, style_token=style_token)
+    rng = np.random.default_rng(seed + 2)
+    arrs = {"seed": np.int64(seed), "B": np.int64(B), "T": np.int64(T), "P": np.int64(P),
+            "style_token": np.int64(style_token), "loss": loss}
+    bt = np.stack([rng.integers(0, B, 6), rng.integers(0, T, 6)], 1)
+    arrs["logit_rows_bt"] = bt
+    arrs["logit_rows"] = np.stack([logits[b, t].numpy() for b, t in bt])
+    arrs["logits_sum"] = np.float64(logits.double().sum())
+    arrs["logits_sumsq"] = np.float64((logits.double() ** 2).sum())
+    arrs["argmax_tokens"] = logits.argmax(-1).numpy().astype(np.int32)
+    top2 = logits.topk(2, dim=-1).values
+    arrs["argmax_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+    arrs["alphas_rows"] = np.stack([alphas[b, t].numpy() for b, t in bt])
+    ti = rng.integers(0, dims.theta_size, 512)
+    dtheta = grads.pop("dtheta")
+    arrs["theta_idx"] = ti; arrs["theta_vals"] = theta.numpy()[ti]
+    arrs["theta_sumsq"] = np.float64((theta.double() ** 2).sum())
+    arrs["dtheta_vals"] = dtheta.numpy()[ti]
+    arrs["dtheta_sumsq"] = np.float64((dtheta.double() ** 2).sum())
+    norms = {}
+    for k in O.trainable_names(p):
+        g = grads[k]
+        norms[k] = float(g.double().norm())
+        flat = g.flatten()
+        idx = rng.integers(0, flat.numel(), 64)
+        arrs["gidx/" + k] = idx
+        arrs["gval/" + k] = flat.numpy()[idx]
+    save_npz(os.path.join(OUT, name + ".npz"), **arrs)
+    return {"grad_norms": norms, "heads": O.head_layout(dims),
+            "generated_by": "oracle/caphn_oracle.py (no reference module exists at this configuration); the oracle was asserted "
+                            "equal to the reference's AttentionLstm + flip/set_all_parameters on lstm_tiny in the same run",
+            "oracle_vs_reference_on_lstm_tiny_max_abs": pin}
+
+
 def ref_captioner(dims, p, x_style):
     """Reference AttentionGru with theta from the restated hypernet injected by the reference's own
     flip_parameters_to_tensors / set_all_parameters (as HyperNet.forward does, hypernet_attention.py:111-121)."""
@@ -580,6 +636,14 @@ def main():
             json.dump(meta, f, indent=1, sort_keys=True)
         print(json.dumps({k: meta[k] for k in CATR_CASES}, indent=1))
         return
+    if "--only-lstm-full" in sys.argv:         # BASELINE config 3 at full size (oracle-generated, oracle pinned on lstm_tiny)
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["lstm_full"] = lstm_full_case("lstm_full", seed=2025)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        print(json.dumps({k: v for k, v in meta["lstm_full"].items() if k != "grad_norms"}, indent=1))
+        return
     if "--only-plain" in sys.argv:             # refresh the hypernet.py / later.py vectors only
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -615,6 +679,7 @@ def main():
         meta[nm] = catr_case(nm, *args)
     if os.environ.get("CAPHN_GOLDEN_FULL", "1") == "1":
         meta["gru_full"] = full_case("gru_full", seed=2024)
+        meta["lstm_full"] = lstm_full_case("lstm_full", seed=2025)
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print(json.dumps({k: v for k, v in meta.items() if k != "gru_full"}, indent=1)[:2000])
