@@ -34,7 +34,7 @@ class HyperGrads(C.Structure):
 
 class DecoderDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "T", "P", "D", "F", "E", "H", "V", "cell", "raw_features", "row_subset",
-                                         "grads_zeroed", "precomputed")]
+                                         "grads_zeroed", "precomputed")] + [("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
 
 
 _DEC_FIELDS = ("fc0_w", "fc0_b", "fc2_w", "fc2_b", "embed_w", "out_w", "out_b", "Wa_w", "Wa_b",

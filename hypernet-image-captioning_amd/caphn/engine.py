@@ -54,8 +54,8 @@ class FusedTrainer:
         if dev.type != "cuda":
             raise CaphnError("FusedTrainer needs the model on a CUDA(HIP) device")
         self.dev = dev
-        if getattr(self.cap, "layers", None) or self.cap.drop.p > 0:
-            raise NotImplementedError("fused step supports num_layers=1, dropout p=0")
+        if getattr(self.cap, "layers", None):
+            raise NotImplementedError("fused step supports num_layers=1")
         d0 = self.cap.dec_dims(1, 1, 1)
         self._cell_names = d0.cell_names()
         # arena order of the decoder's parameters = the order their gradients are finished by the backward, so that
@@ -357,6 +357,12 @@ class FusedTrainer:
         T = captions.shape[1]
         buf = self._buffers(B, T, P)
         dims = buf["dims"]
+        if self.cap.training and self.cap.drop.p > 0:
+            # h = self.drop(h) (models/decoderlstm.py:104): a fresh counter-based mask per step, the same seed in the backward
+            import dataclasses
+            from .functional import next_seed
+            dims = dataclasses.replace(dims, drop_p=float(self.cap.drop.p), seed=next_seed())
+            self.last_dropout_seed = dims.seed
         hp = self._hyper_params()
         if domain_input is not None:
             key = self._fe_key(domain_input)

@@ -290,6 +290,8 @@ class DecDims:
     rows: bool = False       # True: vocab GEMMs only touch rows with a live target (decoder_prepare_rows first)
     pre: int = 0             # bit mask (see caphn_decoder_dims.precomputed): 1 precompute, 2 G, 4 inputs
     gz: bool = False         # True: the caller zero-filled every gradient output (one zero_ over its arena)
+    drop_p: float = 0.0      # dropout on h_t in training mode (caphn_decoder_dims.dropout_p); the backward needs the same seed
+    seed: int = 0
 
     @property
     def NG(self) -> int:
@@ -297,7 +299,8 @@ class DecDims:
 
     def c(self) -> L.DecoderDims:
         return L.DecoderDims(self.B, self.T, self.P, self.D, self.F, self.E, self.H, self.V,
-                             1 if self.cell == "lstm" else 0, int(self.raw), int(self.rows), int(self.gz), int(self.pre))
+                             1 if self.cell == "lstm" else 0, int(self.raw), int(self.rows), int(self.gz), int(self.pre),
+                             float(self.drop_p), int(self.seed) & (2 ** 64 - 1))
 
     def fields(self):
         """Ordered (C struct field, parameter name) pairs this configuration uses."""

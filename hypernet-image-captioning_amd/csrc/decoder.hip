@@ -218,6 +218,7 @@ __global__ void build_idx_kernel(int B, int T, const int64_t* __restrict__ caps,
 }
 
 inline bool dims_ok(const caphn_decoder_dims* d) {
+    if (d && !(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return false;
     if (!(d && d->B > 0 && d->T > 0 && d->P > 0 && d->D > 0 && d->F > 0 && d->E > 0 && d->H > 0 && d->V > 0)) return false;
     if (d->cell != CAPHN_CELL_GRU && d->cell != CAPHN_CELL_LSTM) return false;
     if (d->raw_features && d->F != d->D) return false;
@@ -424,6 +425,7 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     a.vecS = (H % 4 == 0) && caphn_aligned16(ws);
     a.prof = reinterpret_cast<unsigned long long*>(ws + w.prof);
     a.rotate = g_tune_rec_rotate;
+    a.drop_p = d->dropout_p; a.drop_seed = d->dropout_seed;
     if (pair) {
         a.xch = reinterpret_cast<unsigned long long*>(ws + w.xch);
         a.WP = ws + w.wp; a.wp_pitch = caphn_rec_pair_pitch(H);
@@ -528,6 +530,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     a.rotate = g_tune_rec_rotate;
     // attention parameter gradients (dWaf, partial d v_a / d b_va) come out of the BPTT kernel itself when its thread
     // map can carry them (it evaluates the same tanh for d(U_a h)): one ~50 us kernel less on the chain
+    a.drop_p = d->dropout_p; a.drop_seed = d->dropout_seed;
     const int ang = pair ? caphn_rec_pair_bwd_groups(P, H) : caphn_rec_bwd_groups(P, H);
     if (ang > 0) { a.dWaf = ws + w.dWaf; a.apart = ws + w.apart; }
     if (pair) {
@@ -643,6 +646,7 @@ extern "C" int caphn_decoder_forward_sampled(const caphn_decoder_dims* d, const 
                                              const unsigned char* use_sampling,
                                              float* logits, float* alphas, void* ws_, caphn_stream_t stream) {
     if (!dims_ok(d) || !p || !features || !captions || !use_sampling || !logits || !ws_) return CAPHN_EINVAL;
+    if (d->dropout_p > 0.f) return CAPHN_EINVAL;      // forward only: evaluation, no dropout
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = layout(d);
     float* ws = static_cast<float*>(ws_);

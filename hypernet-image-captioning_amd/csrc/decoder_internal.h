@@ -27,6 +27,7 @@ struct RecFwdArgs {
     unsigned long long* xch = nullptr;   // exchange area, caphn_rec_pair_xch_bytes, zero at launch
     const float* WP = nullptr; int wp_pitch = 0;   // [U_a; W_hh] packed to a 128-byte-aligned row pitch (caphn_launch_rec_pair_prep)
     int t0 = 0, t1 = 0;                  // time-step window [t0, t1) of this launch (t1 == 0: T); t0 > 0 continues from Hs / Cs
+    float drop_p = 0.f; unsigned long long drop_seed = 0;   // dropout on h_t: element (b, t, k) keeps by the hash of (seed, (b T + t) H + k)
 };
 struct RecBwdArgs {
     int B, T, P, H;
@@ -50,6 +51,7 @@ struct RecBwdArgs {
     unsigned long long* xch = nullptr;   // pair kernels: exchange area (zero at launch)
     const float* WP = nullptr; int wp_pitch = 0;
     int apart_rows = 0;                  // pair kernels: rows of `apart` per caption
+    float drop_p = 0.f; unsigned long long drop_seed = 0;
 };
 struct AttnGradArgs {
     int T, P, H, pchunk;

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
                 a.gates[bt * GH + k] = r; a.gates[bt * GH + H + k] = z; a.gates[bt * GH + 2 * H + k] = n;
                 a.hn[bt * H + k] = hnv;
             }
+            if (a.drop_p > 0.f) hnew *= caphn_keep_scale(a.drop_seed, (unsigned long long)bt * H + k, a.drop_p, 1.0f / (1.0f - a.drop_p));
             a.Hprev[bt * H + k] = hp;
             a.Hs[bt * H + k] = hnew;
             a.uah[bt * H + k] = uah_s[k];
@@ -317,7 +318,8 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
         for (int p = tid; p < P; p += NT) al_s[p] = a.alphas[bt * P + p];
         // cell backward (pointwise), thread k
         for (int k = tid; k < H; k += NT) {
-            const float dh = dh_s[k] + a.dHs[bt * H + k];
+            float dh = dh_s[k] + a.dHs[bt * H + k];
+            if (a.drop_p > 0.f) dh *= caphn_keep_scale(a.drop_seed, (unsigned long long)bt * H + k, a.drop_p, 1.0f / (1.0f - a.drop_p));
             uah_s[k] = a.uah[bt * H + k];
             if (LSTM) {
                 const float gi = a.gates[bt * GH + k], gf = a.gates[bt * GH + H + k], gg = a.gates[bt * GH + 2 * H + k];

@@ -376,6 +376,7 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
                 a.gates[bt * GH + k] = r; a.gates[bt * GH + H + k] = z; a.gates[bt * GH + 2 * H + k] = n;
                 a.hn[bt * H + k] = hnv;
             }
+            if (a.drop_p > 0.f) hnew *= caphn_keep_scale(a.drop_seed, (unsigned long long)bt * H + k, a.drop_p, 1.0f / (1.0f - a.drop_p));
             a.Hprev[bt * H + k] = hp;
             a.Hs[bt * H + k] = hnew;
             a.uah[bt * H + k] = uah_s[kk];
@@ -522,7 +523,8 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
         // cell backward (pointwise) for my k
         for (int kk = tid; kk < nk; kk += NT) {
             const int k = k0 + kk;
-            const float dh = dh_s[kk] + (pfk ? pf[0] : a.dHs[bt * H + k]);
+            float dh = dh_s[kk] + (pfk ? pf[0] : a.dHs[bt * H + k]);
+            if (a.drop_p > 0.f) dh *= caphn_keep_scale(a.drop_seed, (unsigned long long)bt * H + k, a.drop_p, 1.0f / (1.0f - a.drop_p));
             uah_s[kk] = pfk ? pf[1] : a.uah[bt * H + k];
             if (LSTM) {
                 const float gi = pfk ? pf[2] : a.gates[bt * GH + k], gf = pfk ? pf[3] : a.gates[bt * GH + H + k];

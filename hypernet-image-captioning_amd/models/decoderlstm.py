@@ -70,15 +70,18 @@ class AttentionGru(nn.Module):
         """features [B,P,num_features], captions [B,T] -> (outputs [B,T,V], atten_weights [B,T,P])."""
         if self.layers:
             raise NotImplementedError("num_layers > 1 is not supported by the fused HIP path")
-        if self.training and self.drop.p > 0:
-            raise NotImplementedError("dropout p > 0 is not supported by the fused HIP path "
-                                      "(the hypernet path constructs AttentionGru with p=0.0)")
         B, P, D = features.shape
         if D != self.num_features:
             raise CaphnError(f"features have {D} channels, module expects {self.num_features}")
         dims = self.dec_dims(B, captions.shape[1], P)
         if sample_prob != 0.0:
+            if self.training and self.drop.p > 0:
+                raise NotImplementedError("free running / scheduled sampling with dropout active is not fused: call .eval()")
             return _sampled_forward(self, dims, features, captions, sample_prob)
+        if self.training and self.drop.p > 0:
+            # h = self.drop(h) (models/decoderlstm.py:104): counter-based mask, a fresh seed per call (the backward re-derives it)
+            import dataclasses
+            dims = dataclasses.replace(dims, drop_p=float(self.drop.p), seed=CF.next_seed())
         return CF.attention_gru_forward(dims, features, captions, self._named_tensors())
 
     def dec_dims(self, B, T, P):
@@ -185,15 +188,17 @@ class AttentionLstm(nn.Module):
     def forward(self, captions, features, sample_prob=1.0):
         """captions [B,T], features [B,P,num_features] -> (outputs [B,T,V], atten_weights [B,T,P]).
         NOTE the reference's argument order and its default sample_prob=1.0 (decoderlstm.py:224)."""
-        if self.training and self.drop.p > 0:
-            raise NotImplementedError("dropout p > 0 in training mode is not supported by the fused HIP path; "
-                                      "construct with p=0.0 or call .eval()")
         B, P, D = features.shape
         if D != self.num_features:
             raise CaphnError(f"features have {D} channels, module expects {self.num_features}")
         dims = self.dec_dims(B, captions.shape[1], P)
         if sample_prob != 0.0:
+            if self.training and self.drop.p > 0:
+                raise NotImplementedError("free running / scheduled sampling with dropout active is not fused: call .eval()")
             return _sampled_forward(self, dims, features, captions, sample_prob)
+        if self.training and self.drop.p > 0:       # h = self.drop(h) (models/decoderlstm.py:254), the reference default p = 0.5
+            import dataclasses
+            dims = dataclasses.replace(dims, drop_p=float(self.drop.p), seed=CF.next_seed())
         return CF.attention_gru_forward(dims, features, captions, self._named_tensors())
 
     def init_hidden(self, features):

@@ -191,6 +191,13 @@ typedef struct caphn_decoder_dims {
                            given captions, i.e. after the generated W_ih is final), 4 = embedding lookup + x-side gate
                            pre-activations (caphn_decoder_inputs, or that same call).  7: the forward starts at the
                            recurrent kernel */
+    float dropout_p;    /* h = self.drop(h) (models/decoderlstm.py:44,104; AttentionLstm :254) in TRAINING mode: every h_t is
+                           multiplied by keep / (1 - p) before it feeds fc, the next step's cell and the next step's attention.
+                           0 = off (eval mode, or p = 0 as the hypernet path constructs its decoder).  The keep decision of
+                           element (b, t, k) is caphn_dropout_f32's counter-based hash of (dropout_seed, (b T + t) H + k) -- NOT
+                           torch's Philox stream: masks differ from the reference's, parity is pinned with dropout off and,
+                           with it on, against the oracle given this mask.  The backward needs the same p and seed. */
+    unsigned long long dropout_seed;
 } caphn_decoder_dims;
 
 typedef struct caphn_decoder_params {   /* reference state_dict names in comments */

@@ -235,7 +235,8 @@ def lstm_cell(x: Tensor, h: Tensor, c: Tensor, w: Dict[str, Tensor]) -> Tuple[Te
 def decoder_forward(dims: Dims, p: Dict[str, Tensor], cellw: Dict[str, Tensor],
                     features: Tensor, captions: Tensor,
                     use_sampling: Optional[Sequence[bool]] = None,
-                    sample_temp: float = 0.5, use_feature_fc: bool = True) -> Tuple[Tensor, Tensor]:
+                    sample_temp: float = 0.5, use_feature_fc: bool = True,
+                    drop_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """AttentionGru.forward, models/decoderlstm.py:49-120 (cell == 'gru'), or the
     same loop around an LSTMCell behind the same feature_fc (cell == 'lstm'; the
     build's hypernet-LSTM configuration).
@@ -279,6 +280,8 @@ def decoder_forward(dims: Dims, p: Dict[str, Tensor], cellw: Dict[str, Tensor],
             h = gru_cell(xin, h, cellw)                                  # :100
         else:
             h, c = lstm_cell(xin, h, c, cellw)
+        if drop_mask is not None:                                        # h = self.drop(h), :104 -- the dropped h also
+            h = h * drop_mask[:, t]                                      # is the next step's hidden state; mask = keep / (1 - p)
         output = F_.linear(h, p["captioner.fc.weight"], p["captioner.fc.bias"])  # :105
         if samp and dims.cell == "lstm":                                 # :247-251
             top = torch.argmax(F_.log_softmax(output / sample_temp, dim=1), dim=1)
@@ -575,7 +578,8 @@ def frontend_forward(p: Dict[str, Tensor], mode: str, inp) -> Tensor:
 
 def forward_backward(dims: Dims, p: Dict[str, Tensor], x_style: Tensor, features: Tensor,
                      captions: Tensor, style_token: Optional[int] = None,
-                     detach_theta: bool = False, frontend: Optional[Tuple[str, object]] = None):
+                     detach_theta: bool = False, frontend: Optional[Tuple[str, object]] = None,
+                     drop_mask: Optional[Tensor] = None, use_sampling: Optional[Sequence[bool]] = None):
     """One forward + backward.  Returns (loss, logits, alphas, theta, grads) where
     grads holds (i) the literal quantities the reference's autograd yields -- grads
     of the non-generated captioner parameters and 'dtheta' = cat of the leaf grads of
@@ -594,7 +598,7 @@ def forward_backward(dims: Dims, p: Dict[str, Tensor], x_style: Tensor, features
     theta = hyper_forward(q, x)
     theta_leaf = theta.detach().clone().requires_grad_(True)             # utils.py:57
     cellw = split_theta(dims, theta_leaf)
-    logits, alphas = decoder_forward(dims, q, cellw, features, captions)
+    logits, alphas = decoder_forward(dims, q, cellw, features, captions, drop_mask=drop_mask, use_sampling=use_sampling)
     loss = caption_loss(logits, captions)
     loss.backward()
     dtheta = theta_leaf.grad.detach().clone()
