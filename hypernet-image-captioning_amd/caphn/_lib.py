@@ -115,6 +115,8 @@ SIGNATURES = {
     "caphn_decoder_prepare_rows": (C.c_int, [C.POINTER(DecoderDims), c_fp, C.c_int64, c_fp, c_fp]),
     "caphn_decoder_forward_sampled": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
                                                 C.c_char_p, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_decoder_forward_sampled_train": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
+                                                      C.c_char_p, c_fp, c_fp, c_fp, c_fp]),
     "caphn_decoder_backward": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
                                          c_fp, c_fp, C.POINTER(DecoderGrads), c_fp, c_fp]),
     "caphn_decoder_hyper_backward": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,

@@ -42,6 +42,48 @@ class _DecoderFn(torch.autograd.Function):
         return (None, None, None) + tuple(grads[n] for n in dims.names())
 
 
+class _DecoderSampledFn(torch.autograd.Function):
+    """AttentionGru / AttentionLstm forward with scheduled sampling (models/decoderlstm.py:78-96, :236-251) as a trainable
+    node: the argmax feedback is not differentiable, so the backward is the teacher-forced one over the token ids the
+    forward actually fed (kept in the workspace)."""
+
+    @staticmethod
+    def forward(ctx, dims, flags, features, captions, *tensors):
+        if features.requires_grad:
+            raise NotImplementedError("no gradient flows to the encoder's feature map (frozen encoder, models/encoder.py:11-13)")
+        params = {n: t.detach().contiguous() for n, t in zip(dims.names(), tensors)}
+        features = features.detach().contiguous()
+        captions = captions.contiguous()
+        ws = ops.decoder_workspace(dims, features.device)
+        logits, alphas = ops.decoder_forward_sampled(dims, params, features, captions, flags, ws, keep_state=True)
+        ctx.save_for_backward(features, captions, *tensors)
+        ctx.dims, ctx.ws = dims, ws
+        return logits, alphas
+
+    @staticmethod
+    def backward(ctx, dlogits, dalphas):
+        dims = ctx.dims
+        features, captions, *tensors = ctx.saved_tensors
+        params = {n: t.detach().contiguous() for n, t in zip(dims.names(), tensors)}
+        dev = features.device
+        if dlogits is None:
+            dlogits = torch.zeros(dims.B, dims.T, dims.V, device=dev)
+        grads = {n: torch.empty(s, dtype=torch.float32, device=dev) for n, s in dims.param_shapes().items()}
+        ops.decoder_backward(dims, params, features, captions, dlogits.contiguous(), grads, ctx.ws,
+                             dalphas.contiguous() if dalphas is not None else None)
+        ctx.ws = None
+        return (None, None, None, None) + tuple(grads[n] for n in dims.names())
+
+
+def attention_sampled_forward(dims: ops.DecDims, flags, features: torch.Tensor, captions: torch.Tensor,
+                              named: Dict[str, torch.Tensor]):
+    if not features.is_cuda:
+        raise CaphnError("libcaphn's HIP kernels need CUDA(HIP) tensors (there is no CPU fallback)")
+    if bool((captions < 0).any()) or bool((captions >= dims.V).any()):
+        raise IndexError("caption token id out of range")
+    return _DecoderSampledFn.apply(dims, list(flags), features.float(), captions.long(), *[named[n] for n in dims.names()])
+
+
 def attention_gru_forward(dims: ops.DecDims, features: torch.Tensor, captions: torch.Tensor,
                           named: Dict[str, torch.Tensor]):
     if not features.is_cuda:

@@ -430,9 +430,10 @@ def decoder_prepare_rows(dims: DecDims, targets: torch.Tensor, ignore_index: int
 
 
 def decoder_forward_sampled(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor,
-                            captions: torch.Tensor, use_sampling: Sequence[bool], ws: torch.Tensor):
-    """Free-running / scheduled-sampling forward (models/decoderlstm.py:78-96, :236-251); forward only.
-    use_sampling[t] is the per-step draw ``np.random.random() < sample_prob`` (entry 0 ignored)."""
+                            captions: torch.Tensor, use_sampling: Sequence[bool], ws: torch.Tensor, keep_state: bool = False):
+    """Free-running / scheduled-sampling forward (models/decoderlstm.py:78-96, :236-251).
+    use_sampling[t] is the per-step draw ``np.random.random() < sample_prob`` (entry 0 ignored).
+    keep_state=True keeps what decoder_backward needs in ws (training through scheduled sampling)."""
     lib = L.load()
     if tuple(features.shape) != (dims.B, dims.P, dims.D) or tuple(captions.shape) != (dims.B, dims.T):
         raise L.CaphnError(f"features {tuple(features.shape)} / captions {tuple(captions.shape)} do not match {dims}")
@@ -446,9 +447,10 @@ def decoder_forward_sampled(dims: DecDims, params: Dict[str, torch.Tensor], feat
     logits = _f32(dims.B, dims.T, dims.V, device=dev)
     alphas = _f32(dims.B, dims.T, dims.P, device=dev)
     flags = bytes(1 if bool(x) else 0 for x in use_sampling)
-    L.check(lib.caphn_decoder_forward_sampled(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64),
-                                              flags, L.ptr(logits), L.ptr(alphas), C.c_void_p(ws.data_ptr()),
-                                              L.stream_ptr()), "caphn_decoder_forward_sampled")
+    fn = lib.caphn_decoder_forward_sampled_train if keep_state else lib.caphn_decoder_forward_sampled
+    L.check(fn(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64), flags, L.ptr(logits), L.ptr(alphas),
+               C.c_void_p(ws.data_ptr()), L.stream_ptr()),
+            "caphn_decoder_forward_sampled_train" if keep_state else "caphn_decoder_forward_sampled")
     return logits, alphas
 
 

@@ -310,10 +310,11 @@ static int decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_p
 // 2 -> argmax_v logits[b, col, v] (lowest index on ties)
 __global__ __launch_bounds__(256) void next_token_kernel(int B, int T, int V, int mode, int col,
                                                          const int64_t* __restrict__ caps, const float* __restrict__ logits,
-                                                         int64_t* __restrict__ idx) {
+                                                         int64_t* __restrict__ idx_out, int ostride) {
     __shared__ float bv[4];
     __shared__ int bi[4];
     const int b = blockIdx.x, tid = threadIdx.x;
+    int64_t* idx = idx_out + (size_t)b * ostride - b;          // idx[b] below lands on idx_out[b * ostride]
     if (mode == 0) { if (tid == 0) idx[b] = -1; return; }
     if (mode == 1) { if (tid == 0) idx[b] = caps[(size_t)b * T + col]; return; }
     const float* row = logits + ((size_t)b * T + col) * V;
@@ -669,7 +670,7 @@ extern "C" int caphn_decoder_forward_sampled(const caphn_decoder_dims* d, const 
         } else if (!lstm) {
             src_mode = 2; src_col = t - 1;              // GRU: argmax of the previous output, taken now
         }                                               // LSTM: keep what the previous iteration left
-        hipLaunchKernelGGL(next_token_kernel, dim3(B), dim3(256), 0, s, B, T, V, src_mode, src_col, captions, logits, idx);
+        hipLaunchKernelGGL(next_token_kernel, dim3(B), dim3(256), 0, s, B, T, V, src_mode, src_col, captions, logits, idx, 1);
         RUN(caphn_embedding_gather(B, E, p->embed_w, idx, ws + w.Xe, s));
         RUN(caphn_gemm_f32(0, 1, B, GH, E, ws + w.Xe, E, p->w_ih, EF, ws + w.Xg, GH, p->b_ih, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
         RecFwdArgs a;
@@ -691,6 +692,67 @@ extern "C" int caphn_decoder_forward_sampled(const caphn_decoder_dims* d, const 
                                  sizeof(float) * P, B, hipMemcpyDeviceToDevice, s) != hipSuccess) return CAPHN_ELAUNCH;
         if (samp && lstm) { src_mode = 2; src_col = t; }    // :247-251: sampled embedding of THIS output, used later
     }
+    return caphn_launch_status();
+}
+
+// The same forward KEEPING the backward state (training with sample_prob > 0: train_gru.py:84 calls the captioner with 1.0
+// inside training_step; cc_train_hypernet.py trains with 0.0).  The argmax is not differentiable, so autograd's graph of the
+// reference is the teacher-forced one with the sampled token ids in place of the caption's: the recurrent kernel runs one
+// time-step window per launch on the [B, T] workspace layout, the sampled ids are kept in the workspace's idx array (the
+// backward scatters d x_t into THEIR embedding rows), and caphn_decoder_backward applies unchanged.
+extern "C" int caphn_decoder_forward_sampled_train(const caphn_decoder_dims* d, const caphn_decoder_params* p,
+                                                   const float* features, const int64_t* captions,
+                                                   const unsigned char* use_sampling,
+                                                   float* logits, float* alphas, void* ws_, caphn_stream_t stream) {
+    if (!dims_ok(d) || !p || !features || !captions || !use_sampling || !logits || !ws_) return CAPHN_EINVAL;
+    if (d->row_subset || d->precomputed) return CAPHN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = layout(d);
+    float* ws = static_cast<float*>(ws_);
+    const int B = d->B, T = d->T, P = d->P, E = d->E, F = d->F, H = d->H, V = d->V;
+    const bool lstm = d->cell == CAPHN_CELL_LSTM;
+    const int GH = w.NG * H, EF = E + F;
+    const bool pair = use_pair(d);
+    const int RG = pair ? caphn_rec_pair_resident_gates(P, H, w.NG) : caphn_rec_resident_gates(P, H, w.NG);
+    if (RG < 0) return CAPHN_ELIMIT;
+    if (lstm && (!p->initc_w || !p->initc_b)) return CAPHN_EINVAL;
+    const float* f = nullptr;
+    RUN(decoder_precompute(d, p, w, ws, features, &f, s));
+    int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
+    RecFwdArgs a;
+    a.B = B; a.T = T; a.P = P; a.H = H; a.RG = RG;
+    a.Waf = ws + w.Waf; a.G = ws + w.G; a.Xg = ws + w.Xg; a.h0 = ws + w.h0; a.c0 = ws + w.c0;
+    a.W_hh = p->w_hh; a.b_hh = p->b_hh; a.U_a = p->Ua_w; a.b_Ua = p->Ua_b; a.v_a = p->va_w; a.b_va = p->va_b;
+    a.Hs = ws + w.Hs; a.Hprev = ws + w.Hprev; a.alphas = ws + w.alphas; a.gates = ws + w.gates; a.hn = ws + w.hn;
+    a.Cs = ws + w.Cs; a.Cprev = ws + w.Cprev; a.uah = ws + w.uah;
+    a.vecW = (H % 4 == 0) && caphn_aligned16(p->w_hh) && caphn_aligned16(p->Ua_w);
+    a.vecS = (H % 4 == 0) && caphn_aligned16(ws);
+    a.prof = nullptr; a.rotate = 0;
+    a.drop_p = d->dropout_p; a.drop_seed = d->dropout_seed;
+    if (pair) {
+        a.xch = reinterpret_cast<unsigned long long*>(ws + w.xch);
+        a.WP = ws + w.wp; a.wp_pitch = caphn_rec_pair_pitch(H);
+        RUN(caphn_launch_rec_pair_prep(a.xch, 2 * w.xch_floats * sizeof(float) / sizeof(unsigned long long), p->Ua_w, p->w_hh, H, w.NG,
+                                       ws + w.wp, s));
+    }
+    int src_mode = 0, src_col = 0;
+    for (int t = 0; t < T; ++t) {
+        const bool samp = t > 0 && use_sampling[t] != 0;
+        if (!samp) { if (t < 2) { src_mode = 0; } else { src_mode = 1; src_col = t - 1; } }
+        else if (!lstm) { src_mode = 2; src_col = t - 1; }
+        // x_t: token id -> idx[b, t] -> Xe[b, t, :] -> x-side gate pre-activations of step t
+        hipLaunchKernelGGL(next_token_kernel, dim3(B), dim3(256), 0, s, B, T, V, src_mode, src_col, captions, logits, idx + t, T);
+        RUN(caphn_embedding_gather_strided(B, E, p->embed_w, idx + t, T, ws + w.Xe + (size_t)t * E, T * E, s));
+        RUN(caphn_gemm_f32(0, 1, B, GH, E, ws + w.Xe + (size_t)t * E, T * E, p->w_ih, EF, ws + w.Xg + (size_t)t * GH, T * GH, p->b_ih,
+                           nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+        a.t0 = t; a.t1 = t + 1;
+        if (pair) RUN(caphn_launch_rec_pair_fwd(a, lstm, s)); else RUN(caphn_launch_rec_fwd(a, lstm, s));
+        RUN(caphn_gemm_f32(0, 1, B, V, H, ws + w.Hs + (size_t)t * H, T * H, p->out_w, H, logits + (size_t)t * V, T * V, p->out_b, nullptr, 0,
+                           CAPHN_GEMM_BIAS, 1, s));
+        if (samp && lstm) { src_mode = 2; src_col = t; }
+    }
+    if (alphas)
+        if (hipMemcpyAsync(alphas, ws + w.alphas, sizeof(float) * (size_t)B * T * P, hipMemcpyDeviceToDevice, s) != hipSuccess) return CAPHN_ELAUNCH;
     return caphn_launch_status();
 }
 

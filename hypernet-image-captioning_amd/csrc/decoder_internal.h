@@ -83,6 +83,7 @@ int caphn_launch_df(int B, int T, int P, int F, const float* alphas, const float
 int caphn_launch_dmean(int B, int H, int F, const float* dh0, const float* Wh, const float* dc0, const float* Wc, float* out, hipStream_t s);
 int caphn_launch_init_state(int B, int P, int F, int H, const float* f, const float* Wh, const float* bh, const float* Wc,
                             const float* bc, float* meanf, float* h0, float* c0, hipStream_t s);
+int caphn_embedding_gather_strided(int rows, int E, const float* table, const int64_t* idx, int istride, float* out, int ostride, hipStream_t s);
 int caphn_launch_mean_p(int B, int P, int F, const float* f, float* out, hipStream_t s);
 
 // Beam / greedy search state (search.hip); all pointers are device memory inside the caller's search workspace.

@@ -227,6 +227,13 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(int rows, int E, cons
     const int64_t id = idx[r];
     for (int e = threadIdx.x; e < E; e += 256) out[(size_t)r * E + e] = id < 0 ? 0.f : table[(size_t)id * E + e];
 }
+// out[r * ostride ...] = table[idx[r * istride]] (one time step's column of a [B, T] layout)
+__global__ __launch_bounds__(256) void embed_gather_strided_kernel(int rows, int E, const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                                                   int istride, float* __restrict__ out, int ostride) {
+    const int r = blockIdx.x;
+    const int64_t id = idx[(size_t)r * istride];
+    for (int e = threadIdx.x; e < E; e += 256) out[(size_t)r * ostride + e] = id < 0 ? 0.f : table[(size_t)id * E + e];
+}
 __global__ __launch_bounds__(256) void embed_scatter_kernel(int rows, int E, const float* __restrict__ g, const int64_t* __restrict__ idx, float* __restrict__ tg) {
     const int r = blockIdx.x;
     const int64_t id = idx[r];
@@ -729,6 +736,11 @@ extern "C" int caphn_axpy_f32(size_t n, float alpha, const float* x, float* y, c
 extern "C" int caphn_embedding_gather(int rows, int E, const float* table, const int64_t* idx, float* out, caphn_stream_t stream) {
     if (rows <= 0 || E <= 0 || !table || !idx || !out) return CAPHN_EINVAL;
     hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), rows, E, table, idx, out);
+    return caphn_launch_status();
+}
+int caphn_embedding_gather_strided(int rows, int E, const float* table, const int64_t* idx, int istride, float* out, int ostride, hipStream_t s) {
+    if (rows <= 0 || E <= 0 || !table || !idx || !out) return CAPHN_EINVAL;
+    hipLaunchKernelGGL(embed_gather_strided_kernel, dim3(rows), dim3(256), 0, s, rows, E, table, idx, istride, out, ostride);
     return caphn_launch_status();
 }
 extern "C" int caphn_embedding_scatter_add(int rows, int E, const float* g, const int64_t* idx, float* table_grad, caphn_stream_t stream) {

@@ -119,9 +119,12 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
     const int sb = a.slab_div > 1 ? b / a.slab_div : b;
     const float* Gb = a.G + (size_t)sb * P * GH;
     load_G_resident(G_s, Gb, P, GH, RGH, a.vecS, tid);
+    // time-step window [t0, t1) of this launch (t1 == 0: all T steps); t0 > 0 continues from the saved h_{t0-1} (c_{t0-1})
+    const int t0 = a.t0, t1 = a.t1 > 0 ? a.t1 : a.T;
     for (int k = tid; k < H; k += NT) {
-        h_s[k] = a.h0[(size_t)b * H + k]; va_s[k] = a.v_a[k];
-        c_s[k] = LSTM ? a.c0[(size_t)b * H + k] : 0.f;
+        h_s[k] = t0 == 0 ? a.h0[(size_t)b * H + k] : a.Hs[((size_t)b * T + t0 - 1) * H + k];
+        va_s[k] = a.v_a[k];
+        c_s[k] = LSTM ? (t0 == 0 ? a.c0[(size_t)b * H + k] : a.Cs[((size_t)b * T + t0 - 1) * H + k]) : 0.f;
     }
     const float bva = a.b_va[0];
     const float* Waf_b = a.Waf + (size_t)sb * P * H;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
     __syncthreads();
     PDECL;
 
-    for (int t = 0; t < T; ++t) {
+    for (int t = t0; t < t1; ++t) {
         const size_t bt = (size_t)b * T + t;
         // A: U_a h + b_Ua -> uah_s ; W_hh h + b_hh -> gh_s   (W_hh, U_a streamed from L2)
         matvec_rows(a.U_a, a.b_Ua, h_s, uah_s, H, H, a.vecW, tid, rotU);

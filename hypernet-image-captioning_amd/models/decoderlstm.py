@@ -16,14 +16,15 @@ from .attention import BahdanauAttention
 def _sampled_forward(module, dims, features, captions, sample_prob):
     """Scheduled sampling / free running (models/decoderlstm.py:78-96, :236-251).  The per-timestep
     draws consume numpy's global RNG exactly like the reference: one np.random.random() per step, compared
-    with 0.0 at t = 0 and with sample_prob afterwards.  Forward only (validation / inference)."""
+    with 0.0 at t = 0 and with sample_prob afterwards.  Under torch.no_grad() (validation_step,
+    cc_train_hypernet.py:187-188) nothing is kept; with gradients enabled (train_gru.py:84 trains through
+    sample_prob = 1.0) the forward keeps the backward state and the node is differentiable."""
     flags = [bool(np.random.random() < (0.0 if t == 0 else sample_prob)) for t in range(dims.T)]
     if not features.is_cuda:
         raise CaphnError("libcaphn's HIP kernels need CUDA(HIP) tensors (there is no CPU fallback)")
     named = module._named_tensors()
     if torch.is_grad_enabled() and any(t.requires_grad for t in named.values()):
-        raise NotImplementedError("the free-running / scheduled-sampling path is forward only: call it under "
-                                  "torch.no_grad() (validation_step does, cc_train_hypernet.py:187-188)")
+        return CF.attention_sampled_forward(dims, flags, features, captions, named)
     params = {n: named[n].detach().contiguous().float() for n in dims.names()}
     ws = ops.decoder_workspace(dims, features.device)
     return ops.decoder_forward_sampled(dims, params, features.detach().float().contiguous(),

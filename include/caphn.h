@@ -261,6 +261,14 @@ int caphn_decoder_forward_sampled(const caphn_decoder_dims* d, const caphn_decod
                                   const float* features, const int64_t* captions,
                                   const unsigned char* use_sampling,
                                   float* logits, float* alphas, void* ws, caphn_stream_t stream);
+/* The same forward KEEPING the state caphn_decoder_backward needs: training through scheduled sampling (train_gru.py:84 calls
+ * the captioner with sample_prob 1.0 inside training_step).  The argmax feedback is not differentiable, so the gradient is
+ * the teacher-forced one with the sampled token ids in place of the caption's (their embedding rows receive d x_t);
+ * caphn_decoder_backward on the same dims / workspace follows.  row_subset and precomputed must be 0. */
+int caphn_decoder_forward_sampled_train(const caphn_decoder_dims* d, const caphn_decoder_params* p,
+                                        const float* features, const int64_t* captions,
+                                        const unsigned char* use_sampling,
+                                        float* logits, float* alphas, void* ws, caphn_stream_t stream);
 /* dlogits [B,T,V] (may be overwritten) -> parameter gradients.  ws must be the workspace the
  * matching forward filled.  dalphas (gradient w.r.t. the returned attention weights) may be NULL. */
 int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_decoder_params* p,

@@ -102,3 +102,36 @@ def test_grunet_validation_step_pattern():
     rb, _ = O.decoder_forward(dims, p, cellw, feats, caps, use_sampling=[True] * 9)
     assert maxdiff(a.cpu(), ra) < 5e-6
     assert maxdiff(b.cpu(), rb) < 2e-5 and torch.equal(b.cpu().argmax(-1), rb.argmax(-1))
+
+
+@pytest.mark.parametrize("T", [9, 12])
+def test_grunet_literal_training_step_trains_through_the_sampled_call(T):
+    """train_gru.py:84-86 as written: BOTH calls inside training_step carry gradients --
+        loss = 0.5 * CE(captioner(feats, caps, 1.0)) + 0.5 * CE(captioner(feats, caps, 0.0))
+    The 1.0 call feeds back argmax(output / 0.5) at every step t >= 1; the argmax is not differentiable, so its gradient is
+    the teacher-forced one over the sampled ids.  Against the oracle's autograd through the same loop."""
+    net, dims = _build(seed=3)
+    p, cellw = _oracle_view(net)
+    batch = O.synth_batch(dims, B=8, T=T, P=49, seed=8)
+    feats, caps = batch["features"], batch["captions"]
+    net = net.to(DEV).train()
+    tf = 0.5                                                                         # self.teacher_forcing_proba, :40
+    a = net(feats.to(DEV), caps.to(DEV).long(), 1.0)
+    b = net(feats.to(DEV), caps.to(DEV).long(), 0.0)
+    loss = tf * F.cross_entropy(a.view(-1, dims.V), caps.to(DEV).view(-1), ignore_index=0) + \
+        (1 - tf) * F.cross_entropy(b.view(-1, dims.V), caps.to(DEV).view(-1), ignore_index=0)
+    loss.backward()
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    cw = {k: v.clone().requires_grad_(True) for k, v in cellw.items()}
+    ra, _ = O.decoder_forward(dims, q, cw, feats, caps, use_sampling=[True] * T)
+    rb, _ = O.decoder_forward(dims, q, cw, feats, caps)
+    rl = tf * O.caption_loss(ra, caps) + (1 - tf) * O.caption_loss(rb, caps)
+    rl.backward()
+    assert torch.equal(a.detach().cpu().argmax(-1), ra.detach().argmax(-1))            # the sampled trajectories coincide
+    assert maxdiff(a.detach().cpu(), ra.detach()) < 2e-5 and maxdiff(b.detach().cpu(), rb.detach()) < 5e-6
+    assert abs(float(loss) - float(rl)) < 5e-6
+    got = dict(net.named_parameters())
+    for k, v in q.items():
+        assert maxdiff(got[k[len("captioner."):]].grad.cpu(), v.grad) < 1e-5, k
+    for k, v in cw.items():
+        assert maxdiff(got["gru." + k].grad.cpu(), v.grad) < 1e-5, k

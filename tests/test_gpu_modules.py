@@ -96,8 +96,8 @@ def test_module_errors():
     with pytest.raises(CaphnError):
         m(torch.zeros(2, 7, 32), torch.zeros(2, 5, dtype=torch.long))       # CPU tensors: no fallback
     m = m.to(DEV)
-    with pytest.raises(NotImplementedError):      # sampling path is forward-only: needs no_grad
-        m(torch.zeros(2, 7, 32, device=DEV), torch.zeros(2, 5, dtype=torch.long, device=DEV), 1.0)
+    out, _ = m(torch.zeros(2, 7, 32, device=DEV), torch.zeros(2, 5, dtype=torch.long, device=DEV), 1.0)
+    assert out.requires_grad                     # the sampling path is a differentiable node (train_gru.py:84 trains through it)
     with pytest.raises(CaphnError):
         m(torch.zeros(2, 7, 31, device=DEV), torch.zeros(2, 5, dtype=torch.long, device=DEV))
     with pytest.raises(IndexError):
@@ -222,8 +222,8 @@ def test_hypernet_lstm_module_and_engine():
         if k == "dtheta" or v is None:
             continue
         assert maxdiff(sd[k.replace("captioner.embed.", "captioner.embeddings.")].grad.cpu(), v) < 3e-6, k
-    with pytest.raises(NotImplementedError):
-        cap(caps, feats)                                     # the reference default sample_prob=1.0
+    lf, _ = cap(caps, feats)                                 # the reference default sample_prob=1.0 (free running)
+    assert lf.shape == logits.shape and lf.requires_grad
     tr = FusedTrainer(build(), lr=1e-3)
     l = tr.forward_backward(feats, caps, x_style=x.to(DEV), validate=True)
     assert abs(float(l[0]) - float(loss_ref)) < 3e-6
