@@ -177,6 +177,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cell", choices=["gru", "lstm"], default="gru",
                     help="gru: the metric's workload; lstm: BASELINE config 3 (hypernet-generated LSTMCell, side measurement)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: the metric's arithmetic (the reference trains with precision=32).  bf16: SIDE measurement, never the "
+                         "headline -- every dense contraction as one bf16 MFMA product on operands rounded to bf16, fp32 accumulate; "
+                         "recurrent kernels, softmax, loss, Adam and master weights stay fp32 (caphn_tune key 11)")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not tell the optimiser pass the next minibatch's style (disables the fused next-theta GEMV)")
@@ -235,6 +239,8 @@ def main():
     for kv in args.tune:
         k, v = kv.split("=")
         assert _lib.load().caphn_tune(int(k), int(v)) == 0
+    if args.dtype == "bf16":
+        assert _lib.load().caphn_tune(11, 1) == 0
 
     B, T, P, D, F, E, H, V = args.batch, 20, 49, 2048, 200, 200, 200, 9684
     torch.manual_seed(1234)                       # identical replicas on every rank
@@ -411,10 +417,11 @@ def main():
         line = {
             "metric": METRIC, "value": B * world * args.steps / dt, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" + (" (each minibatch copied from pinned host memory inside the timed region)" if args.from_host else ""),
             "config": {"workload": f"Flickr30k-shaped {args.cell.upper()}+additive-attention decoder + hypernet (3 style domains), "
-                                   "full training step (fwd, CE, bwd, clip 5.0, Adam)",
+                                   "full training step (fwd, CE, bwd, clip 5.0, Adam)" +
+                                   (" -- SIDE MEASUREMENT: single-product bf16 contractions, not the metric's fp32 arithmetic" if args.dtype == "bf16" else ""),
                        "per_gpu_batch": B, "global_batch": B * world, "T": T, "P": P, "D": D, "F": F, "E": E, "H": H,
                        "V": V, "hypernet_params": int(sum(q.numel() for q in net.hn_base.parameters()) +
                                                       sum(q.numel() for q in net.hn_heads.parameters())),

@@ -110,6 +110,17 @@ struct TileS {
     // unsound: the register allocator may COPY a register set between the load and the wait -- it did, at the loop's
     // back edge -- reading registers whose loads are still in flight.  The failure is intermittent.)
     __device__ static __forceinline__ void issue(f32x4& r, const float* p) { r = *reinterpret_cast<const f32x4*>(p); }
+    // reduced-precision side mode: one plane, operands rounded to bf16 (v_cvt_pk_bf16_f32, round to nearest even)
+    __device__ static __forceinline__ void store_single(const f32x4 (&r)[NV], __bf16* __restrict__ S, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            const bf16x4 v = {(__bf16)r[i][0], (__bf16)r[i][1], (__bf16)r[i][2], (__bf16)r[i][3]};
+            __bf16* p = KC ? S + (idx >> 3) * PITCH + (idx & 7) * 4
+                           : S + (idx / (BMN / 4)) * PITCHM + (idx % (BMN / 4)) * 4;
+            *reinterpret_cast<bf16x4*>(p) = v;
+        }
+    }
     __device__ static __forceinline__ void store(const f32x4 (&r)[NV], __bf16* __restrict__ S, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -200,8 +211,14 @@ struct TileS {
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
-template <int BM, int BN, bool TA, bool TB, bool PL>
+// MODE 0: fp32 operands split into three planes on every use of a tile, six products (fp32-class accuracy; the default)
+// MODE 1: pre-split operands (GemmArgs::Ap / Bp), six products
+// MODE 2: ONE product on operands rounded to bf16 (round to nearest even) at staging -- the reduced-precision side mode
+//         (caphn_tune key 11; never the default, never the headline measurement)
+template <int BM, int BN, bool TA, bool TB, int MODE>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
+    constexpr bool PL = MODE == 1;
+    constexpr bool SINGLE = MODE == 2;
     using TileA = TileS<BM, !TA>;
     using TileB = TileS<BN, TB>;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -285,15 +302,23 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (ks < nks) {
+                constexpr int NPL = SINGLE ? 1 : 3;
                 bf16x8 fa[TM][3], fb[TN][3];
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) fa[a][p] = TileA::frag(As, p, wm * WM + a * 32, ks, lane);
+                    for (int p = 0; p < NPL; ++p) fa[a][p] = TileA::frag(As, p, wm * WM + a * 32, ks, lane);
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) fb[b][p] = TileB::frag(Bs, p, wn * WN + b * 32, ks, lane);
+                    for (int p = 0; p < NPL; ++p) fb[b][p] = TileB::frag(Bs, p, wn * WN + b * 32, ks, lane);
+                if constexpr (SINGLE) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+                } else
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -339,8 +364,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                 for (int i = 0; i < TileA::NV; ++i) csum += ra[i];
             }
         }
-        TileA::store(ra, As, tid);
-        TileB::store(rb, Bs, tid);
+        if constexpr (SINGLE) { TileA::store_single(ra, As, tid); TileB::store_single(rb, Bs, tid); }
+        else { TileA::store(ra, As, tid); TileB::store(rb, Bs, tid); }
     };
     auto mainloop = [&](auto fc) {
         // In the branch-free path the look-ahead loads are issued UNCONDITIONALLY (slab index clamped to the last one,
@@ -493,7 +518,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool PL>
+template <int BM, int BN, bool TA, bool TB, int PL>
 int launch_one(const GemmArgs& g, hipStream_t s) {
     using TileA = TileS<BM, !TA>;
     using TileB = TileS<BN, TB>;
@@ -510,18 +535,19 @@ int launch_one(const GemmArgs& g, hipStream_t s) {
     hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, PL>), grid, dim3(256), lds, s, g);
     return caphn_launch_status();
 }
-template <int BM, int BN, bool PL>
+template <int BM, int BN, int PL>
 int launch_cfg(const GemmArgs& g, int ta, int tb, hipStream_t s) {
     if (!ta && tb) return launch_one<BM, BN, false, true, PL>(g, s);
     if (!ta && !tb) return launch_one<BM, BN, false, false, PL>(g, s);
     if (ta && !tb) return launch_one<BM, BN, true, false, PL>(g, s);
-    if constexpr (PL) return CAPHN_EINVAL;      // TT is never pre-split (no caller)
-    else return launch_one<BM, BN, true, true, false>(g, s);
+    if constexpr (PL != 0) return CAPHN_EINVAL;      // TT is never pre-split / reduced (no caller)
+    else return launch_one<BM, BN, true, true, 0>(g, s);
 }
 
 }  // namespace
 
 extern int g_tune_gemm_planes;
+int g_tune_gemm_single = 0;   // 1: reduced-precision side mode -- one bf16 product per contraction instead of six (caphn_tune key 11)
 int g_tune_gemm_xcd = 1;      // 1 (default): XCD-aware tile order
 int g_tune_gemm_fast = 1;     // 1 (default): branch-free loads (static vmcnt) where alignment allows
 // Tile choice: 128x128 when that alone gives >= 512 workgroups, else 64x64 (five workgroups per CU).  Measured and
@@ -552,11 +578,15 @@ int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.splitk;
     const bool pl = caphn_gemm_planes_ok(g, ta, tb);
     if (pl) {
-        if (tiles128 >= 512) return launch_cfg<128, 128, true>(g, ta, tb, s);
-        return launch_cfg<64, 64, true>(g, ta, tb, s);
+        if (tiles128 >= 512) return launch_cfg<128, 128, 1>(g, ta, tb, s);
+        return launch_cfg<64, 64, 1>(g, ta, tb, s);
     }
-    if (tiles128 >= 512) return launch_cfg<128, 128, false>(g, ta, tb, s);
-    return launch_cfg<64, 64, false>(g, ta, tb, s);
+    if (g_tune_gemm_single && !(ta && tb)) {
+        if (tiles128 >= 512) return launch_cfg<128, 128, 2>(g, ta, tb, s);
+        return launch_cfg<64, 64, 2>(g, ta, tb, s);
+    }
+    if (tiles128 >= 512) return launch_cfg<128, 128, 0>(g, ta, tb, s);
+    return launch_cfg<64, 64, 0>(g, ta, tb, s);
 }
 
 // ---------------------------------------------------------------------------------------------- operand splitting

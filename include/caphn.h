@@ -449,7 +449,9 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * (key 0: forward-GEMV variant, key 1: rank-Adam variant, key 2: GEMM back end -- 0 fp32 MFMA, 1 split-bf16 MFMA,
  * key 3: row rotation in the recurrent kernels, key 4: side-stream forking of the decoder composites, key 6: XCD-aware
  * GEMM tile order, key 7: branch-free GEMM loads, key 8: pre-split GEMM operands -- 0 off (every tile split on use), 1 on, key 9: recurrent kernels with two workgroups
- * per caption -- 0 off, 1 on).  Defaults are the measured-fastest. */
+ * per caption -- 0 off, 1 on, key 10: timing experiments only, key 11: REDUCED-PRECISION side mode -- 1 = every dense
+ * contraction as ONE bf16 product (operands rounded to bf16 at staging, fp32 accumulate; recurrent kernels, softmax, loss,
+ * Adam and the master weights stay fp32), 0 = the fp32-class six-product default).  Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
 /* ---------------------------------------------------------------------------------------
