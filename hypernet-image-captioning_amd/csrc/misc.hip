@@ -138,7 +138,15 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(int rows, const float* _
                                                         const int* __restrict__ nvi, float* out) {
     __shared__ double red[4];
     double s = 0.0;
-    for (int i = threadIdx.x; i < rows; i += 256) s += (double)row_loss[i];
+    // all of a thread's loads are requested before the first is added (one latency instead of rows / 256 of them: the kernel
+    // sits on the training step's critical path)
+    for (int i0 = threadIdx.x; i0 < rows; i0 += 256 * 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = i0 + 256 * u; v[u] = i < rows ? row_loss[i] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += (double)v[u];
+    }
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();

@@ -513,8 +513,16 @@ __global__ __launch_bounds__(256) void dmean_kernel(int H, int F, const float* _
     __syncthreads();
     for (int k = threadIdx.x; k < F; k += 256) {
         float s0 = 0.f, s1 = 0.f;
-        for (int j = 0; j < H; ++j) s0 += dv[j] * Wh[(size_t)j * F + k];
-        if (dc0) for (int j = 0; j < H; ++j) s1 += dv[H + j] * Wc[(size_t)j * F + k];
+        // eight rows' loads in flight (the plain loop waited for every load: H dependent L2 latencies on the post-BPTT chain)
+        int j = 0;
+        for (; j + 8 <= H; j += 8) {
+            float w[8], c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { w[u] = Wh[(size_t)(j + u) * F + k]; c[u] = dc0 ? Wc[(size_t)(j + u) * F + k] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s0 += dv[j + u] * w[u]; s1 += dv[H + j + u] * c[u]; }
+        }
+        for (; j < H; ++j) { s0 += dv[j] * Wh[(size_t)j * F + k]; if (dc0) s1 += dv[H + j] * Wc[(size_t)j * F + k]; }
         out[(size_t)b * F + k] = s0 + s1;
     }
 }
@@ -525,7 +533,15 @@ __global__ void ctx_kernel(int P, int F, int T, const float* __restrict__ alphas
     const float* al = alphas + ((size_t)b * T + t) * P;
     for (int k = threadIdx.x; k < F; k += blockDim.x) {
         float s = 0.f;
-        for (int p = 0; p < P; ++p) s += al[p] * f[((size_t)b * P + p) * F + k];
+        int p = 0;
+        for (; p + 8 <= P; p += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = f[((size_t)b * P + p + u) * F + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += al[p + u] * v[u];
+        }
+        for (; p < P; ++p) s += al[p] * f[((size_t)b * P + p) * F + k];
         ctx[((size_t)b * T + t) * F + k] = s;
     }
 }
@@ -536,7 +552,15 @@ __global__ void df_kernel(int P, int F, int T, const float* __restrict__ alphas,
     const float invP = 1.0f / (float)P;
     for (int k = threadIdx.x; k < F; k += blockDim.x) {
         float s = dmean[(size_t)b * F + k] * invP;
-        for (int t = 0; t < T; ++t) s += alphas[((size_t)b * T + t) * P + p] * dctx[((size_t)b * T + t) * F + k];
+        int t = 0;
+        for (; t + 8 <= T; t += 8) {
+            float a[8], v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[u] = alphas[((size_t)b * T + t + u) * P + p]; v[u] = dctx[((size_t)b * T + t + u) * F + k]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += a[u] * v[u];
+        }
+        for (; t < T; ++t) s += alphas[((size_t)b * T + t) * P + p] * dctx[((size_t)b * T + t) * F + k];
         df[((size_t)b * P + p) * F + k] = s;
     }
 }
