@@ -547,6 +547,7 @@ int launch_cfg(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 }  // namespace
 
 extern int g_tune_gemm_planes;
+int g_tune_gemm_tile = 0;     // 0: automatic tile choice; 64 / 128: forced (experiments)
 int g_tune_gemm_single = 0;   // 1: reduced-precision side mode -- one bf16 product per contraction instead of six (caphn_tune key 11)
 int g_tune_gemm_xcd = 1;      // 1 (default): XCD-aware tile order
 int g_tune_gemm_fast = 1;     // 1 (default): branch-free loads (static vmcnt) where alignment allows
@@ -575,7 +576,8 @@ int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
         if (ints <= 4096) g.kmap_lds = ints;      // 16 KB at most next to the 30 KB of tiles (64x64 configuration)
     }
     if (!g_tune_gemm_fast) g.flags |= 1 << 21;
-    const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.splitk;
+    long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.splitk;
+    if (g_tune_gemm_tile == 64) tiles128 = 0; else if (g_tune_gemm_tile == 128) tiles128 = 1 << 20;      // A/B experiments (caphn_tune key 12)
     const bool pl = caphn_gemm_planes_ok(g, ta, tb);
     if (pl) {
         if (tiles128 >= 512) return launch_cfg<128, 128, 1>(g, ta, tb, s);

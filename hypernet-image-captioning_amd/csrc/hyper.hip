@@ -562,6 +562,7 @@ extern int g_tune_gemm_fast;
 extern int g_tune_gemm_planes;
 extern int g_tune_rec_pair;
 extern int g_tune_gemm_single;
+extern int g_tune_gemm_tile;
 int caphn_rec_pair_debug_skip(int v);
 extern "C" int caphn_tune(int key, int value) {
     if (key == 0) { g_tune_gemv = value; return CAPHN_OK; }
@@ -575,5 +576,6 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 9) { g_tune_rec_pair = value; return CAPHN_OK; }
     if (key == 10) return caphn_rec_pair_debug_skip(value);
     if (key == 11) { g_tune_gemm_single = value; return CAPHN_OK; }
+    if (key == 12) { g_tune_gemm_tile = value; return CAPHN_OK; }
     return CAPHN_EINVAL;
 }

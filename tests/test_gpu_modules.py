@@ -192,6 +192,30 @@ def test_graph_replayed_step_matches_eager():
     assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 1e-4
 
 
+def test_graph_capture_after_eager_steps_that_left_side_work_pending():
+    """Regression for the capture hazards ADVICE named: an eager step that announced the next minibatch leaves a side-stream
+    precompute (an event the next forward would wait on) and a prefetched theta pending; step_graphed must drain both before it
+    captures (a capturing stream may not wait on uncaptured work), and the composites' forked branches must all be joined when
+    the capture ends.  The replayed trajectory equals eager stepping."""
+    from caphn.engine import FusedTrainer
+    name = "gru_tiny_flickr"
+    dims = TINY_DIMS[name]
+    g, p = load_case(name)
+    _, tok = style_args(g)
+    feats, caps = g["features"].to(DEV), g["captions"].to(DEV)
+    ta = FusedTrainer(build_net(dims, p, cc=False), lr=1e-3)
+    tb = FusedTrainer(build_net(dims, p, cc=False), lr=1e-3)
+    la = [float(ta.step(feats, caps, style_token=tok)[0]) for _ in range(5)]
+    lb = [float(tb.step_graphed(feats, caps, style_token=tok)[0])]          # first sight of these buffers: runs eagerly
+    lb.append(float(tb.step(feats, caps, style_token=tok, next_style_token=tok, next_features=feats, next_captions=caps)[0]))
+    assert tb._pre_key is not None and tb._next_key is not None            # side work IS pending when the capture starts
+    for _ in range(3):
+        lb.append(float(tb.step_graphed(feats, caps, style_token=tok)[0]))  # capture + replay, then two replays
+    assert len(tb._graphs) == 1 and tb.step_count == 5 and tb._pre_key is None
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
+    assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 1e-4
+
+
 def test_hypernet_lstm_module_and_engine():
     """HyperNet(cell='lstm'): hypernet generates the LSTMCell weights of an AttentionLstm behind a
     feature_fc.  Module API gradients and one fused engine step against the oracle."""
