@@ -14,6 +14,7 @@
 #include <initializer_list>
 #include <mutex>
 
+int g_tune_deterministic = 0;   // 1: bit-reproducible gradients -- no split-K (fp32 atomics), embedding gradient by a destination-major scan
 int g_tune_rec_pair = 1;     // 1 (default): two workgroups per caption in the recurrent kernels (recurrent_pair.hip)
 int g_tune_rec_rotate = 1;
 int g_tune_fork = 1;        // 0: one stream; 1 (default): independent branches on side streams, the dW_fc branch starting
@@ -228,6 +229,7 @@ inline bool dims_ok(const caphn_decoder_dims* d) {
 // split-K heuristic for the weight-gradient GEMMs (small MxN, long K): aim at >= 4 workgroups per CU
 // with at least 8 K-slabs each (the kernel picks 64x64 tiles below 1024 128x128 tiles)
 inline int pick_splitk(int M, int N, int K) {
+    if (g_tune_deterministic) return 1;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (t128 >= 1024) return 1;
     const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);

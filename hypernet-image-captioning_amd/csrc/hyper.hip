@@ -563,6 +563,8 @@ extern int g_tune_gemm_planes;
 extern int g_tune_rec_pair;
 extern int g_tune_gemm_single;
 extern int g_tune_gemm_tile;
+extern int g_tune_deterministic;
+extern int g_det_vocab;
 int caphn_rec_pair_debug_skip(int v);
 extern "C" int caphn_tune(int key, int value) {
     if (key == 0) { g_tune_gemv = value; return CAPHN_OK; }
@@ -577,5 +579,6 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 10) return caphn_rec_pair_debug_skip(value);
     if (key == 11) { g_tune_gemm_single = value; return CAPHN_OK; }
     if (key == 12) { g_tune_gemm_tile = value; return CAPHN_OK; }
+    if (key == 13) { g_tune_deterministic = value > 0; g_det_vocab = value; return CAPHN_OK; }
     return CAPHN_EINVAL;
 }

@@ -242,6 +242,26 @@ __global__ __launch_bounds__(256) void embed_gather_strided_kernel(int rows, int
     const int64_t id = idx[(size_t)r * istride];
     for (int e = threadIdx.x; e < E; e += 256) out[(size_t)r * ostride + e] = id < 0 ? 0.f : table[(size_t)id * E + e];
 }
+// deterministic variant: wave w of the grid owns table row v = w; it walks idx[0..rows) in order, adding every matching source row
+__global__ __launch_bounds__(256) void embed_scatter_det_kernel(int rows, int E, int V, const float* __restrict__ g, const int64_t* __restrict__ idx,
+                                                                float* __restrict__ tg) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= V) return;
+    bool any = false;
+    for (int r0 = 0; r0 < rows; r0 += 64) {
+        const int r = r0 + lane;
+        const bool hit = r < rows && idx[r] == (int64_t)v;
+        unsigned long long ball = __ballot(hit);
+        while (ball) {
+            const int b = __ffsll((long long)ball) - 1;
+            ball &= ball - 1;
+            const float* src = g + (size_t)(r0 + b) * E;
+            for (int e = lane; e < E; e += 64) tg[(size_t)v * E + e] += src[e];
+            any = true;
+        }
+    }
+    (void)any;
+}
 __global__ __launch_bounds__(256) void embed_scatter_kernel(int rows, int E, const float* __restrict__ g, const int64_t* __restrict__ idx, float* __restrict__ tg) {
     const int r = blockIdx.x;
     const int64_t id = idx[r];
@@ -751,8 +771,16 @@ int caphn_embedding_gather_strided(int rows, int E, const float* table, const in
     hipLaunchKernelGGL(embed_gather_strided_kernel, dim3(rows), dim3(256), 0, s, rows, E, table, idx, istride, out, ostride);
     return caphn_launch_status();
 }
+extern int g_tune_deterministic;
+int g_det_vocab = 0;      // rows of the embedding table the deterministic scatter scans (set with the mode: caphn_tune(13, V))
 extern "C" int caphn_embedding_scatter_add(int rows, int E, const float* g, const int64_t* idx, float* table_grad, caphn_stream_t stream) {
     if (rows <= 0 || E <= 0 || !g || !idx || !table_grad) return CAPHN_EINVAL;
+    if (g_tune_deterministic && g_det_vocab > 0 && rows > 1) {
+        // destination-major: one wave per table row scans the indices in order and adds its matches in that order (no atomics)
+        hipLaunchKernelGGL(embed_scatter_det_kernel, dim3((g_det_vocab + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), rows, E,
+                           g_det_vocab, g, idx, table_grad);
+        return caphn_launch_status();
+    }
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), rows, E, g, idx, table_grad);
     return caphn_launch_status();
 }

@@ -451,7 +451,10 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * GEMM tile order, key 7: branch-free GEMM loads, key 8: pre-split GEMM operands -- 0 off (every tile split on use), 1 on, key 9: recurrent kernels with two workgroups
  * per caption -- 0 off, 1 on, key 10: timing experiments only, key 11: REDUCED-PRECISION side mode -- 1 = every dense
  * contraction as ONE bf16 product (operands rounded to bf16 at staging, fp32 accumulate; recurrent kernels, softmax, loss,
- * Adam and the master weights stay fp32), 0 = the fp32-class six-product default).  Defaults are the measured-fastest. */
+ * Adam and the master weights stay fp32), 0 = the fp32-class six-product default, key 12: forced GEMM tile (experiments), key 13: DETERMINISTIC gradients -- value V > 0 (the
+ * vocabulary size) turns split-K off in the decoder composites (its partial products are summed with fp32 atomics) and computes
+ * the embedding gradient by a destination-major scan of the V table rows instead of atomic scatter-adds: gradients are then
+ * bit-identical from run to run, at a cost in speed; 0 = off).  Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
 /* ---------------------------------------------------------------------------------------
