@@ -34,12 +34,12 @@ class HyperGrads(C.Structure):
 
 class DecoderDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "T", "P", "D", "F", "E", "H", "V", "cell", "raw_features", "row_subset",
-                                         "grads_zeroed", "precomputed")] + [("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
+                                         "grads_zeroed", "precomputed", "layers")] + [("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
 
 
 _DEC_FIELDS = ("fc0_w", "fc0_b", "fc2_w", "fc2_b", "embed_w", "out_w", "out_b", "Wa_w", "Wa_b",
                "Ua_w", "Ua_b", "va_w", "va_b", "inith_w", "inith_b", "w_ih", "w_hh", "b_ih", "b_hh",
-               "initc_w", "initc_b")
+               "initc_w", "initc_b") + tuple(f"{a}{i}" for a in ("lw_ih", "lw_hh", "lb_ih", "lb_hh") for i in range(3))
 
 
 class DecoderParams(C.Structure):

@@ -290,6 +290,7 @@ class DecDims:
     rows: bool = False       # True: vocab GEMMs only touch rows with a live target (decoder_prepare_rows first)
     pre: int = 0             # bit mask (see caphn_decoder_dims.precomputed): 1 precompute, 2 G, 4 inputs
     gz: bool = False         # True: the caller zero-filled every gradient output (one zero_ over its arena)
+    layers: int = 1          # AttentionGru(num_layers): extra GRUCells h = layer(h, h) per time step (GRU only)
     drop_p: float = 0.0      # dropout on h_t in training mode (caphn_decoder_dims.dropout_p); the backward needs the same seed
     seed: int = 0
 
@@ -300,7 +301,7 @@ class DecDims:
     def c(self) -> L.DecoderDims:
         return L.DecoderDims(self.B, self.T, self.P, self.D, self.F, self.E, self.H, self.V,
                              1 if self.cell == "lstm" else 0, int(self.raw), int(self.rows), int(self.gz), int(self.pre),
-                             float(self.drop_p), int(self.seed) & (2 ** 64 - 1))
+                             int(self.layers), float(self.drop_p), int(self.seed) & (2 ** 64 - 1))
 
     def fields(self):
         """Ordered (C struct field, parameter name) pairs this configuration uses."""
@@ -317,6 +318,9 @@ class DecDims:
             f += [("initc_w", "init_c.weight"), ("initc_b", "init_c.bias")]
         c = self.cell
         f += [("w_ih", f"{c}.weight_ih"), ("w_hh", f"{c}.weight_hh"), ("b_ih", f"{c}.bias_ih"), ("b_hh", f"{c}.bias_hh")]
+        for l in range(self.layers - 1):
+            f += [(f"lw_ih{l}", f"layers.{l}.weight_ih"), (f"lw_hh{l}", f"layers.{l}.weight_hh"),
+                  (f"lb_ih{l}", f"layers.{l}.bias_ih"), (f"lb_hh{l}", f"layers.{l}.bias_hh")]
         return f
 
     def names(self) -> List[str]:
@@ -334,6 +338,9 @@ class DecDims:
                 "attention.U_a.bias": (H,), "attention.v_a.weight": (1, H), "attention.v_a.bias": (1,),
                 "init_h.weight": (H, F), "init_h.bias": (H,), "init_c.weight": (H, F), "init_c.bias": (H,),
                 f"{c}.weight_ih": (G, E + F), f"{c}.weight_hh": (G, H), f"{c}.bias_ih": (G,), f"{c}.bias_hh": (G,)}
+        for l in range(self.layers - 1):
+            full.update({f"layers.{l}.weight_ih": (3 * H, H), f"layers.{l}.weight_hh": (3 * H, H),
+                         f"layers.{l}.bias_ih": (3 * H,), f"layers.{l}.bias_hh": (3 * H,)})
         return {n: full[n] for n in self.names()}
 
 
@@ -344,7 +351,7 @@ DEC_FIELD_TO_NAME = dict(DecDims(1, 1, 1, 1, 1, 1, 1, 1).fields())
 def _dec_struct(cls, dims: DecDims, t: Dict[str, torch.Tensor]):
     """ctypes view of a name -> tensor dict.  A caller that keeps the SAME dict object for the same storage (the fused
     engine does) may set t["__frozen__"] = True: the validated struct is then memoised inside the dict."""
-    key = ("__struct__", cls.__name__, dims.cell, dims.raw)
+    key = ("__struct__", cls.__name__, dims.cell, dims.raw, dims.layers)
     if t.get("__frozen__") and key in t:
         return t[key]
     s = cls()
@@ -473,7 +480,7 @@ def decoder_search(dims: DecDims, params: Dict[str, torch.Tensor], features: tor
         raise L.CaphnError("greedy search is the beam == 1 case")
     if want_alphas and beam != 1:
         raise L.CaphnError("attention maps are only tracked for beam == 1")
-    rows = DecDims(n * beam, 1, dims.P, dims.D, dims.F, dims.E, dims.H, dims.V, dims.cell, dims.raw, False)
+    rows = DecDims(n * beam, 1, dims.P, dims.D, dims.F, dims.E, dims.H, dims.V, dims.cell, dims.raw, False, layers=dims.layers)
     cd = rows.c()
     cfg = L.SearchCfg(n, beam, max_steps, 0 if greedy else 1, 1 if greedy else 0, first_token, end_token)
     ps = _dec_struct(L.DecoderParams, rows, params)

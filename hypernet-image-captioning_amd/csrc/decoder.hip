@@ -120,13 +120,19 @@ struct Ws {   // float offsets into the workspace
     size_t dHs, dgi, dgh, duah, de, dh0, dc0, ctx, dctx, dXe, dWaf, dmeanf, df, dY1, apart, vtmp, colws, colws_s[3], prof, rowmap;
     size_t xch, xch_floats;     // exchange areas of the pair kernels: forward, then backward (xch_floats each)
     size_t wp;                  // packed recurrent weights of the pair kernels
+    // AttentionGru(num_layers > 1): attention cell output / its gradient [B,T,H], layered initial state, dh carry, GEMM temporaries,
+    // and per extra layer the saved slots (decoder_layers.hip)
+    size_t H0s, dH0, h0L, dcarry, tgi, tgh, tmpA, tmpB;
+    size_t Lin[CAPHN_MAX_DEC_LAYERS - 1], Lgates[CAPHN_MAX_DEC_LAYERS - 1], Lhn[CAPHN_MAX_DEC_LAYERS - 1],
+           Ldgi[CAPHN_MAX_DEC_LAYERS - 1], Ldgh[CAPHN_MAX_DEC_LAYERS - 1];
+    int L1;                     // number of extra layers
     size_t total;
     int npc, pchunk, NG, arows;
 };
 // the recurrent kernels run two workgroups per caption when the shape allows it (teacher-forced launches only)
 inline bool use_pair(const caphn_decoder_dims* d) {
     const int NG = d->cell == CAPHN_CELL_LSTM ? 4 : 3;
-    return g_tune_rec_pair && d->T > 1 && caphn_rec_pair_resident_gates(d->P, d->H, NG) >= 0;
+    return g_tune_rec_pair && d->T > 1 && d->layers <= 1 && caphn_rec_pair_resident_gates(d->P, d->H, NG) >= 0;
 }
 
 inline size_t up4(size_t v) { return (v + 3) & ~(size_t)3; }
@@ -160,11 +166,13 @@ inline Ws layout(const caphn_decoder_dims* d) {
     auto need = [&](size_t M, size_t N) { cs = std::max(cs, caphn_colsum_workspace_bytes((int)M, (int)N) / sizeof(float)); };
     need(B * T, V); need(B * T, NG * H); need(B * T, H); need(B * P, H); need(B * P, F); need(B, H);
     need(B * arows, H + 1);
+    if (d->layers > 1) need(B * (T + 1), 3 * H);
     w.colws = take(cs);
     {   // side-stream branches run their own (small) column sums concurrently
         size_t c2 = 0;
         auto need2 = [&](size_t M, size_t N) { c2 = std::max(c2, caphn_colsum_workspace_bytes((int)M, (int)N) / sizeof(float)); };
         need2(B * T, NG * H); need2(B * T, H); need2(B * P, H); need2(B * P, F); need2(B, H); need2(B * arows, H + 1);
+        if (d->layers > 1) need2(B * (T + 1), 3 * H);
         for (int i = 0; i < 3; ++i) w.colws_s[i] = take(c2);
     }
     w.prof = take(64);        // 2 x 8 uint64 phase counters (forward, backward) of the recurrent kernels
@@ -173,6 +181,17 @@ inline Ws layout(const caphn_decoder_dims* d) {
     w.xch = take(2 * w.xch_floats);
     o = (o + 31) & ~(size_t)31;                                  // 128-byte aligned
     w.wp = take(caphn_rec_pair_wp_floats((int)H, (int)NG));     // [U_a; W_hh] at the aligned row pitch
+    w.L1 = d->layers > 1 ? d->layers - 1 : 0;
+    {
+        const size_t on = w.L1 > 0 ? 1 : 0, S = T + 1;
+        w.H0s = take(on * B * T * H); w.dH0 = take(on * B * T * H); w.h0L = take(on * B * H); w.dcarry = take(on * B * H);
+        w.tgi = take(on * B * 3 * H); w.tgh = take(on * B * 3 * H); w.tmpA = take(on * B * H); w.tmpB = take(on * B * H);
+        for (int l = 0; l < CAPHN_MAX_DEC_LAYERS - 1; ++l) {
+            const size_t u = l < w.L1 ? 1 : 0;
+            w.Lin[l] = take(u * B * S * H); w.Lgates[l] = take(u * B * S * 3 * H); w.Lhn[l] = take(u * B * S * H);
+            w.Ldgi[l] = take(u * B * S * 3 * H); w.Ldgh[l] = take(u * B * S * 3 * H);
+        }
+    }
     w.total = o;
     (void)D;
     return w;
@@ -223,6 +242,13 @@ inline bool dims_ok(const caphn_decoder_dims* d) {
     if (!(d && d->B > 0 && d->T > 0 && d->P > 0 && d->D > 0 && d->F > 0 && d->E > 0 && d->H > 0 && d->V > 0)) return false;
     if (d->cell != CAPHN_CELL_GRU && d->cell != CAPHN_CELL_LSTM) return false;
     if (d->raw_features && d->F != d->D) return false;
+    if (d->layers < 0 || d->layers > CAPHN_MAX_DEC_LAYERS) return false;
+    if (d->layers > 1 && d->cell != CAPHN_CELL_GRU) return false;      // the reference's AttentionLstm has no extra layers
+    return true;
+}
+inline bool layer_params_ok(const caphn_decoder_dims* d, const caphn_decoder_params* p) {
+    for (int l = 0; l + 1 < d->layers; ++l)
+        if (!p->lw_ih[l] || !p->lw_hh[l] || !p->lb_ih[l] || !p->lb_hh[l]) return false;
     return true;
 }
 
@@ -335,6 +361,52 @@ __global__ __launch_bounds__(256) void next_token_kernel(int B, int T, int V, in
     }
 }
 
+// All extra GRUCells at one slot: h = layer(h, h) for every layer (decoderlstm.py:65-67, :101-103).  hin/hout are [B,H] rows
+// at the given pitches; dropout (after the last layer) applies to slot > 0 only.
+static int layers_forward(const caphn_decoder_dims* d, const caphn_decoder_params* p, const Ws& w, float* ws, int slot,
+                          const float* hin, int hin_ld, float* hout, int hout_ld, hipStream_t s) {
+    const int B = d->B, H = d->H, G3 = 3 * d->H;
+    const float* in = hin; int in_ld = hin_ld;
+    for (int l = 0; l < w.L1; ++l) {
+        const bool last = l == w.L1 - 1;
+        float* out = last ? hout : ws + ((l & 1) ? w.tmpB : w.tmpA);
+        const int out_ld = last ? hout_ld : H;
+        RUN(caphn_gemm_f32(0, 1, B, G3, H, in, in_ld, p->lw_ih[l], H, ws + w.tgi, G3, p->lb_ih[l], nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+        RUN(caphn_gemm_f32(0, 1, B, G3, H, in, in_ld, p->lw_hh[l], H, ws + w.tgh, G3, p->lb_hh[l], nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+        LayerFwdArgs a;
+        a.B = B; a.H = H; a.S = d->T + 1; a.slot = slot;
+        a.gi = ws + w.tgi; a.gh = ws + w.tgh; a.hin = in; a.hin_ld = in_ld; a.hout = out; a.hout_ld = out_ld;
+        a.sin = ws + w.Lin[l]; a.sgates = ws + w.Lgates[l]; a.shn = ws + w.Lhn[l];
+        if (last && slot > 0) { a.drop_p = d->dropout_p; a.drop_seed = d->dropout_seed; a.T = d->T; a.t = slot - 1; }
+        RUN(caphn_launch_layer_gru_fwd(a, s));
+        in = out; in_ld = out_ld;
+    }
+    return CAPHN_OK;
+}
+
+// Backward of layers_forward at one slot: dh of the last layer's output = d1 (+ d2) -> dout = gradient of the input.
+static int layers_backward(const caphn_decoder_dims* d, const caphn_decoder_params* p, const Ws& w, float* ws, int slot,
+                           const float* d1, int d1_ld, const float* d2, float* dout, int dout_ld, hipStream_t s) {
+    const int B = d->B, H = d->H, G3 = 3 * d->H, S = d->T + 1;
+    for (int l = w.L1 - 1; l >= 0; --l) {
+        float* o = l == 0 ? dout : ws + ((l & 1) ? w.tmpB : w.tmpA);
+        const int o_ld = l == 0 ? dout_ld : H;
+        LayerBwdArgs a;
+        a.B = B; a.H = H; a.S = S; a.slot = slot;
+        a.d1 = d1; a.d1_ld = d1_ld; a.d2 = d2;
+        a.sin = ws + w.Lin[l]; a.sgates = ws + w.Lgates[l]; a.shn = ws + w.Lhn[l];
+        a.dgi = ws + w.Ldgi[l]; a.dgh = ws + w.Ldgh[l]; a.dout = o; a.dout_ld = o_ld;
+        if (l == w.L1 - 1 && slot > 0) { a.drop_p = d->dropout_p; a.drop_seed = d->dropout_seed; a.T = d->T; a.t = slot - 1; }
+        RUN(caphn_launch_layer_gru_bwd(a, s));
+        RUN(caphn_gemm_f32(0, 0, B, H, G3, ws + w.Ldgi[l] + (size_t)slot * G3, S * G3, p->lw_ih[l], H, o, o_ld, nullptr, nullptr, 0,
+                           CAPHN_GEMM_ACCUM, 1, s));
+        RUN(caphn_gemm_f32(0, 0, B, H, G3, ws + w.Ldgh[l] + (size_t)slot * G3, S * G3, p->lw_hh[l], H, o, o_ld, nullptr, nullptr, 0,
+                           CAPHN_GEMM_ACCUM, 1, s));
+        d1 = o; d1_ld = o_ld; d2 = nullptr;
+    }
+    return CAPHN_OK;
+}
+
 }  // namespace
 
 extern "C" size_t caphn_decoder_workspace_bytes(const caphn_decoder_dims* d) {
@@ -411,6 +483,7 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     if (RG < 0) return CAPHN_ELIMIT;
     if (lstm && (!p->initc_w || !p->initc_b)) return CAPHN_EINVAL;
     if (!raw && (!p->fc0_w || !p->fc0_b || !p->fc2_w || !p->fc2_b)) return CAPHN_EINVAL;
+    if (!layer_params_ok(d, p)) return CAPHN_EINVAL;
 
     const float* f = nullptr;
     // precomputed bits: 1 the theta-independent part, 2 G, 4 the x side (embedding lookup + gate pre-activations)
@@ -435,6 +508,16 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
         RUN(caphn_launch_rec_pair_prep(a.xch, 2 * w.xch_floats * sizeof(float) / sizeof(unsigned long long), p->Ua_w, p->w_hh, H, w.NG,
                                        ws + w.wp, s));
         RUN(caphn_launch_rec_pair_fwd(a, lstm, s));
+    } else if (w.L1 > 0) {
+        // num_layers > 1: one launch window per step.  The attention cell writes its h_t to H0s, the extra cells take it to
+        // Hs[:, t] (the h the vocabulary projection and the next step see); the initial state passes through them too.
+        RUN(layers_forward(d, p, w, ws, 0, ws + w.h0, H, ws + w.h0L, H, s));
+        a.h0 = ws + w.h0L; a.Hs = ws + w.H0s; a.Hsrc = ws + w.Hs; a.drop_p = 0.f;
+        for (int t = 0; t < T; ++t) {
+            a.t0 = t; a.t1 = t + 1;
+            RUN(caphn_launch_rec_fwd(a, lstm, s));
+            RUN(layers_forward(d, p, w, ws, t + 1, ws + w.H0s + (size_t)t * H, T * H, ws + w.Hs + (size_t)t * H, T * H, s));
+        }
     } else
     RUN(caphn_launch_rec_fwd(a, lstm, s));
 
@@ -490,6 +573,8 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     if (RG < 0) return CAPHN_ELIMIT;
     if (lstm && (!g->initc_w || !g->initc_b)) return CAPHN_EINVAL;
     if (!raw && (!g->fc0_w || !g->fc0_b || !g->fc2_w || !g->fc2_b)) return CAPHN_EINVAL;    // before any branch is forked
+    if (!layer_params_ok(d, p)) return CAPHN_EINVAL;
+    for (int l = 0; l < w.L1; ++l) if (!g->lw_ih[l] || !g->lw_hh[l] || !g->lb_ih[l] || !g->lb_hh[l]) return CAPHN_EINVAL;
     void* cws = ws + w.colws;
     const int64_t* idx = reinterpret_cast<const int64_t*>(ws + w.idx);
     const float* f = raw ? features : ws + w.f;
@@ -534,9 +619,21 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     // attention parameter gradients (dWaf, partial d v_a / d b_va) come out of the BPTT kernel itself when its thread
     // map can carry them (it evaluates the same tanh for d(U_a h)): one ~50 us kernel less on the chain
     a.drop_p = d->dropout_p; a.drop_seed = d->dropout_seed;
-    const int ang = pair ? caphn_rec_pair_bwd_groups(P, H) : caphn_rec_bwd_groups(P, H);
+    // (a windowed BPTT cannot keep the fused accumulators across launches: layered decoders use the separate kernel)
+    const int ang = w.L1 > 0 ? 0 : pair ? caphn_rec_pair_bwd_groups(P, H) : caphn_rec_bwd_groups(P, H);
     if (ang > 0) { a.dWaf = ws + w.dWaf; a.apart = ws + w.apart; }
-    if (pair) {
+    if (w.L1 > 0) {
+        // per step, top down: the extra cells' backward turns d h_t (vocab projection + what step t + 1 sent back) into the
+        // gradient of the attention cell's output, one BPTT window consumes it and leaves d h_{t-1} in dcarry
+        RUN(caphn_zero_f32(ws + w.dcarry, (size_t)B * H, s));
+        a.dHs = ws + w.dH0; a.dh0 = ws + w.dcarry; a.drop_p = 0.f;
+        for (int t = T - 1; t >= 0; --t) {
+            RUN(layers_backward(d, p, w, ws, t + 1, ws + w.dHs + (size_t)t * H, T * H, ws + w.dcarry, ws + w.dH0 + (size_t)t * H, T * H, s));
+            a.t0 = t; a.t1 = t + 1;
+            RUN(caphn_launch_rec_bwd(a, lstm, s));
+        }
+        RUN(layers_backward(d, p, w, ws, 0, ws + w.dcarry, H, nullptr, ws + w.dh0, H, s));
+    } else if (pair) {
         a.xch = reinterpret_cast<unsigned long long*>(ws + w.xch) + w.xch_floats * sizeof(float) / sizeof(unsigned long long);
         a.apart_rows = ang;
         a.WP = ws + w.wp; a.wp_pitch = caphn_rec_pair_pitch(H);
@@ -592,6 +689,11 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     }
     if (!hold_big) RUN(sd.milestone(CAPHN_MS_HYPER, b1));
     RUN(wgrad_bias(H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, g->Ua_b, nullptr, cw1, b1, gz));
+    for (int l = 0; l < w.L1; ++l) {     // extra cells: one transposed GEMM over all B (T + 1) slots per weight
+        const int BS = B * (T + 1), G3 = 3 * H;
+        RUN(wgrad_bias(G3, H, BS, ws + w.Ldgi[l], G3, ws + w.Lin[l], H, g->lw_ih[l], H, g->lb_ih[l], nullptr, cw1, b1, gz));
+        RUN(wgrad_bias(G3, H, BS, ws + w.Ldgh[l], G3, ws + w.Lin[l], H, g->lw_hh[l], H, g->lb_hh[l], nullptr, cw1, b1, gz));
+    }
     RUN(wgrad_bias(H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, g->inith_b, nullptr, cw1, b1, gz));
     if (lstm) RUN(wgrad_bias(H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, g->initc_b, nullptr, cw1, b1, gz));
     // main -- df = alpha^T dctx + dmean/P + dWaf W_a, then feature_fc backward
@@ -660,7 +762,9 @@ extern "C" int caphn_decoder_forward_sampled(const caphn_decoder_dims* d, const 
     if (RG < 0) return CAPHN_ELIMIT;
     if (lstm && (!p->initc_w || !p->initc_b)) return CAPHN_EINVAL;
     const float* f = nullptr;
+    if (!layer_params_ok(d, p)) return CAPHN_EINVAL;
     RUN(decoder_precompute(d, p, w, ws, features, &f, s));
+    if (w.L1 > 0) RUN(layers_forward(d, p, w, ws, 0, ws + w.h0, H, ws + w.h0L, H, s));
     int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
     // source of word_embed: 0 zero, 1 teacher column `col`, 2 sampled from logits column `col`
     int src_mode = 0, src_col = 0;
@@ -678,7 +782,7 @@ extern "C" int caphn_decoder_forward_sampled(const caphn_decoder_dims* d, const 
         RecFwdArgs a;
         a.B = B; a.T = 1; a.P = P; a.H = H; a.RG = RG;
         a.Waf = ws + w.Waf; a.G = ws + w.G; a.Xg = ws + w.Xg;
-        a.h0 = t == 0 ? ws + w.h0 : ws + w.Hs + (size_t)(t - 1) * B * H;
+        a.h0 = t == 0 ? ws + (w.L1 > 0 ? w.h0L : w.h0) : ws + w.Hs + (size_t)(t - 1) * B * H;
         a.c0 = lstm ? (t == 0 ? ws + w.c0 : ws + w.Cs + (size_t)(t - 1) * B * H) : nullptr;
         a.W_hh = p->w_hh; a.b_hh = p->b_hh; a.U_a = p->Ua_w; a.b_Ua = p->Ua_b; a.v_a = p->va_w; a.b_va = p->va_b;
         a.Hs = ws + w.Hs + (size_t)t * B * H; a.Hprev = ws + w.Hprev; a.alphas = ws + w.alphas;
@@ -686,9 +790,12 @@ extern "C" int caphn_decoder_forward_sampled(const caphn_decoder_dims* d, const 
         a.prof = nullptr; a.rotate = 0;
         a.vecW = (H % 4 == 0) && caphn_aligned16(p->w_hh) && caphn_aligned16(p->Ua_w);
         a.vecS = (H % 4 == 0) && caphn_aligned16(ws);
+        float* ht = a.Hs;
+        if (w.L1 > 0) a.Hs = ws + w.H0s;
         RUN(caphn_launch_rec_fwd(a, lstm, s));
+        if (w.L1 > 0) RUN(layers_forward(d, p, w, ws, t + 1, ws + w.H0s, H, ht, H, s));
         // logits[:, t, :] = h_t W_fc^T + b   (leading dimension T*V)
-        RUN(caphn_gemm_f32(0, 1, B, V, H, a.Hs, H, p->out_w, H, logits + (size_t)t * V, T * V, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+        RUN(caphn_gemm_f32(0, 1, B, V, H, ht, H, p->out_w, H, logits + (size_t)t * V, T * V, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
         if (alphas)
             if (hipMemcpy2DAsync(alphas + (size_t)t * P, sizeof(float) * (size_t)T * P, ws + w.alphas, sizeof(float) * P,
                                  sizeof(float) * P, B, hipMemcpyDeviceToDevice, s) != hipSuccess) return CAPHN_ELAUNCH;
@@ -718,6 +825,7 @@ extern "C" int caphn_decoder_forward_sampled_train(const caphn_decoder_dims* d, 
     const int RG = pair ? caphn_rec_pair_resident_gates(P, H, w.NG) : caphn_rec_resident_gates(P, H, w.NG);
     if (RG < 0) return CAPHN_ELIMIT;
     if (lstm && (!p->initc_w || !p->initc_b)) return CAPHN_EINVAL;
+    if (!layer_params_ok(d, p)) return CAPHN_EINVAL;
     const float* f = nullptr;
     RUN(decoder_precompute(d, p, w, ws, features, &f, s));
     int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
@@ -737,6 +845,10 @@ extern "C" int caphn_decoder_forward_sampled_train(const caphn_decoder_dims* d, 
         RUN(caphn_launch_rec_pair_prep(a.xch, 2 * w.xch_floats * sizeof(float) / sizeof(unsigned long long), p->Ua_w, p->w_hh, H, w.NG,
                                        ws + w.wp, s));
     }
+    if (w.L1 > 0) {     // as in caphn_decoder_forward
+        RUN(layers_forward(d, p, w, ws, 0, ws + w.h0, H, ws + w.h0L, H, s));
+        a.h0 = ws + w.h0L; a.Hs = ws + w.H0s; a.Hsrc = ws + w.Hs; a.drop_p = 0.f;
+    }
     int src_mode = 0, src_col = 0;
     for (int t = 0; t < T; ++t) {
         const bool samp = t > 0 && use_sampling[t] != 0;
@@ -749,6 +861,7 @@ extern "C" int caphn_decoder_forward_sampled_train(const caphn_decoder_dims* d, 
                            nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
         a.t0 = t; a.t1 = t + 1;
         if (pair) RUN(caphn_launch_rec_pair_fwd(a, lstm, s)); else RUN(caphn_launch_rec_fwd(a, lstm, s));
+        if (w.L1 > 0) RUN(layers_forward(d, p, w, ws, t + 1, ws + w.H0s + (size_t)t * H, T * H, ws + w.Hs + (size_t)t * H, T * H, s));
         RUN(caphn_gemm_f32(0, 1, B, V, H, ws + w.Hs + (size_t)t * H, T * H, p->out_w, H, logits + (size_t)t * V, T * V, p->out_b, nullptr, 0,
                            CAPHN_GEMM_BIAS, 1, s));
         if (samp && lstm) { src_mode = 2; src_col = t; }
@@ -814,14 +927,17 @@ extern "C" int caphn_decoder_search_begin(const caphn_decoder_dims* d, const cap
     caphn_decoder_dims di = *d;
     di.B = c->n_images;
     const float* f = nullptr;
+    if (!layer_params_ok(d, p)) return CAPHN_EINVAL;
     RUN(decoder_precompute(&di, p, w, ws, features, &f, s));
+    if (w.L1 > 0) RUN(layers_forward(&di, p, w, ws, 0, ws + w.h0, d->H, ws + w.h0L, d->H, s));
     const SearchArgs a = search_args(d, c, w, ws, static_cast<char*>(sws_));
-    return caphn_launch_search_init(a, ws + w.h0, c->first_token, c->lookup_first, s);
+    return caphn_launch_search_init(a, ws + (w.L1 > 0 ? w.h0L : w.h0), c->first_token, c->lookup_first, s);
 }
 
 extern "C" int caphn_decoder_search_steps(const caphn_decoder_dims* d, const caphn_decoder_params* p, const caphn_search_cfg* c,
                                           int step0, int nsteps, float* alphas, void* ws_, void* sws_, caphn_stream_t stream) {
     if (!search_ok(d, c) || !p || !ws_ || !sws_ || step0 < 1 || nsteps < 0 || step0 + nsteps - 1 > c->max_steps) return CAPHN_EINVAL;
+    if (!layer_params_ok(d, p)) return CAPHN_EINVAL;
     if (alphas && c->beam != 1) return CAPHN_EINVAL;      // attention maps are only tracked without beam re-ordering
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = layout(d);
@@ -844,7 +960,9 @@ extern "C" int caphn_decoder_search_steps(const caphn_decoder_dims* d, const cap
         a.Cs = nullptr; a.Cprev = nullptr; a.uah = ws + w.uah; a.prof = nullptr; a.rotate = 0;
         a.vecW = (H % 4 == 0) && caphn_aligned16(p->w_hh) && caphn_aligned16(p->Ua_w);
         a.vecS = (H % 4 == 0) && caphn_aligned16(ws);
+        if (w.L1 > 0) a.Hs = ws + w.H0s;
         RUN(caphn_launch_rec_fwd(a, false, s));
+        if (w.L1 > 0) RUN(layers_forward(d, p, w, ws, 1, ws + w.H0s, H, ws + w.Hs, H, s));
         RUN(caphn_gemm_f32(0, 1, R, V, H, ws + w.Hs, H, p->out_w, H, logits, V, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
         if (alphas)
             if (hipMemcpy2DAsync(alphas + (size_t)(step - 1) * P, sizeof(float) * (size_t)c->max_steps * P, ws + w.alphas,

@@ -28,6 +28,8 @@ struct RecFwdArgs {
     const float* WP = nullptr; int wp_pitch = 0;   // [U_a; W_hh] packed to a 128-byte-aligned row pitch (caphn_launch_rec_pair_prep)
     int t0 = 0, t1 = 0;                  // time-step window [t0, t1) of this launch (t1 == 0: T); t0 > 0 continues from Hs / Cs
     float drop_p = 0.f; unsigned long long drop_seed = 0;   // dropout on h_t: element (b, t, k) keeps by the hash of (seed, (b T + t) H + k)
+    const float* Hsrc = nullptr;         // t0 > 0: h_{t0-1} comes from Hsrc [B,T,H] instead of Hs (multi-layer decoders: Hs receives the
+                                         // attention cell's output, the next step continues from the LAST layer's output)
 };
 struct RecBwdArgs {
     int B, T, P, H;
@@ -52,6 +54,9 @@ struct RecBwdArgs {
     const float* WP = nullptr; int wp_pitch = 0;
     int apart_rows = 0;                  // pair kernels: rows of `apart` per caption
     float drop_p = 0.f; unsigned long long drop_seed = 0;
+    int t0 = 0, t1 = 0;                  // time-step window [t0, t1), walked backwards (t1 == 0: T).  A window starts from dh = 0 (dc
+                                         // from dc0 when t1 < T) and leaves dh_{t0-1} in dh0 (dc in dc0): the caller adds it to what
+                                         // arrives at step t0 - 1
 };
 struct AttnGradArgs {
     int T, P, H, pchunk;
@@ -59,6 +64,26 @@ struct AttnGradArgs {
     float* dWaf;            // [B,P,H]
     float* part;            // [B*npc, H+1]
 };
+
+// decoder_layers.hip: pointwise part of one extra GRUCell application h = layer(h, h) at one slot (0: initial state, t + 1: step t)
+struct LayerFwdArgs {
+    int B, H, S, slot;                   // S = T + 1 slots per caption in the saved arrays
+    const float* gi; const float* gh;    // [B,3H] h W_ih^T + b_ih, h W_hh^T + b_hh
+    const float* hin; int hin_ld;        // [B,H] rows at pitch hin_ld
+    float* hout; int hout_ld;
+    float* sin; float* sgates; float* shn;   // saved per slot: input [B,S,H], gates r,z,n [B,S,3H], W_hn h + b_hn [B,S,H]
+    float drop_p = 0.f; unsigned long long drop_seed = 0; int T = 1, t = 0;   // dropout on the output (last layer, slot > 0)
+};
+struct LayerBwdArgs {
+    int B, H, S, slot;
+    const float* d1; int d1_ld; const float* d2;     // dh = d1 (+ d2 [B,H])
+    const float* sin; const float* sgates; const float* shn;
+    float* dgi; float* dgh;              // [B,S,3H]
+    float* dout; int dout_ld;            // dh z (the caller accumulates d gi W_ih + d gh W_hh on top)
+    float drop_p = 0.f; unsigned long long drop_seed = 0; int T = 1, t = 0;
+};
+int caphn_launch_layer_gru_fwd(const LayerFwdArgs& a, hipStream_t s);
+int caphn_launch_layer_gru_bwd(const LayerBwdArgs& a, hipStream_t s);
 
 size_t caphn_rec_fwd_lds_bytes(int P, int H, int NG, int RG);
 size_t caphn_rec_bwd_lds_bytes(int P, int H, int NG, int RG);

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(NT) void rec_attn_fwd_kernel(RecFwdArgs a) {
     // time-step window [t0, t1) of this launch (t1 == 0: all T steps); t0 > 0 continues from the saved h_{t0-1} (c_{t0-1})
     const int t0 = a.t0, t1 = a.t1 > 0 ? a.t1 : a.T;
     for (int k = tid; k < H; k += NT) {
-        h_s[k] = t0 == 0 ? a.h0[(size_t)b * H + k] : a.Hs[((size_t)b * T + t0 - 1) * H + k];
+        h_s[k] = t0 == 0 ? a.h0[(size_t)b * H + k] : (a.Hsrc ? a.Hsrc : a.Hs)[((size_t)b * T + t0 - 1) * H + k];
         va_s[k] = a.v_a[k];
         c_s[k] = LSTM ? (t0 == 0 ? a.c0[(size_t)b * H + k] : a.Cs[((size_t)b * T + t0 - 1) * H + k]) : 0.f;
     }
@@ -297,7 +297,11 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
 
     const float* Gb = a.G + (size_t)b * P * GH;
     load_G_resident(G_s, Gb, P, GH, RGH, a.vecS, tid);
-    for (int k = tid; k < H; k += NT) { dh_s[k] = 0.f; dc_s[k] = 0.f; va_s[k] = a.v_a[k]; }
+    const int bt0 = a.t0, bt1 = a.t1 > 0 ? a.t1 : T;
+    for (int k = tid; k < H; k += NT) {
+        dh_s[k] = 0.f; va_s[k] = a.v_a[k];
+        dc_s[k] = (LSTM && bt1 < T) ? a.dc0[(size_t)b * H + k] : 0.f;
+    }
     const float* Waf_b = a.Waf + (size_t)b * P * H;
     // transposed mat-vec thread map: chunk of CH columns x row slice
     const int CH = a.vecW ? 4 : 1;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(NT) void rec_attn_bwd_kernel(RecBwdArgs a) {
     for (int i = 0; i < PGM; ++i) dw[i] = 0.f;
     float dva = 0.f, dbva = 0.f;
 
-    for (int t = T - 1; t >= 0; --t) {
+    for (int t = bt1 - 1; t >= bt0; --t) {
         const size_t bt = (size_t)b * T + t;
         for (int p = tid; p < P; p += NT) al_s[p] = a.alphas[bt * P + p];
         // cell backward (pointwise), thread k

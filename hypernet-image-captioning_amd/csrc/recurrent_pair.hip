@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
     }
     const int t0 = a.t0, t1 = a.t1 > 0 ? a.t1 : a.T, T = a.T;
     for (int k = tid; k < H; k += NT)
-        h_s[k] = t0 == 0 ? a.h0[(size_t)b * H + k] : a.Hs[((size_t)b * T + t0 - 1) * H + k];
+        h_s[k] = t0 == 0 ? a.h0[(size_t)b * H + k] : (a.Hsrc ? a.Hsrc : a.Hs)[((size_t)b * T + t0 - 1) * H + k];
     for (int kk = tid; kk < nk; kk += NT) {
         va_s[kk] = a.v_a[k0 + kk];
         c_s[kk] = LSTM ? (t0 == 0 ? a.c0[(size_t)b * H + k0 + kk] : a.Cs[((size_t)b * T + t0 - 1) * H + k0 + kk]) : 0.f;
@@ -435,7 +435,11 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
             G_s[(size_t)pq * nk + kk] = Gb[(size_t)p * GH + q * H + k0 + kk];
         }
     }
-    for (int kk = tid; kk < nk; kk += NT) { dh_s[kk] = 0.f; dc_s[kk] = 0.f; va_s[kk] = a.v_a[k0 + kk]; }
+    const int bt0 = a.t0, bt1 = a.t1 > 0 ? a.t1 : T;
+    for (int kk = tid; kk < nk; kk += NT) {
+        dh_s[kk] = 0.f; va_s[kk] = a.v_a[k0 + kk];
+        dc_s[kk] = (LSTM && bt1 < T) ? a.dc0[(size_t)b * H + k0 + kk] : 0.f;
+    }
     const float* Waf_b = a.Waf + (size_t)b * P * H;
     // transposed mat-vec thread map over ONE half of the columns at a time: chunk of CH columns x row slice
     const int CH = (H % 4) == 0 ? 4 : 1;
@@ -514,9 +518,9 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
             else { pf[5] = a.hn[bt * H + k]; pf[6] = a.Hprev[bt * H + k]; }
         }
     };
-    if (pfk) prefetch(T - 1);
+    if (pfk) prefetch(bt1 - 1);
 
-    for (int t = T - 1; t >= 0; --t) {
+    for (int t = bt1 - 1; t >= bt0; --t) {
         const size_t bt = (size_t)b * T + t;
         if (pfk) { if (tid < P) al_s[tid] = pfa; }
         else for (int p = tid; p < P; p += NT) al_s[p] = a.alphas[bt * P + p];
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
                 a.dgh[bt * GH + k] = drp; a.dgh[bt * GH + H + k] = dzp; a.dgh[bt * GH + 2 * H + k] = dnp * r;
             }
         }
-        if (pfk && t > 0) prefetch(t - 1);
+        if (pfk && t > bt0) prefetch(t - 1);
         __syncthreads();
         PSTAMP(0);
         // my part of d alpha_p = G_p . dgi (sum over my k)

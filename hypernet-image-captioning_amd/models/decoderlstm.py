@@ -65,12 +65,12 @@ class AttentionGru(nn.Module):
         # generated (or ordinary) cell weights: Parameters or plain tensors set by set_all_parameters
         for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
             t["gru." + n] = getattr(self.gru, n)
+            for l in range(self.num_layers - 1):       # the extra cells h = layer(h, h) (models/decoderlstm.py:34-36)
+                t[f"layers.{l}.{n}"] = getattr(self.layers[l], n)
         return t
 
     def forward(self, features, captions, sample_prob=0.0):
         """features [B,P,num_features], captions [B,T] -> (outputs [B,T,V], atten_weights [B,T,P])."""
-        if self.layers:
-            raise NotImplementedError("num_layers > 1 is not supported by the fused HIP path")
         B, P, D = features.shape
         if D != self.num_features:
             raise CaphnError(f"features have {D} channels, module expects {self.num_features}")
@@ -87,7 +87,7 @@ class AttentionGru(nn.Module):
 
     def dec_dims(self, B, T, P):
         return ops.DecDims(B, T, P, self.num_features, self.feature_out, self.embedding_dim, self.hidden_dim,
-                           self.vocab_size)
+                           self.vocab_size, layers=max(1, self.num_layers))
 
     def init_hidden(self, features):
         """models/decoderlstm.py:122-135 (features are post-feature_fc here, as in the reference)."""
@@ -97,13 +97,12 @@ class AttentionGru(nn.Module):
         """models/decoderlstm.py:138-175.  features are feature_fc outputs [1,P,F] -> (sentence, weights): the
         token list (ending with end_sentence unless max_sentence was hit) and one attention map [1,P] per step.
         A batch [B,P,F] decodes every image at once on the device and returns lists of those per image."""
-        if self.layers:
-            raise NotImplementedError("num_layers > 1 is not supported by the fused HIP path")
         B, P, Fo = features.shape
         if Fo != self.feature_out:
             raise CaphnError(f"greedy_search takes feature_fc outputs ({self.feature_out} channels), got {Fo}")
         named = self._named_tensors()
-        dims = ops.DecDims(B, 1, P, Fo, Fo, self.embedding_dim, self.hidden_dim, self.vocab_size, raw=True)
+        dims = ops.DecDims(B, 1, P, Fo, Fo, self.embedding_dim, self.hidden_dim, self.vocab_size, raw=True,
+                           layers=max(1, self.num_layers))
         params = {n: named[n].detach().contiguous().float() for n in dims.names()}
         seqs, lengths, _, _, alphas = ops.decoder_search(dims, params, features.detach().float().contiguous(), 1,
                                                          max_sentence, end_token=end_sentence, greedy=True,

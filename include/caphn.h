@@ -191,6 +191,10 @@ typedef struct caphn_decoder_dims {
                            given captions, i.e. after the generated W_ih is final), 4 = embedding lookup + x-side gate
                            pre-activations (caphn_decoder_inputs, or that same call).  7: the forward starts at the
                            recurrent kernel */
+    int layers;         /* num_layers of AttentionGru (models/decoderlstm.py:34-36): 1 (or 0) = the cell alone; L > 1 adds L - 1 GRUCells
+                           applied as h = layer(h, h) after the attention cell at every time step (:101-103).  Then the time loop
+                           runs one launch window per step (the extra cells are small batched GEMMs + a gate kernel between the
+                           windows).  GRU only, L <= CAPHN_MAX_DEC_LAYERS. */
     float dropout_p;    /* h = self.drop(h) (models/decoderlstm.py:44,104; AttentionLstm :254) in TRAINING mode: every h_t is
                            multiplied by keep / (1 - p) before it feeds fc, the next step's cell and the next step's attention.
                            0 = off (eval mode, or p = 0 as the hypernet path constructs its decoder).  The keep decision of
@@ -200,6 +204,7 @@ typedef struct caphn_decoder_dims {
     unsigned long long dropout_seed;
 } caphn_decoder_dims;
 
+#define CAPHN_MAX_DEC_LAYERS 4
 typedef struct caphn_decoder_params {   /* reference state_dict names in comments */
     const float* fc0_w; const float* fc0_b;   /* captioner.feature_fc.0  [F,D],[F] */
     const float* fc2_w; const float* fc2_b;   /* captioner.feature_fc.2  [F,F],[F] */
@@ -212,6 +217,9 @@ typedef struct caphn_decoder_params {   /* reference state_dict names in comment
     const float* w_ih; const float* w_hh;     /* cell weight_ih [NG*H,E+F], weight_hh [NG*H,H] (slices of theta) */
     const float* b_ih; const float* b_hh;     /* cell bias_ih [NG*H], bias_hh [NG*H] */
     const float* initc_w; const float* initc_b; /* captioner.init_c    [H,F],[H]  (LSTM only, else NULL) */
+    /* captioner.layers.l (dims.layers > 1 only): GRUCell(H, H) l = 0 .. layers-2 -- weight_ih [3H,H], weight_hh [3H,H], biases [3H] */
+    const float* lw_ih[CAPHN_MAX_DEC_LAYERS - 1]; const float* lw_hh[CAPHN_MAX_DEC_LAYERS - 1];
+    const float* lb_ih[CAPHN_MAX_DEC_LAYERS - 1]; const float* lb_hh[CAPHN_MAX_DEC_LAYERS - 1];
 } caphn_decoder_params;
 
 typedef struct caphn_decoder_grads {    /* same shapes as the parameters; all required (feature_fc ones unless raw_features, init_c ones if LSTM) */
@@ -222,6 +230,8 @@ typedef struct caphn_decoder_grads {    /* same shapes as the parameters; all re
     float* inith_w; float* inith_b;
     float* w_ih; float* w_hh; float* b_ih; float* b_hh;   /* = dtheta, in theta order when contiguous */
     float* initc_w; float* initc_b;     /* LSTM only */
+    float* lw_ih[CAPHN_MAX_DEC_LAYERS - 1]; float* lw_hh[CAPHN_MAX_DEC_LAYERS - 1];
+    float* lb_ih[CAPHN_MAX_DEC_LAYERS - 1]; float* lb_hh[CAPHN_MAX_DEC_LAYERS - 1];
 } caphn_decoder_grads;
 
 /* Saved-activation workspace shared by forward and backward (one training step). */

@@ -236,7 +236,8 @@ def decoder_forward(dims: Dims, p: Dict[str, Tensor], cellw: Dict[str, Tensor],
                     features: Tensor, captions: Tensor,
                     use_sampling: Optional[Sequence[bool]] = None,
                     sample_temp: float = 0.5, use_feature_fc: bool = True,
-                    drop_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+                    drop_mask: Optional[Tensor] = None,
+                    layers: Optional[Sequence[Dict[str, Tensor]]] = None) -> Tuple[Tensor, Tensor]:
     """AttentionGru.forward, models/decoderlstm.py:49-120 (cell == 'gru'), or the
     same loop around an LSTMCell behind the same feature_fc (cell == 'lstm'; the
     build's hypernet-LSTM configuration).
@@ -244,6 +245,9 @@ def decoder_forward(dims: Dims, p: Dict[str, Tensor], cellw: Dict[str, Tensor],
     use_sampling[t]: the per-timestep draw ``np.random.random() < sample_prob``
     (:80); None == all False (sample_prob = 0.0, teacher forcing).  t = 0 never
     samples (:79).
+
+    layers: the extra GRUCells of num_layers > 1 (:34-36), one weight dict each; every one is applied as
+    h = layer(h, h) to the initial state (:65-67) and after the attention cell at every step (:101-103).
 
     Quirk (:82-84): at t = 0 the reference zeroes a *view* of embed[:,0,:] in place,
     so x_0 = 0 and, because step 1 reads embed[:,0,:] again, x_1 = 0 as well.
@@ -260,6 +264,8 @@ def decoder_forward(dims: Dims, p: Dict[str, Tensor], cellw: Dict[str, Tensor],
     c = None
     if dims.cell == "lstm":
         c = F_.linear(mean_f, p["captioner.init_c.weight"], p["captioner.init_c.bias"])
+    for lw in (layers or ()):                                            # :65-67
+        h = gru_cell(h, h, lw)
     Waf = F_.linear(f, p["captioner.attention.W_a.weight"], p["captioner.attention.W_a.bias"])
     outs, alphas = [], []
     output = None
@@ -280,6 +286,8 @@ def decoder_forward(dims: Dims, p: Dict[str, Tensor], cellw: Dict[str, Tensor],
             h = gru_cell(xin, h, cellw)                                  # :100
         else:
             h, c = lstm_cell(xin, h, c, cellw)
+        for lw in (layers or ()):                                        # :101-103
+            h = gru_cell(h, h, lw)
         if drop_mask is not None:                                        # h = self.drop(h), :104 -- the dropped h also
             h = h * drop_mask[:, t]                                      # is the next step's hidden state; mask = keep / (1 - p)
         output = F_.linear(h, p["captioner.fc.weight"], p["captioner.fc.bias"])  # :105
@@ -298,17 +306,22 @@ def _feature_fc(p: Dict[str, Tensor], features: Tensor) -> Tensor:
 
 
 def greedy_search(p: Dict[str, Tensor], cellw: Dict[str, Tensor], feats: Tensor,
-                  end_sentence: int = 2, max_sentence: int = 20) -> Tuple[List[int], List[Tensor]]:
+                  end_sentence: int = 2, max_sentence: int = 20,
+                  layers: Optional[Sequence[Dict[str, Tensor]]] = None) -> Tuple[List[int], List[Tensor]]:
     """AttentionGru.greedy_search, models/decoderlstm.py:138-175, for ONE image.  feats [1,P,F] are already
     feature_fc outputs (infer applies feature_fc first, :181).  The first input is embed(0) -- looked up,
     not zeroed (:150,156)."""
     sentence, weights = [], []
     word = torch.tensor([0])
     h = F_.linear(feats.mean(dim=1), p["captioner.init_h.weight"], p["captioner.init_h.bias"])
+    for lw in (layers or ()):                                            # :152-154
+        h = gru_cell(h, h, lw)
     while True:
         emb = p["captioner.embed.weight"][word]
         ctx, alpha = attention(p, feats, h)
         h = gru_cell(torch.cat([emb, ctx], dim=1), h, cellw)
+        for lw in (layers or ()):                                        # :161-163
+            h = gru_cell(h, h, lw)
         out = F_.linear(h, p["captioner.fc.weight"], p["captioner.fc.bias"])
         top = torch.log_softmax(out, dim=1)[0].topk(1)[1]
         sentence.append(int(top.item()))

@@ -302,3 +302,39 @@ def test_plain_train_step_protocol():
         assert torch.equal(p[f"hn_heads.{i}.0.bias"], p0[f"hn_heads.{i}.0.bias"])
     for n in ("hn_heads.0.2.weight", "hn_heads.3.2.bias", "hn_base.0.weight", "captioner.embed.weight"):
         assert not torch.equal(p[n], p0[n])
+
+
+def test_layers_case_oracle_matches_reference_module():
+    """AttentionGru(num_layers = 3): the oracle's `layers` path against the reference module's own outputs and gradients."""
+    g, _ = load_case("gru_layers")
+    dims = O.Dims(D=32, F=16, E=16, H=16, V=50, he=16)
+    names = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+    p = {"captioner." + k[2:]: v.clone().requires_grad_(True) for k, v in g.items()
+         if k.startswith("p/") and not k.startswith("p/gru.") and not k.startswith("p/layers.")}
+    cw = {n: g["p/gru." + n].clone().requires_grad_(True) for n in names}
+    layers = [{n: g[f"p/layers.{l}.{n}"].clone().requires_grad_(True) for n in names} for l in range(int(g["num_layers"]) - 1)]
+    assert len(layers) == 2
+    logits, alphas = O.decoder_forward(dims, p, cw, g["features"], g["captions"], layers=layers)
+    assert maxdiff(logits, g["logits"]) < 2e-5 and maxdiff(alphas, g["alphas"]) < 2e-6
+    loss = O.caption_loss(logits, g["captions"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    for k, v in p.items():
+        ref = g["g/" + k[len("captioner."):]]
+        assert maxdiff(v.grad, ref) < 2e-5 * max(1.0, float(ref.abs().max())), k
+    for l, lw in enumerate(layers):
+        for n, v in lw.items():
+            ref = g[f"g/layers.{l}.{n}"]
+            assert maxdiff(v.grad, ref) < 2e-5 * max(1.0, float(ref.abs().max())), (l, n)
+    T = g["captions"].shape[1]
+    with torch.no_grad():
+        lf, af = O.decoder_forward(dims, p, cw, g["features"], g["captions"], use_sampling=[True] * T, layers=layers)
+    assert maxdiff(lf, g["logits_free"]) < 5e-5 and maxdiff(af, g["alphas_free"]) < 5e-6
+    q = {k: v.detach().clone() for k, v in p.items()}
+    q["captioner.fc.bias"] = g["fc_bias_search"]
+    ff = O._feature_fc(q, g["features"])
+    for b in range(g["features"].shape[0]):
+        sent, wts = O.greedy_search(q, {k: v.detach() for k, v in cw.items()}, ff[b:b + 1], 2, 12,
+                                    layers=[{k: v.detach() for k, v in lw.items()} for lw in layers])
+        assert sent == g[f"greedy_{b}"].tolist()
+        assert maxdiff(torch.cat(wts, 0), g[f"greedy_w_{b}"]) < 5e-6

@@ -354,6 +354,58 @@ def lstm_full_case(name, seed):
             "oracle_vs_reference_on_lstm_tiny_max_abs": pin}
 
 
+def layers_case(name, seed, num_layers=3):
+    """Reference AttentionGru(num_layers > 1) (models/decoderlstm.py:34-36, :65-67, :101-103) with ORDINARY cell parameters (no
+    hypernet: the extra GRUCells are not generated in hypernet_attention.py, which builds its hypernet over captioner.gru only).
+    Teacher-forced logits / alphas / loss / all parameter gradients, the free-running forward, and greedy_search."""
+    dims = O.Dims(D=32, F=16, E=16, H=16, V=50, he=16)
+    B, T, P = 4, 7, 7
+    p = O.init_params(dims, seed)
+    batch = O.synth_batch(dims, B, T, P, seed=seed + 1)
+    feats, caps = batch["features"], batch["captions"]
+    torch.manual_seed(seed)
+    cap = AttentionGru(dims.D, dims.F, dims.E, dims.H, dims.V, num_layers=num_layers, p=0.0)
+    msd = {k[len("captioner."):]: v.clone() for k, v in p.items() if k.startswith("captioner.")}
+    res = cap.load_state_dict(msd, strict=False)
+    assert all(k.startswith("gru.") or k.startswith("layers.") for k in res.missing_keys), res
+    rng = np.random.default_rng(seed + 7)
+    with torch.no_grad():
+        for n, q in cap.named_parameters():
+            if n.startswith("gru.") or n.startswith("layers."):
+                q.copy_(torch.from_numpy(rng.uniform(-1.2, 1.2, size=tuple(q.shape)).astype(np.float32)))
+        # three stacked random cells squash h towards a fixed point: sharpen the token path so that decoded sequences differ
+        cap.embed.weight.mul_(8.0); cap.fc.weight.mul_(8.0)
+    arrs = {"features": feats, "captions": caps, "num_layers": np.int64(num_layers)}
+    for n, q in cap.named_parameters():
+        arrs["p/" + n] = q.detach().clone()
+    logits, alphas = cap(feats, caps.long(), 0.0)
+    loss = F.cross_entropy(logits.view(-1, dims.V), caps.view(-1).long(), ignore_index=0)
+    loss.backward()
+    arrs.update({"logits": logits, "alphas": alphas, "loss": loss})
+    for n, q in cap.named_parameters():
+        arrs["g/" + n] = q.grad.detach().clone()
+    with torch.no_grad():
+        lf, af = cap(feats, caps.long(), 1.0)          # np.random.random() < 1.0: every step t >= 1 samples
+    arrs["logits_free"] = lf; arrs["alphas_free"] = af
+    top2 = lf.topk(2, dim=-1)[0]
+    margin_free = float((top2[..., 0] - top2[..., 1])[:, :-1].min())
+    # greedy_search per image on feature_fc outputs, with </s> made reachable
+    cap.eval()
+    with torch.no_grad():
+        cap.fc.bias[2] += 4.0
+        arrs["fc_bias_search"] = cap.fc.bias.detach().clone()
+        ff = cap.feature_fc(feats)
+        lens = []
+        for b in range(B):
+            sent, wts = cap.greedy_search(ff[b:b + 1], 2, 12)
+            arrs[f"greedy_{b}"] = np.array(sent, dtype=np.int64)
+            arrs[f"greedy_w_{b}"] = torch.cat(wts, 0)
+            lens.append(len(sent))
+    save_npz(os.path.join(OUT, name + ".npz"), **arrs)
+    return {"num_layers": num_layers, "B": B, "T": T, "P": P, "greedy_lengths": lens, "loss": float(loss),
+            "min_top2_margin_free": margin_free}
+
+
 def ref_captioner(dims, p, x_style):
     """Reference AttentionGru with theta from the restated hypernet injected by the reference's own
     flip_parameters_to_tensors / set_all_parameters (as HyperNet.forward does, hypernet_attention.py:111-121)."""
@@ -644,6 +696,14 @@ def main():
             json.dump(meta, f, indent=1, sort_keys=True)
         print(json.dumps({k: v for k, v in meta["lstm_full"].items() if k != "grad_norms"}, indent=1))
         return
+    if "--only-layers" in sys.argv:            # AttentionGru(num_layers = 3)
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["gru_layers"] = layers_case("gru_layers", seed=57)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        print(json.dumps(meta["gru_layers"], indent=1))
+        return
     if "--only-plain" in sys.argv:             # refresh the hypernet.py / later.py vectors only
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -672,6 +732,7 @@ def main():
     odd = O.Dims(D=37, F=13, E=11, H=19, V=83, he=5)
     meta["gru_odd_cc"] = tiny_case("gru_odd_cc", odd, B=5, T=9, P=10, seed=31, flickr=False, max_norm=5.0)
     meta["lstm_tiny"] = lstm_case("lstm_tiny", seed=41)
+    meta["gru_layers"] = layers_case("gru_layers", seed=57)
     meta["gru_search"] = search_case("gru_search", tiny, n_images=6, P=7, seed=462, end_bump=SEARCH_END_BUMP, sharpen=SEARCH_SHARPEN)
     for nm, (dd, B, T, sd) in PLAIN_CASES.items():
         meta[nm] = plain_case(nm, O.PlainDims(**dd), B, T, sd)
