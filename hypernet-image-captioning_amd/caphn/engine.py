@@ -17,6 +17,8 @@ Memory layout (sized for HBM streaming):
 """
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import torch
 
 from . import dp, ops

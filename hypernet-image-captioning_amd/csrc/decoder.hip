@@ -17,8 +17,13 @@
 int g_tune_deterministic = 0;   // 1: bit-reproducible gradients -- no split-K (fp32 atomics), embedding gradient by a destination-major scan
 int g_tune_rec_pair = 1;     // 1 (default): two workgroups per caption in the recurrent kernels (recurrent_pair.hip)
 int g_tune_rec_rotate = 1;
-int g_tune_fork = 1;        // 0: one stream; 1 (default): independent branches on side streams, the dW_fc branch starting
-                            // after BPTT (measured 1-2 % better than 2: beside BPTT, where both fight for the same CUs)
+int g_tune_chain_main = 0;  // 1: with the hypernet VJP hooked in, the chain to it runs on the caller's stream (see "after BPTT");
+                            // measured 30 us per step WORSE than 0 (2.026/2.023 vs 1.996/1.994 ms, same box, alternating)
+int g_tune_fork = 4;        // 0: one stream; 1: independent branches on side streams, the vocabulary weight gradient (dW_fc) starting
+                            // after BPTT; 2: dW_fc beside BPTT; 3: as 1, the big leaves held back until df exists; 4 (default): 2 when
+                            // the pair kernels run BPTT (512-thread workgroups leave wave slots, registers and 60 KB of LDS per CU
+                            // for a GEMM workgroup: 1.987/2.004 -> 1.956/1.958 ms per step), else 1 (a 1024-thread BPTT workgroup
+                            // and the GEMM fight for the same CUs: 1-2 % worse, round 1)
 #define RUN(x) do { int _rc = (x); if (_rc != CAPHN_OK) return _rc; } while (0)
 
 namespace {
@@ -147,13 +152,13 @@ inline Ws layout(const caphn_decoder_dims* d) {
     auto take = [&](size_t n) { size_t r = o; o += up4(n); return r; };
     w.Y1 = take(raw ? 0 : B * P * F); w.f = take(raw ? 0 : B * P * F); w.meanf = take(B * F); w.h0 = take(B * H);
     w.c0 = take(lstm ? B * H : 0);
-    w.Waf = take(B * P * H); w.G = take(B * P * NG * H); w.Xe = take(B * T * E); w.Xg = take(B * T * NG * H);
+    w.Waf = take(B * P * H); w.G = take(B * P * NG * H); w.Xe = take(B * T * (E + F)); w.Xg = take(B * T * NG * H);     // Xc = [Xe | ctx] rows of E + F: the cell's input, one operand for dW_ih
     w.Hs = take(B * T * H); w.Hprev = take(B * T * H); w.gates = take(B * T * NG * H); w.hn = take(lstm ? 0 : B * T * H);
     w.Cs = take(lstm ? B * T * H : 0); w.Cprev = take(lstm ? B * T * H : 0);
     w.uah = take(B * T * H); w.alphas = take(B * T * P); w.idx = take(2 * B * T);   // int64
     w.dHs = take(B * T * H); w.dgi = take(B * T * NG * H); w.dgh = take(lstm ? 0 : B * T * NG * H); w.duah = take(B * T * H);
     w.de = take(B * T * P); w.dh0 = take(B * H); w.dc0 = take(lstm ? B * H : 0);
-    w.ctx = take(B * T * F); w.dctx = take(raw ? 0 : B * T * F);
+    w.ctx = w.Xe + E; w.dctx = take(raw ? 0 : B * T * F);
     w.dXe = take(B * T * E); w.dWaf = take(B * P * H); w.dmeanf = take(raw ? 0 : B * F); w.df = take(raw ? 0 : B * P * F);
     w.dY1 = take(raw ? 0 : B * P * F);
     w.pchunk = 1; w.npc = (int)((P + w.pchunk - 1) / w.pchunk);     // one workgroup per (caption, position)
@@ -440,8 +445,8 @@ static int decoder_inputs(const caphn_decoder_dims* d, const caphn_decoder_param
     const int BT = d->B * d->T, E = d->E, GH = w.NG * d->H, EF = d->E + d->F;
     int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
     hipLaunchKernelGGL(build_idx_kernel, dim3((BT + 255) / 256), dim3(256), 0, s, d->B, d->T, captions, idx);
-    RUN(caphn_embedding_gather(BT, E, p->embed_w, idx, ws + w.Xe, s));
-    RUN(caphn_gemm_f32(0, 1, BT, GH, E, ws + w.Xe, E, p->w_ih, EF, ws + w.Xg, GH, p->b_ih, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    RUN(caphn_embedding_gather_strided(BT, E, p->embed_w, idx, 1, ws + w.Xe, EF, s));
+    RUN(caphn_gemm_f32(0, 1, BT, GH, E, ws + w.Xe, EF, p->w_ih, EF, ws + w.Xg, GH, p->b_ih, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
     return CAPHN_OK;
 }
 
@@ -591,7 +596,8 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     // vocab projection.  dHs = dlogits W feeds BPTT (main); dW = dlogits^T Hs and db = colsum(dlogits) are only
     // needed by the optimiser: branch 0 computes them beside the BPTT kernel, which occupies B of the 256 CUs.
     const int* rmap = d->row_subset ? reinterpret_cast<const int*>(ws + w.rowmap) : nullptr;
-    const bool late = g_tune_fork != 2;
+    const int fork_mode = g_tune_fork == 4 ? (pair ? 2 : 1) : g_tune_fork;
+    const bool late = fork_mode != 2;
     const bool gz = d->grads_zeroed != 0;
     if (!late) {
         RUN(sd.forkto(0));
@@ -641,83 +647,88 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     } else
     RUN(caphn_launch_rec_bwd(a, lstm, s));
 
-    // ---- after BPTT.  Only  attn_param_grads -> df -> dY1 -> dW_fc0  is a true chain (main stream); every other
-    // product is a leaf of it.  Leaves run on branches 0-2; E0..E4 are record/wait events between streams.
-    //   E2 dWaf ready (main)   E3 dW_ih ready (b2)   E4 df ready (main)
+    // ---- after BPTT.  Two chains and their leaves:
+    //   sT  ctx -> dW_ih (-> d theta complete once dW_hh is) -> hypernet VJP: the longest one, on branch 1 (caphn_tune(15, 1) puts it
+    //       on the caller's stream instead: measured slower).
+    //   sF  attn_param_grads -> df -> dY1 -> dW_fc0 (attention / feature_fc), on the caller's stream.
+    //   b2  dW_hh, then the embedding gradient and the leaves of sF;  b0  vocabulary gradients (beside or after BPTT) and BPTT's leaves.
+    // Events: E2 dWaf ready (sF)   E3 dW_hh ready (b2)   E4 df ready (sF).  Column-sum scratch: cw0 sF, cw1 sT, cw2 b2, cws b0.
     hipStream_t b0 = sd.s(0), b1 = sd.s(1), b2 = sd.s(2);
-    const bool hold_big = late && !raw && g_tune_fork == 3;   // 3: release the two big leaves only once df exists (measured: no gain)
-    if (late) RUN(sd.fork_many({0, 1, 2})); else RUN(sd.fork_many({1, 2}));
+    const bool t_main = hook != nullptr && g_tune_chain_main != 0;
+    hipStream_t sT = t_main ? s : b1, sF = t_main ? b1 : s;
+    const bool hold_big = late && !raw && fork_mode == 3;   // 3: release the two big leaves only once df exists (measured: no gain)
+    RUN(sd.fork_many({0, 1, 2}));
     if (late && !hold_big) {   // the optimiser-only vocab gradients
         RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0, gz));
         RUN(sd.milestone(CAPHN_MS_VOCAB, b0));
     }
-    if (!raw) {
-        // The chain's own small inputs stay on the chain's stream: waiting on a side-stream event here stalled
-        // the chain for ~275 us in the kernel trace although the producers had long finished.
-        RUN(caphn_gemm_f32(0, 0, BT, F, GH, dgi, GH, p->w_ih + E, EF, ws + w.dctx, F, nullptr, nullptr, 0, 0, 1, s));
-        RUN(caphn_launch_dmean(B, H, F, ws + w.dh0, p->inith_w, lstm ? ws + w.dc0 : nullptr, lstm ? p->initc_w : nullptr,
-                               ws + w.dmeanf, s));
-    }
-    // main: attention parameter gradients (dWaf, partial d v_a)
-    AttnGradArgs ag;
-    ag.T = T; ag.P = P; ag.H = H; ag.pchunk = w.pchunk;
-    ag.Waf = ws + w.Waf; ag.uah = ws + w.uah; ag.de = ws + w.de; ag.v_a = p->va_w;
-    ag.dWaf = ws + w.dWaf; ag.part = ws + w.apart;
-    if (ang == 0) RUN(caphn_launch_attn_param_grads(ag, B, w.npc, s));
-    RUN(sd.record(2, s));
-    // b2 -- input weights dW_ih[:, :E] = dgi^T Xe, dW_ih[:, E:] = dgi^T ctx; embedding gradient
-    RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, b2));
-    if (lstm) RUN(gemm_auto(1, 0, GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, nullptr, 0, b2, nullptr, 0, gz));
-    else RUN(wgrad_bias(GH, E, BT, dgi, GH, ws + w.Xe, E, g->w_ih, EF, g->b_ih, nullptr, cw2, b2, gz));      // + db_ih
-    RUN(gemm_auto(1, 0, GH, F, BT, dgi, GH, ws + w.ctx, F, g->w_ih + E, EF, nullptr, 0, b2, nullptr, 0, gz));
+    // sT -- input weights dW_ih = dgi^T [Xe | ctx] (ctx lands beside the embeddings, so this is ONE GEMM: two back to back on the
+    // chain to d theta cost 72 + 57 us)
+    RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, EF, sT));
+    if (lstm) RUN(gemm_auto(1, 0, GH, EF, BT, dgi, GH, ws + w.Xe, EF, g->w_ih, EF, nullptr, 0, sT, nullptr, 0, gz));
+    else RUN(wgrad_bias(GH, EF, BT, dgi, GH, ws + w.Xe, EF, g->w_ih, EF, g->b_ih, nullptr, cw1, sT, gz));      // + db_ih
+    // b2 -- recurrent weights dW_hh = dgh^T Hprev (+ db_hh), then the embedding gradient
+    RUN(wgrad_bias(GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, g->b_hh, nullptr, cw2, b2, gz));
+    if (lstm) RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cw2, b2));      // dgh aliases dgi: db_ih == db_hh
     RUN(sd.record(3, b2));
     RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, b2));
     if (!gz) RUN(caphn_zero_f32(g->embed_w, (size_t)V * E, b2));
     RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, b2));
     RUN(sd.milestone(CAPHN_MS_EMBED, b2));
-    // b1 -- recurrent weights dW_hh = dgh^T Hprev, dU_a = duah^T Hprev, biases by column sums; init_h / init_c
-    RUN(wgrad_bias(GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, g->b_hh, nullptr, cw1, b1, gz));
-    if (lstm) RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cw1, b1));      // dgh aliases dgi: db_ih == db_hh
-    // dL/dtheta = [dW_ih | dW_hh | db_ih | db_hh] is complete once E3 has fired on top of b1's own work so far: a
+    // dL/dtheta = [dW_ih | dW_hh | db_ih | db_hh] is complete once E3 has fired on top of sT's own work so far: a
     // data-parallel caller starts its all-gather of the rank-1 row factors here (CAPHN_MS_DTHETA)
-    RUN(sd.wait(3, b1));
-    RUN(sd.milestone(CAPHN_MS_DTHETA, b1));
+    RUN(sd.wait(3, sT));
+    RUN(sd.milestone(CAPHN_MS_DTHETA, sT));
     if (hook && !hold_big) {
-        // the hypernet VJP (HBM-bound transposed GEMV over the 576 MB of second-layer weights) runs here, beside
-        // the main chain
-        RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, b1));
+        // the hypernet VJP (HBM-bound transposed GEMV over the 576 MB of second-layer weights), beside the sF chain
+        RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, sT));
     }
-    if (!hold_big) RUN(sd.milestone(CAPHN_MS_HYPER, b1));
-    RUN(wgrad_bias(H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, g->Ua_b, nullptr, cw1, b1, gz));
+    if (!hold_big) RUN(sd.milestone(CAPHN_MS_HYPER, sT));
+    // sF -- the chain's own small inputs stay on the chain's stream: waiting on a side-stream event here stalled the chain for
+    // ~275 us in the kernel trace although the producers had long finished
+    if (!raw) {
+        RUN(caphn_gemm_f32(0, 0, BT, F, GH, dgi, GH, p->w_ih + E, EF, ws + w.dctx, F, nullptr, nullptr, 0, 0, 1, sF));
+        RUN(caphn_launch_dmean(B, H, F, ws + w.dh0, p->inith_w, lstm ? ws + w.dc0 : nullptr, lstm ? p->initc_w : nullptr,
+                               ws + w.dmeanf, sF));
+    }
+    // attention parameter gradients (dWaf, partial d v_a) when the BPTT kernel did not fuse them
+    AttnGradArgs ag;
+    ag.T = T; ag.P = P; ag.H = H; ag.pchunk = w.pchunk;
+    ag.Waf = ws + w.Waf; ag.uah = ws + w.uah; ag.de = ws + w.de; ag.v_a = p->va_w;
+    ag.dWaf = ws + w.dWaf; ag.part = ws + w.apart;
+    if (ang == 0) RUN(caphn_launch_attn_param_grads(ag, B, w.npc, sF));
+    RUN(sd.record(2, sF));
+    // b0 -- leaves of BPTT that nothing else waits for (behind the vocabulary gradients when those run after BPTT)
+    RUN(wgrad_bias(H, H, BT, ws + w.duah, H, ws + w.Hprev, H, g->Ua_w, H, g->Ua_b, nullptr, cws, b0, gz));
     for (int l = 0; l < w.L1; ++l) {     // extra cells: one transposed GEMM over all B (T + 1) slots per weight
         const int BS = B * (T + 1), G3 = 3 * H;
-        RUN(wgrad_bias(G3, H, BS, ws + w.Ldgi[l], G3, ws + w.Lin[l], H, g->lw_ih[l], H, g->lb_ih[l], nullptr, cw1, b1, gz));
-        RUN(wgrad_bias(G3, H, BS, ws + w.Ldgh[l], G3, ws + w.Lin[l], H, g->lw_hh[l], H, g->lb_hh[l], nullptr, cw1, b1, gz));
+        RUN(wgrad_bias(G3, H, BS, ws + w.Ldgi[l], G3, ws + w.Lin[l], H, g->lw_ih[l], H, g->lb_ih[l], nullptr, cws, b0, gz));
+        RUN(wgrad_bias(G3, H, BS, ws + w.Ldgh[l], G3, ws + w.Lin[l], H, g->lw_hh[l], H, g->lb_hh[l], nullptr, cws, b0, gz));
     }
-    RUN(wgrad_bias(H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, g->inith_b, nullptr, cw1, b1, gz));
-    if (lstm) RUN(wgrad_bias(H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, g->initc_b, nullptr, cw1, b1, gz));
-    // main -- df = alpha^T dctx + dmean/P + dWaf W_a, then feature_fc backward
+    RUN(wgrad_bias(H, F, B, ws + w.dh0, H, ws + w.meanf, F, g->inith_w, F, g->inith_b, nullptr, cws, b0, gz));
+    if (lstm) RUN(wgrad_bias(H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, g->initc_b, nullptr, cws, b0, gz));
+    // sF -- df = alpha^T dctx + dmean/P + dWaf W_a, then feature_fc backward
     if (!raw) {
-        RUN(caphn_launch_df(B, T, P, F, ws + w.alphas, ws + w.dctx, ws + w.dmeanf, ws + w.df, s));
-        RUN(caphn_gemm_f32(0, 0, BP, F, H, ws + w.dWaf, H, p->Wa_w, F, ws + w.df, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, s));
-        RUN(sd.record(4, s));
+        RUN(caphn_launch_df(B, T, P, F, ws + w.alphas, ws + w.dctx, ws + w.dmeanf, ws + w.df, sF));
+        RUN(caphn_gemm_f32(0, 0, BP, F, H, ws + w.dWaf, H, p->Wa_w, F, ws + w.df, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, sF));
+        RUN(sd.record(4, sF));
         if (hold_big) {
             // The chain's small kernels are starved while big leaf kernels fill the machine (a 160-275 us stall of
             // df_kernel in the kernel trace), so the latency-critical front of the chain runs first; the optimiser-only
-            // vocab gradients (b0) and the hypernet VJP (b1) start here, beside the two remaining chain GEMMs.
+            // vocab gradients (b0) and the hypernet VJP (sT) start here, beside the two remaining chain GEMMs.
             RUN(sd.wait(4, b0));
             RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0, gz));
             RUN(sd.milestone(CAPHN_MS_VOCAB, b0));
             if (hook) {
-                RUN(sd.wait(4, b1));
-                RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, b1));
+                RUN(sd.wait(4, sT));
+                RUN(caphn_hyper_backward(hook->hd, g->w_ih, hook->acts, hook->hg, hook->ws, sT));
             }
-            RUN(sd.milestone(CAPHN_MS_HYPER, b1));
+            RUN(sd.milestone(CAPHN_MS_HYPER, sT));
         }
-        RUN(caphn_gemm_f32(0, 0, BP, F, F, ws + w.df, F, p->fc2_w, F, ws + w.dY1, F, nullptr, ws + w.Y1, F, CAPHN_GEMM_MASK, 1, s));
-        RUN(wgrad_bias(F, D, BP, ws + w.dY1, F, features, D, g->fc0_w, D, g->fc0_b, nullptr, cw0, s, gz));
+        RUN(caphn_gemm_f32(0, 0, BP, F, F, ws + w.df, F, p->fc2_w, F, ws + w.dY1, F, nullptr, ws + w.Y1, F, CAPHN_GEMM_MASK, 1, sF));
+        RUN(wgrad_bias(F, D, BP, ws + w.dY1, F, features, D, g->fc0_w, D, g->fc0_b, nullptr, cw0, sF, gz));
     }
-    // b2 (leaves of the chain) -- d v_a, d b_va, dW_a, db_Wa once dWaf exists; fc2 gradients once df exists
+    // b2 (leaves of sF) -- d v_a, d b_va, dW_a, db_Wa once dWaf exists; fc2 gradients once df exists
     RUN(sd.wait(2, b2));
     RUN(caphn_colsum_f32(B * (ang > 0 ? ang : w.npc), H + 1, ws + w.apart, H + 1, ws + w.vtmp, cw2, b2));
     hipLaunchKernelGGL(copy2_kernel, dim3((H + 256) / 256), dim3(256), 0, b2, ws + w.vtmp, H, g->va_w, g->va_b);   // one launch, no runtime blits
@@ -856,8 +867,8 @@ extern "C" int caphn_decoder_forward_sampled_train(const caphn_decoder_dims* d, 
         else if (!lstm) { src_mode = 2; src_col = t - 1; }
         // x_t: token id -> idx[b, t] -> Xe[b, t, :] -> x-side gate pre-activations of step t
         hipLaunchKernelGGL(next_token_kernel, dim3(B), dim3(256), 0, s, B, T, V, src_mode, src_col, captions, logits, idx + t, T);
-        RUN(caphn_embedding_gather_strided(B, E, p->embed_w, idx + t, T, ws + w.Xe + (size_t)t * E, T * E, s));
-        RUN(caphn_gemm_f32(0, 1, B, GH, E, ws + w.Xe + (size_t)t * E, T * E, p->w_ih, EF, ws + w.Xg + (size_t)t * GH, T * GH, p->b_ih,
+        RUN(caphn_embedding_gather_strided(B, E, p->embed_w, idx + t, T, ws + w.Xe + (size_t)t * EF, T * EF, s));
+        RUN(caphn_gemm_f32(0, 1, B, GH, E, ws + w.Xe + (size_t)t * EF, T * EF, p->w_ih, EF, ws + w.Xg + (size_t)t * GH, T * GH, p->b_ih,
                            nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
         a.t0 = t; a.t1 = t + 1;
         if (pair) RUN(caphn_launch_rec_pair_fwd(a, lstm, s)); else RUN(caphn_launch_rec_fwd(a, lstm, s));

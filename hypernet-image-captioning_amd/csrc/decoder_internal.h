@@ -103,7 +103,7 @@ int caphn_launch_rec_pair_fwd(const RecFwdArgs& a, bool lstm, hipStream_t s);
 int caphn_launch_rec_pair_bwd(const RecBwdArgs& a, bool lstm, hipStream_t s);
 int caphn_rec_bwd_groups(int P, int H);     // > 0: the backward kernel can fuse the attention parameter gradients (rows of `apart` per caption)
 int caphn_launch_attn_param_grads(const AttnGradArgs& a, int B, int npc, hipStream_t s);
-int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const float* f, float* ctx, hipStream_t s);
+int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const float* f, float* ctx, int ldc, hipStream_t s);   // ctx rows at pitch ldc
 int caphn_launch_df(int B, int T, int P, int F, const float* alphas, const float* dctx, const float* dmean, float* df, hipStream_t s);
 int caphn_launch_dmean(int B, int H, int F, const float* dh0, const float* Wh, const float* dc0, const float* Wc, float* out, hipStream_t s);
 int caphn_launch_init_state(int B, int P, int F, int H, const float* f, const float* Wh, const float* bh, const float* Wc,

@@ -564,6 +564,8 @@ extern int g_tune_rec_pair;
 extern int g_tune_gemm_single;
 extern int g_tune_gemm_tile;
 extern int g_tune_deterministic;
+extern int g_tune_adam_cap;
+extern int g_tune_chain_main;
 extern int g_det_vocab;
 int caphn_rec_pair_debug_skip(int v);
 extern "C" int caphn_tune(int key, int value) {
@@ -580,5 +582,7 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 11) { g_tune_gemm_single = value; return CAPHN_OK; }
     if (key == 12) { g_tune_gemm_tile = value; return CAPHN_OK; }
     if (key == 13) { g_tune_deterministic = value > 0; g_det_vocab = value; return CAPHN_OK; }
+    if (key == 15) { g_tune_chain_main = value != 0; return CAPHN_OK; }
+    if (key == 14) { if (value < 64 || value > 65535) return CAPHN_EINVAL; g_tune_adam_cap = value; return CAPHN_OK; }
     return CAPHN_EINVAL;
 }

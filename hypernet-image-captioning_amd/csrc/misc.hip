@@ -637,6 +637,7 @@ __global__ __launch_bounds__(256) void rowdot_kernel(int rows, int k, const floa
 }
 
 }  // namespace
+int g_tune_adam_cap = 4096;   // workgroups of one rank-1 Adam launch (grid-stride over rows): fewer leave wave slots for a side stream
 int g_tune_adam = 6;   // measured on 240000x480 after the occupancy fix: 6 (non-temporal, 2 rows/iteration) 497 us,
                        // 3 (non-temporal, 1 row) 508 us, 0 (plain) 541 us
 namespace {
@@ -865,7 +866,7 @@ static int adam_rank_launch(int R, int rows, int k, float* W, float* m, float* v
     const int vec = (k % 4 == 0) && (lda % 4 == 0) && caphn_aligned16(W) && caphn_aligned16(m) && caphn_aligned16(v) && caphn_aligned16(afac)
                     && (!nx.a || caphn_aligned16(nx.a));
     long nb = ((long)rows + 3) / 4;
-    if (nb > 4096) nb = 4096;
+    if (nb > g_tune_adam_cap) nb = g_tune_adam_cap;
     if (nb < 1) nb = 1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const AdamK K = make_adam(hp);

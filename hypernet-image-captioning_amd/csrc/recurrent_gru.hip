@@ -532,7 +532,8 @@ __global__ __launch_bounds__(256) void dmean_kernel(int H, int F, const float* _
 }
 
 // ctx[b,t,k] = sum_p alpha[b,t,p] f[b,p,k]
-__global__ void ctx_kernel(int P, int F, int T, const float* __restrict__ alphas, const float* __restrict__ f, float* __restrict__ ctx) {
+__global__ void ctx_kernel(int P, int F, int T, const float* __restrict__ alphas, const float* __restrict__ f, float* __restrict__ ctx,
+                           int ldc) {
     const int b = blockIdx.x, t = blockIdx.y;
     const float* al = alphas + ((size_t)b * T + t) * P;
     for (int k = threadIdx.x; k < F; k += blockDim.x) {
@@ -546,7 +547,7 @@ __global__ void ctx_kernel(int P, int F, int T, const float* __restrict__ alphas
             for (int u = 0; u < 8; ++u) s += al[p + u] * v[u];
         }
         for (; p < P; ++p) s += al[p] * f[((size_t)b * P + p) * F + k];
-        ctx[((size_t)b * T + t) * F + k] = s;
+        ctx[((size_t)b * T + t) * ldc + k] = s;
     }
 }
 // df[b,p,k] = sum_t alpha[b,t,p] dctx[b,t,k] + dmean[b,k] / P
@@ -686,8 +687,8 @@ int caphn_launch_dmean(int B, int H, int F, const float* dh0, const float* Wh, c
     hipLaunchKernelGGL(dmean_kernel, dim3(B), dim3(256), sizeof(float) * 2 * H, s, H, F, dh0, Wh, dc0, Wc, out);
     return caphn_launch_status();
 }
-int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const float* f, float* ctx, hipStream_t s) {
-    hipLaunchKernelGGL(ctx_kernel, dim3(B, T), dim3(F >= 192 ? 256 : 64), 0, s, P, F, T, alphas, f, ctx);
+int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const float* f, float* ctx, int ldc, hipStream_t s) {
+    hipLaunchKernelGGL(ctx_kernel, dim3(B, T), dim3(F >= 192 ? 256 : 64), 0, s, P, F, T, alphas, f, ctx, ldc);
     return caphn_launch_status();
 }
 int caphn_launch_df(int B, int T, int P, int F, const float* alphas, const float* dctx, const float* dmean, float* df, hipStream_t s) {

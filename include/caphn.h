@@ -464,7 +464,11 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * Adam and the master weights stay fp32), 0 = the fp32-class six-product default, key 12: forced GEMM tile (experiments), key 13: DETERMINISTIC gradients -- value V > 0 (the
  * vocabulary size) turns split-K off in the decoder composites (its partial products are summed with fp32 atomics) and computes
  * the embedding gradient by a destination-major scan of the V table rows instead of atomic scatter-adds: gradients are then
- * bit-identical from run to run, at a cost in speed; 0 = off).  Defaults are the measured-fastest. */
+ * bit-identical from run to run, at a cost in speed; 0 = off), key 14: workgroup cap of one rank-1 Adam launch (64..65535, default
+ * 4096), key 15: 1 = caphn_decoder_hyper_backward runs the chain to the hypernet VJP on the caller's stream and the
+ * attention / feature_fc chain on a side stream, 0 (default) = the other way round; key 4 values: 0 one stream, 1 vocabulary weight
+ * gradient after BPTT, 2 beside BPTT, 3 big leaves held back, 4 (default) 2 with the pair recurrent kernels else 1.
+ * Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
 /* ---------------------------------------------------------------------------------------

@@ -30,6 +30,14 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), short(r["Kernel_Name"]),
                          int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])) * max(1, int(r["Grid_Size_Y"])) * max(1, int(r["Grid_Size_Z"])),
                          int(r["Workgroup_Size_X"]), int(r["VGPR_Count"]), int(r["LDS_Block_Size"])))
+    # memory copies (rocprofv3 --memory-copy-trace writes <prefix>_memory_copy_trace.csv next to the kernel trace)
+    mc = args.csv.replace("kernel_trace", "memory_copy_trace")
+    import os
+    if mc != args.csv and os.path.exists(mc):
+        with open(mc) as f:
+            for r in csv.DictReader(f):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), -1, "COPY " + r.get("Direction", "") + " " + r.get("Size", ""),
+                             0, 0, 0, 0))
     rows.sort()
     # the arena zero fill is the biggest zero_kernel launch of a step
     marks = [i for i, r in enumerate(rows) if r[3].startswith(args.marker) and r[4] >= 256]
