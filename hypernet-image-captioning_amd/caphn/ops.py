@@ -717,8 +717,13 @@ def _hp(lr, betas, eps, step, dev_scalars=None):
 
 
 def adam_scalars(lr, betas, step):
-    """Host values of the two step-dependent Adam scalars {lr / (1 - b1^t), sqrt(1 - b2^t)}."""
-    return float(lr / (1.0 - betas[0] ** step)), float((1.0 - betas[1] ** step) ** 0.5)
+    """Host values of the two step-dependent Adam scalars {lr / (1 - b1^t), sqrt(1 - b2^t)}, computed exactly as the library
+    computes them when they travel by value (make_adam in csrc/misc.hip: the betas of caphn_adam_hparams are C floats, the powers
+    and the square root are taken in double) -- a captured step that reads them from device memory then updates bit-identically
+    to an eagerly launched one."""
+    import math
+    b1, b2, lrf = float(C.c_float(betas[0]).value), float(C.c_float(betas[1]).value), float(C.c_float(lr).value)
+    return float(lrf / (1.0 - math.pow(b1, float(step)))), float(math.sqrt(1.0 - math.pow(b2, float(step))))
 
 
 def adam_dense(p, m, v, g, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_scalars=None) -> None:

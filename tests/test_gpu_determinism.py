@@ -61,3 +61,26 @@ def test_gradients_are_bit_identical_in_deterministic_mode():
         assert torch.equal(p1, tr2.flat_p)
     finally:
         assert lib.caphn_tune(13, 0) == 0
+
+
+def test_graph_replay_equals_eager_bit_for_bit_in_deterministic_mode():
+    """A race detector for the composites' side streams: with the atomics out of the way (caphn_tune 13), five steps replayed from
+    a captured hipGraph and five eagerly launched steps must leave bit-identical parameters -- any ordering bug between the
+    forked branches (fork modes, milestones, the pair kernels' hand-offs) would show as a difference."""
+    from caphn import _lib
+    lib = _lib.load()
+    dims = O.Dims(D=64, F=32, E=24, H=32, V=300, he=8)
+    p = O.init_params(dims, seed=31)
+    batch = O.synth_batch(dims, B=16, T=9, P=12, seed=32)
+    feats, caps = batch["features"].to(DEV), batch["captions"].to(DEV)
+    x = torch.zeros(dims.he, device=DEV); x[1] = 1.0
+    try:
+        assert lib.caphn_tune(13, dims.V) == 0
+        ta, tb = _trainer(dims, p), _trainer(dims, p)
+        la = [float(ta.step(feats, caps, x_style=x)[0]) for _ in range(5)]
+        lb = [float(tb.step_graphed(feats, caps, x_style=x)[0]) for _ in range(5)]
+        assert len(tb._graphs) == 1
+        assert la == lb
+        assert torch.equal(ta.flat_p, tb.flat_p)
+    finally:
+        assert lib.caphn_tune(13, 0) == 0

@@ -189,7 +189,9 @@ def test_graph_replayed_step_matches_eager():
     assert la[0] == lb[0]
     assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
     assert la[-1] < la[0]
-    assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 1e-4
+    # (two runs with fp32-atomic gradient sums: Adam turns last-bit noise on near-zero gradients into visible steps of up to lr
+    #  each; tests/test_gpu_determinism.py makes the same comparison bit-exact with the atomics switched off)
+    assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 5e-4
 
 
 def test_graph_capture_after_eager_steps_that_left_side_work_pending():
