@@ -651,7 +651,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     //   sT  ctx -> dW_ih (-> d theta complete once dW_hh is) -> hypernet VJP: the longest one, on branch 1 (caphn_tune(15, 1) puts it
     //       on the caller's stream instead: measured slower).
     //   sF  attn_param_grads -> df -> dY1 -> dW_fc0 (attention / feature_fc), on the caller's stream.
-    //   b2  dW_hh, then the embedding gradient and the leaves of sF;  b0  vocabulary gradients (beside or after BPTT) and BPTT's leaves.
+    //   b2  dW_hh, then the leaves of sF;  b0  vocabulary gradients (beside or after BPTT), the embedding gradient, BPTT's leaves.
     // Events: E2 dWaf ready (sF)   E3 dW_hh ready (b2)   E4 df ready (sF).  Column-sum scratch: cw0 sF, cw1 sT, cw2 b2, cws b0.
     hipStream_t b0 = sd.s(0), b1 = sd.s(1), b2 = sd.s(2);
     const bool t_main = hook != nullptr && g_tune_chain_main != 0;
@@ -671,10 +671,13 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     RUN(wgrad_bias(GH, H, BT, dgh, GH, ws + w.Hprev, H, g->w_hh, H, g->b_hh, nullptr, cw2, b2, gz));
     if (lstm) RUN(caphn_colsum_f32(BT, GH, dgi, GH, g->b_ih, cw2, b2));      // dgh aliases dgi: db_ih == db_hh
     RUN(sd.record(3, b2));
-    RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, b2));
-    if (!gz) RUN(caphn_zero_f32(g->embed_w, (size_t)V * E, b2));
-    RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, b2));
-    RUN(sd.milestone(CAPHN_MS_EMBED, b2));
+    // b0 -- the embedding gradient first (7.7 MB, the second-largest bucket of a data-parallel exchange: its milestone should
+    // come as early as BPTT allows), on b2 when the vocabulary gradients occupy b0 after BPTT
+    hipStream_t se = late ? b2 : b0;
+    RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, se));
+    if (!gz) RUN(caphn_zero_f32(g->embed_w, (size_t)V * E, se));
+    RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, se));
+    RUN(sd.milestone(CAPHN_MS_EMBED, se));
     // dL/dtheta = [dW_ih | dW_hh | db_ih | db_hh] is complete once E3 has fired on top of sT's own work so far: a
     // data-parallel caller starts its all-gather of the rank-1 row factors here (CAPHN_MS_DTHETA)
     RUN(sd.wait(3, sT));

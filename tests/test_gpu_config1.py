@@ -135,3 +135,38 @@ def test_grunet_literal_training_step_trains_through_the_sampled_call(T):
         assert maxdiff(got[k[len("captioner."):]].grad.cpu(), v.grad) < 1e-5, k
     for k, v in cw.items():
         assert maxdiff(got["gru." + k].grad.cpu(), v.grad) < 1e-5, k
+
+
+def test_grunet_two_layers_bs8():
+    """train_gru.py's own --num_layers default is 2 (:114): GruNet(..., num_layers=2) adds one GRUCell applied as h = layer(h, h)
+    to the initial state and at every step (models/decoderlstm.py:34-36, :65-67, :101-103)."""
+    from models.decoderlstm import GruNet
+    torch.manual_seed(3)
+    V = 300
+    net = GruNet(2048, 64, 48, 56, V, num_layers=2, p=0.0)
+    dims = O.Dims(D=2048, F=64, E=48, H=56, V=V, he=48)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    p = {"captioner." + k: v for k, v in sd.items() if not k.startswith("gru.") and not k.startswith("layers.")}
+    cellw = {k[4:]: v for k, v in sd.items() if k.startswith("gru.")}
+    layers = [{k[len("layers.0."):]: v for k, v in sd.items() if k.startswith("layers.0.")}]
+    batch = O.synth_batch(dims, B=8, T=12, P=49, seed=7)
+    feats, caps = batch["features"], batch["captions"]
+    net = net.to(DEV).train()
+    out = net(feats.to(DEV), caps.to(DEV), 0.0)
+    assert isinstance(out, torch.Tensor) and out.shape == (8, 12, V)
+    loss = F.cross_entropy(out.view(-1, V), caps.to(DEV).view(-1), ignore_index=0)
+    loss.backward()
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    cw = {k: v.clone().requires_grad_(True) for k, v in cellw.items()}
+    lw = [{k: v.clone().requires_grad_(True) for k, v in layers[0].items()}]
+    ref, _ = O.decoder_forward(dims, q, cw, feats, caps, layers=lw)
+    ref_loss = O.caption_loss(ref, caps)
+    ref_loss.backward()
+    assert maxdiff(out.detach().cpu(), ref.detach()) < 5e-6 and abs(float(loss) - float(ref_loss)) < 2e-6
+    got = dict(net.named_parameters())
+    for k, v in q.items():
+        assert maxdiff(got[k[len("captioner."):]].grad.cpu(), v.grad) < 5e-6, k
+    for k, v in cw.items():
+        assert maxdiff(got["gru." + k].grad.cpu(), v.grad) < 5e-6, k
+    for k, v in lw[0].items():
+        assert maxdiff(got["layers.0." + k].grad.cpu(), v.grad) < 5e-6, k
