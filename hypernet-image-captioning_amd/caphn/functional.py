@@ -139,12 +139,16 @@ class _PlainDecoderFn(torch.autograd.Function):
     """DecoderGRU / DecoderRNN forward with teacher forcing   later.py:394-447 / :254-317"""
 
     @staticmethod
-    def forward(ctx, dims, features, captions, h0, c0, *tensors):
+    def forward(ctx, dims, opts, features, captions, h0, c0, *tensors):
         params = {n: t.detach().contiguous() for n, t in zip(dims.names(), tensors)}
         features = features.detach().contiguous()
         captions = captions.contiguous()
         ws = ops.plain_workspace(dims, features.device)
-        logits = ops.plain_forward(dims, params, features, captions, h0, c0, ws)
+        if opts is not None and opts.get("seed") is not None:
+            # teacher_forcing=False: words drawn per step; the workspace keeps their ids for the backward
+            logits, opts["chosen"] = ops.plain_forward_sampled(dims, params, features, h0, c0, ws, opts["seed"])
+        else:
+            logits = ops.plain_forward(dims, params, features, captions, h0, c0, ws)
         ctx.dims, ctx.ws, ctx.params, ctx.features, ctx.captions, ctx.h0, ctx.c0 = dims, ws, params, features, captions, h0, c0
         ctx.need_f = True
         return logits
@@ -157,14 +161,16 @@ class _PlainDecoderFn(torch.autograd.Function):
         dfeat = torch.empty_like(ctx.features)
         ops.plain_backward(dims, ctx.params, ctx.features, ctx.captions, ctx.h0, ctx.c0, dlogits.contiguous(), grads, ctx.ws, dfeat)
         ctx.ws = None
-        return (None, dfeat, None, None, None) + tuple(grads[n] for n in dims.names())
+        return (None, None, dfeat, None, None, None) + tuple(grads[n] for n in dims.names())
 
 
-def plain_decoder_forward(dims: ops.PlainDims, features, captions, h0, c0, named: Dict[str, torch.Tensor]):
+def plain_decoder_forward(dims: ops.PlainDims, features, captions, h0, c0, named: Dict[str, torch.Tensor], sample=None):
+    """sample: {"seed": int} selects the teacher_forcing=False forward (one word drawn per caption and step from the previous
+    step's softmax); the ids fed are returned in sample["chosen"] [B,T]."""
     if not features.is_cuda:
         raise CaphnError("DecoderGRU / DecoderRNN run on libcaphn's HIP kernels only: move the module and its inputs to a "
                          "CUDA(HIP) device (there is no CPU fallback)")
-    return _PlainDecoderFn.apply(dims, features.float(), captions.long(), h0, c0, *[named[n] for n in dims.names()])
+    return _PlainDecoderFn.apply(dims, sample, features.float(), captions.long(), h0, c0, *[named[n] for n in dims.names()])
 
 
 class _MLPFn(torch.autograd.Function):

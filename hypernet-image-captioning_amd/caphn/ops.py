@@ -863,6 +863,22 @@ def plain_forward(dims: PlainDims, params: Dict[str, torch.Tensor], features: to
     return logits
 
 
+def plain_forward_sampled(dims: PlainDims, params: Dict[str, torch.Tensor], features: torch.Tensor, h0: torch.Tensor,
+                          c0: Optional[torch.Tensor], ws: torch.Tensor, seed: int):
+    """DecoderGRU / DecoderRNN forward with teacher_forcing=False (later.py:418-431 / :290-301): from step 1 on the input is the
+    embedding of a word drawn from softmax(out_{t-1}).  -> (logits [B,T,V], chosen [B,T] int64: the id fed at step t, -1 at 0).
+    The draws follow the kernel's counter-based hash of (seed, b, t), not torch.multinomial's Philox stream."""
+    lib = L.load()
+    cd = dims.c()
+    ps = _plain_struct(L.PlainParams, dims, params)
+    logits = _f32(dims.B, dims.T, dims.V, device=features.device)
+    chosen = torch.empty(dims.B, dims.T, dtype=torch.int64, device=features.device)
+    L.check(lib.caphn_plain_forward_sampled(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(h0), L.ptr(c0, allow_none=True),
+                                            C.c_uint64(int(seed) & (2 ** 64 - 1)), L.ptr(logits), L.ptr(chosen, torch.int64),
+                                            C.c_void_p(ws.data_ptr()), L.stream_ptr()), "caphn_plain_forward_sampled")
+    return logits, chosen
+
+
 def plain_backward(dims: PlainDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,
                    h0: torch.Tensor, c0: Optional[torch.Tensor], dlogits: torch.Tensor, grads: Dict[str, torch.Tensor],
                    ws: torch.Tensor, dfeatures: Optional[torch.Tensor] = None) -> None:

@@ -138,6 +138,67 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(int B, int H, int T
     dc[i] = dcv * fg;
 }
 
+// Step t >= 1 of the sampled forward: one workgroup per caption draws id ~ softmax(logits[b, t-1, :]) by inverse CDF and copies
+// that word's embedding into the step's x row.  Thread i owns the contiguous chunk [i c, (i + 1) c) of the vocabulary.
+__global__ __launch_bounds__(256) void sample_word_kernel(int B, int T, int V, int E, int t, const float* __restrict__ logits,
+                                                         unsigned long long seed, const float* __restrict__ table,
+                                                         float* __restrict__ X, int64_t* __restrict__ idx, int64_t* __restrict__ chosen) {
+    __shared__ float red[256];
+    __shared__ float pre[257];
+    __shared__ int pick;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + ((size_t)b * T + (t - 1)) * V;
+    const int c = (V + 255) / 256, v0 = min(tid * c, V), v1 = min(v0 + c, V);
+    float mx = -INFINITY;
+    for (int v = v0; v < v1; ++v) mx = fmaxf(mx, row[v]);
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    float sl = 0.f;
+    for (int v = v0; v < v1; ++v) sl += caphn_exp(row[v] - mx);
+    red[tid] = sl;
+    if (tid == 0) pick = -1;
+    __syncthreads();
+    if (tid == 0) {                 // exclusive prefix over the 256 chunk sums, in order (deterministic)
+        float acc = 0.f;
+        for (int i = 0; i < 256; ++i) { pre[i] = acc; acc += red[i]; }
+        pre[256] = acc;
+    }
+    __syncthreads();
+    // u in [0, 1): the 24 high bits of splitmix64(seed, b T + t)
+    unsigned long long z = seed + ((unsigned long long)b * T + t) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float target = (float)(z >> 40) * (1.0f / 16777216.0f) * pre[256];
+    if (v0 < v1 && pre[tid] <= target && target < pre[tid + 1]) {
+        float acc = pre[tid];
+        int sel = v1 - 1;
+        for (int v = v0; v < v1; ++v) { acc += caphn_exp(row[v] - mx); if (acc > target) { sel = v; break; } }
+        pick = sel;
+    }
+    __syncthreads();
+    int id = pick;
+    if (id < 0) {                   // target landed on the total by rounding: the last word with a non-zero weight
+        id = V - 1;
+    }
+    if (tid == 0) {
+        idx[(size_t)t * B + b] = id;
+        if (chosen) chosen[(size_t)b * T + t] = id;
+    }
+    const float* src = table + (size_t)id * E;
+    float* dst = X + ((size_t)t * B + b) * E;
+    for (int e = tid; e < E; e += 256) dst[e] = src[e];
+}
+__global__ __launch_bounds__(256) void plain_first_input_kernel(int B, int T, int E, const float* __restrict__ feats, float* __restrict__ X,
+                                                               int64_t* __restrict__ idx, int64_t* __restrict__ chosen) {
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) { idx[b] = -1; if (chosen) chosen[(size_t)b * T] = -1; }
+    for (int e = threadIdx.x; e < E; e += 256) X[(size_t)b * E + e] = feats[(size_t)b * E + e];
+}
+
 inline int pick_sk(int M, int N, int K) {
     const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
     long s = (512 + t64 - 1) / t64;
@@ -158,6 +219,9 @@ inline int wgrad(int M, int N, int K, const float* A, int lda, const float* B, i
 }
 
 }  // namespace
+
+static int plain_cells_step(const caphn_plain_dims* d, const caphn_plain_params* p, const PWs& w, float* ws, int t,
+                            const float* h0, const float* c0, hipStream_t s);
 
 extern "C" size_t caphn_plain_workspace_bytes(const caphn_plain_dims* d) {
     if (!pdims_ok(d)) return 0;
@@ -181,7 +245,47 @@ extern "C" int caphn_plain_forward(const caphn_plain_dims* d, const caphn_plain_
                        reinterpret_cast<int64_t*>(ws + w.idx));
     // x side of layer 0 for every step at once
     RUN(caphn_gemm_f32(0, 1, TB, GH, E, ws + w.X, E, p->w_ih[0], E, ws + w.Xg, GH, p->b_ih[0], nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    for (int t = 0; t < T; ++t) RUN(plain_cells_step(d, p, w, ws, t, h0, c0, s));
+    // vocabulary projection for all (b, t)          later.py:441 / :311
+    RUN(caphn_gemm_f32(0, 1, B * T, V, H, ws + w.Hbt, H, p->out_w, H, logits, V, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    (void)nb; (void)L;
+    return caphn_launch_status();
+}
+
+extern "C" int caphn_plain_forward_sampled(const caphn_plain_dims* d, const caphn_plain_params* p, const float* features,
+                                           const float* h0, const float* c0, unsigned long long seed, float* logits,
+                                           int64_t* chosen, void* ws_, caphn_stream_t stream) {
+    if (!pdims_ok(d) || !p || !features || !h0 || !logits || !ws_) return CAPHN_EINVAL;
+    const bool lstm = d->cell == CAPHN_CELL_LSTM;
+    if (lstm && !c0) return CAPHN_EINVAL;
+    if (!p->embed_w || !p->out_w || !p->out_b) return CAPHN_EINVAL;
+    for (int l = 0; l < d->L; ++l) if (!p->w_ih[l] || !p->w_hh[l] || !p->b_ih[l] || !p->b_hh[l]) return CAPHN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const PWs w = playout(d);
+    float* ws = static_cast<float*>(ws_);
+    const int B = d->B, T = d->T, E = d->E, H = d->H, V = d->V, L = d->L, GH = w.NG * H;
+    int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
     for (int t = 0; t < T; ++t) {
+        // x_t: the image embedding, then the embedding of a word drawn from softmax(out_{t-1})          later.py:418-426
+        if (t == 0) hipLaunchKernelGGL(plain_first_input_kernel, dim3(B), dim3(256), 0, s, B, T, E, features, ws + w.X, idx, chosen);
+        else hipLaunchKernelGGL(sample_word_kernel, dim3(B), dim3(256), 0, s, B, T, V, E, t, logits, seed, p->embed_w, ws + w.X, idx, chosen);
+        RUN(caphn_gemm_f32(0, 1, B, GH, E, ws + w.X + (size_t)t * B * E, E, p->w_ih[0], E, ws + w.Xg + (size_t)t * B * GH, GH, p->b_ih[0],
+                           nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+        RUN(plain_cells_step(d, p, w, ws, t, h0, c0, s));
+        // out_t = fc_out(h_t): rows (b, t) of the [B,T,V] logits, read by the next step's draw
+        RUN(caphn_gemm_f32(0, 1, B, V, H, ws + w.Hl[L - 1] + (size_t)t * B * H, H, p->out_w, H, logits + (size_t)t * V, T * V, p->out_b,
+                           nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    }
+    return caphn_launch_status();
+}
+
+// every cell of step t (layer 0 from the x-side pre-activations in Xg, the extra layers on their own input)
+static int plain_cells_step(const caphn_plain_dims* d, const caphn_plain_params* p, const PWs& w, float* ws, int t,
+                            const float* h0, const float* c0, hipStream_t s) {
+    const bool lstm = d->cell == CAPHN_CELL_LSTM;
+    const int B = d->B, T = d->T, H = d->H, L = d->L, GH = w.NG * H;
+    const int nb = (B * H + 255) / 256;
+    {
         const size_t oG = (size_t)t * B * GH, oH = (size_t)t * B * H;
         for (int l = 0; l < L; ++l) {
             // layer 0: h = cell(x_t, h_prev); layer l >= 1: h = layer(h, h)          later.py:413-416
@@ -203,9 +307,7 @@ extern "C" int caphn_plain_forward(const caphn_plain_dims* d, const caphn_plain_
             }
         }
     }
-    // vocabulary projection for all (b, t)          later.py:441 / :311
-    RUN(caphn_gemm_f32(0, 1, B * T, V, H, ws + w.Hbt, H, p->out_w, H, logits, V, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
-    return caphn_launch_status();
+    return CAPHN_OK;
 }
 
 extern "C" int caphn_plain_backward(const caphn_plain_dims* d, const caphn_plain_params* p, const float* features,

@@ -102,13 +102,10 @@ class HyperNet(_Base):
         style_embed = self.captioner.embed(style)
         self.forward(style_embed)
         img_feats = self.image_encoder(imgs.float())
-        # hypernet.py:134-137 draws np.random.binomial(1, teacher_forcing_proba) and, on a 0, runs the sampled branch
-        # (torch.multinomial per step, later.py:424-426).  The draw is made (same RNG consumption); the sampled branch is
-        # not fused, so such a step is teacher forced here -- said out loud, not silently.
-        if not np.random.binomial(1, self.teacher_forcing_proba):
-            warnings.warn("hypernet.HyperNet.training_step: the reference would have taken the sampled (torch.multinomial) "
-                          "branch for this step; this build teacher-forces it", RuntimeWarning, stacklevel=2)
-        caps_pred = self.captioner(img_feats, caps.long(), True)
+        # hypernet.py:134-137: np.random.binomial(1, teacher_forcing_proba) decides between teacher forcing and the sampled
+        # branch (a word drawn per step from the previous step's softmax, later.py:424-426)
+        teacher_forcing = bool(np.random.binomial(1, self.teacher_forcing_proba))
+        caps_pred = self.captioner(img_feats, caps.long(), teacher_forcing)
         loss = CF.cross_entropy(caps_pred.view(-1, self.hparams['vocab_size']), caps.view(-1).long())
         if self.teacher_forcing_proba > 0.25:
             self.teacher_forcing_proba = self.teacher_forcing_proba * 0.9995

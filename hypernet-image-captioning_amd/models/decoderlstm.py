@@ -242,15 +242,20 @@ class _PlainDecoder(nn.Module):
         raise NotImplementedError
 
     def forward(self, features, captions, teacher_forcing=True):
-        if not teacher_forcing:
-            raise NotImplementedError("the sampled branch draws torch.multinomial per step (later.py:424-426); only teacher "
-                                      "forcing is fused")
+        """teacher_forcing=False (later.py:418-431 / :290-301): from step 1 on the cell's input is the embedding of a word drawn
+        from softmax(out_{t-1}) -- torch.multinomial in the reference, the kernel's counter-based inverse-CDF draw here (same
+        distribution, another random stream); the ids fed are kept in self.last_sampled [B,T]."""
         if self.dropout:
             raise NotImplementedError("dropout=True is not supported by the fused HIP path (hypernet.py:51 passes False)")
         B, T = captions.shape
         dims = ops.PlainDims(B, T, self.embed_size, self.hidden_size, self.vocab_size, self.num_layers, self._cell)
         h0, c0 = self._initial_state(B, features)
-        return CF.plain_decoder_forward(dims, features, captions, h0, c0, self._named_tensors())
+        if teacher_forcing:
+            return CF.plain_decoder_forward(dims, features, captions, h0, c0, self._named_tensors())
+        sample = {"seed": CF.next_seed()}
+        out = CF.plain_decoder_forward(dims, features, captions, h0, c0, self._named_tensors(), sample=sample)
+        self.last_sampled = sample["chosen"]
+        return out
 
 
 class DecoderGRU(_PlainDecoder):

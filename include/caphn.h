@@ -371,6 +371,16 @@ size_t caphn_plain_workspace_bytes(const caphn_plain_dims* d);
 int caphn_plain_forward(const caphn_plain_dims* d, const caphn_plain_params* p, const float* features,
                         const int64_t* captions, const float* h0, const float* c0, float* logits, void* ws,
                         caphn_stream_t stream);
+/* The forward with teacher_forcing = False (later.py:418-431 / :290-301): from step 1 on the input is the embedding of a word
+ * drawn from softmax(out_{t-1}) (torch.multinomial(pred, 1)), not of the caption's.  The draw of (b, t) is the inverse CDF at
+ * the uniform number the counter-based hash of (seed, b T + t) gives -- the same distribution as torch.multinomial, NOT torch's
+ * Philox stream, so the reference's draws cannot be reproduced (parity: given the ids drawn here, everything equals the
+ * teacher-forced forward over them).  chosen [B,T] (optional): chosen[b,t] = the id fed at step t (t >= 1; -1 at t = 0).
+ * The workspace is left as caphn_plain_forward leaves it with those ids in place of the caption's: caphn_plain_backward
+ * applies unchanged (no gradient flows through the draw, as in the reference's autograd graph). */
+int caphn_plain_forward_sampled(const caphn_plain_dims* d, const caphn_plain_params* p, const float* features,
+                                const float* h0, const float* c0, unsigned long long seed, float* logits,
+                                int64_t* chosen, void* ws, caphn_stream_t stream);
 /* Needs the workspace as the forward left it.  Gradient buffers are distinct (non-aliasing) arrays. */
 int caphn_plain_backward(const caphn_plain_dims* d, const caphn_plain_params* p, const float* features,
                          const int64_t* captions, const float* h0, const float* c0, const float* dlogits,

@@ -131,8 +131,13 @@ def test_module_api_hypernet_py(name):
             assert maxdiff(sd[k[5:]].grad.cpu(), v) < ATOL, k
         elif k.startswith("gint_rows/"):
             assert maxdiff(sd[k[10:]].grad.cpu()[:32], v) < ATOL, k
-    with pytest.raises(NotImplementedError):
-        cap(feats, caps, False)
+    # teacher_forcing=False (later.py:418-431): a word drawn per step; the ids fed are valid and the call is differentiable
+    cap = net(net.captioner.embed(style))              # fresh theta: the first backward freed the hypernet's graph
+    out = cap(feats, caps, False)
+    ids = cap.last_sampled
+    assert out.shape == logits.shape and ids.shape == caps.shape
+    assert bool((ids[:, 0] == -1).all()) and bool((ids[:, 1:] >= 0).all()) and bool((ids[:, 1:] < d.V).all())
+    F.cross_entropy(out.view(-1, d.V), caps.view(-1)).backward()
 
 
 @pytest.mark.parametrize("cell,L", [("gru", 1), ("gru", 3), ("lstm", 2)])
@@ -214,3 +219,85 @@ def test_hypernet_py_literal_configuration():
     assert float(g.abs().max()) > 0
     assert all(float(net.hn_heads[i][2].weight.grad.abs().sum()) == 0.0 for i in range(4, 8))
     assert bool(torch.isfinite(loss))
+
+
+@pytest.mark.parametrize("cell,L", [("gru", 2), ("lstm", 1)])
+def test_sampled_branch_equals_teacher_forcing_over_the_drawn_ids(cell, L):
+    """teacher_forcing=False (later.py:418-431 / :290-301): x_t = embed(w), w ~ softmax(out_{t-1}).  The kernel's draws come from
+    its own counter-based stream (torch.multinomial's Philox stream cannot be reproduced: parity with the reference's DRAWS is
+    unpinned); given the ids it drew, logits and every gradient must equal the oracle's teacher-forced pass over those ids
+    with the loss still taken against the caption -- which is the reference's autograd graph (nothing flows through the draw)."""
+    from caphn import ops
+    d = O.PlainDims(E=40, H=36, V=333, L=L, cell=cell)
+    p = O.init_plain_params(d, 8)
+    rng = np.random.default_rng(12)
+    B, T = 16, 9
+    feats = torch.from_numpy(rng.standard_normal((B, d.E), dtype=np.float32))
+    caps = torch.from_numpy(rng.integers(0, d.V, size=(B, T)))
+    h0 = torch.from_numpy(rng.random((B, d.H), dtype=np.float32))
+    c0 = torch.zeros(B, d.H) if cell == "lstm" else None
+    _, _, theta, _, _ = O.plain_forward_backward(d, p, feats, caps, h0, c0, 4)
+    cells = [{n: (3.0 * t).contiguous() for n, t in cw.items()} for cw in O.plain_inject(d, theta.to(DEV))]     # sharper softmax
+    params = {"embed.weight": p["captioner.embed.weight"].to(DEV), "fc_out.weight": (4.0 * p["captioner.fc_out.weight"]).to(DEV),
+              "fc_out.bias": p["captioner.fc_out.bias"].to(DEV)}
+    for li, cw in enumerate(cells):
+        for n, t in cw.items():
+            params[("lstm_cell." if li == 0 else f"layers.{li - 1}.") + n] = t
+    pd = ops.PlainDims(B, T, d.E, d.H, d.V, L, cell)
+    ws = ops.plain_workspace(pd, DEV)
+    f, c, h = feats.to(DEV), caps.to(DEV), h0.to(DEV)
+    cz = c0.to(DEV) if c0 is not None else None
+    lg, ids = ops.plain_forward_sampled(pd, params, f, h, cz, ws, seed=0xABCDEF)
+    lg2, ids2 = ops.plain_forward_sampled(pd, params, f, h, cz, ops.plain_workspace(pd, DEV), seed=0xABCDEF)
+    assert torch.equal(ids, ids2) and torch.equal(lg, lg2)                      # a seed fixes the draws
+    _, ids3 = ops.plain_forward_sampled(pd, params, f, h, cz, ops.plain_workspace(pd, DEV), seed=0xABCDF0)
+    assert not torch.equal(ids, ids3)
+    assert bool((ids[:, 0] == -1).all()) and bool((ids[:, 1:] >= 0).all()) and bool((ids[:, 1:] < d.V).all())
+    assert len(torch.unique(ids[:, 1:])) > 20                                   # not an argmax in disguise
+    # oracle: teacher forcing over the drawn ids (the id fed at step t sits in column t - 1 of the caption it replaces)
+    eff = caps.clone()
+    eff[:, :T - 1] = ids[:, 1:].cpu()
+    q = {k: v.clone() for k, v in p.items()}
+    q["captioner.fc_out.weight"] = 4.0 * q["captioner.fc_out.weight"]
+    q = {k: v.requires_grad_(True) for k, v in q.items()}
+    ocells = [{n: t.detach().cpu().clone().requires_grad_(True) for n, t in cw.items()} for cw in cells]
+    fr = feats.clone().requires_grad_(True)
+    ref = O.plain_decoder_forward(d, q, ocells, fr, eff, h0, c0)
+    assert maxdiff(lg.cpu(), ref.detach()) < 2e-5
+    rl = torch.nn.functional.cross_entropy(ref.view(-1, d.V), caps.view(-1))
+    rl.backward()
+    l2, dl = ops.cross_entropy_fwd_bwd(lg.view(B * T, d.V), c.view(-1), ignore_index=-100)
+    assert abs(float(l2[0]) - float(rl)) < 1e-5
+    gr = {n: torch.empty(s, device=DEV) for n, s in pd.param_shapes().items()}
+    df = torch.empty_like(f)
+    ops.plain_backward(pd, params, f, c, h, cz, dl.view(B, T, d.V), gr, ws, df)
+    assert maxdiff(df.cpu(), fr.grad) < 1e-5
+    assert maxdiff(gr["fc_out.weight"].cpu(), q["captioner.fc_out.weight"].grad) < 1e-5
+    assert maxdiff(gr["embed.weight"].cpu(), q["captioner.embed.weight"].grad) < 1e-5
+    for li, cw in enumerate(ocells):
+        for n, t in cw.items():
+            assert maxdiff(gr[("lstm_cell." if li == 0 else f"layers.{li - 1}.") + n].cpu(), t.grad) < 1e-5, (li, n)
+
+
+def test_sampled_words_follow_the_softmax():
+    """The draw itself: 4096 captions share one logits row; the histogram of the words drawn at step 1 matches softmax(out_0)."""
+    from caphn import ops
+    d = O.PlainDims(E=16, H=16, V=50, L=1, cell="gru")
+    p = O.init_plain_params(d, 3)
+    B, T = 4096, 2
+    rng = np.random.default_rng(5)
+    feats = torch.from_numpy(rng.standard_normal((1, d.E), dtype=np.float32)).repeat(B, 1).to(DEV)
+    h0 = torch.from_numpy(rng.random((1, d.H), dtype=np.float32)).repeat(B, 1).to(DEV)
+    params = {"embed.weight": p["captioner.embed.weight"].to(DEV), "fc_out.weight": (6.0 * p["captioner.fc_out.weight"]).to(DEV),
+              "fc_out.bias": p["captioner.fc_out.bias"].to(DEV)}
+    g = torch.Generator().manual_seed(1)
+    for n, shape in (("weight_ih", (3 * d.H, d.E)), ("weight_hh", (3 * d.H, d.H)), ("bias_ih", (3 * d.H,)), ("bias_hh", (3 * d.H,))):
+        params["lstm_cell." + n] = ((torch.rand(shape, generator=g) - 0.5) * 1.5).to(DEV)
+    pd = ops.PlainDims(B, T, d.E, d.H, d.V, 1, "gru")
+    lg, ids = ops.plain_forward_sampled(pd, params, feats, h0, None, ops.plain_workspace(pd, DEV), seed=77)
+    prob = torch.softmax(lg[0, 0].double().cpu(), 0)
+    assert float((lg[:, 0] - lg[0, 0]).abs().max()) == 0.0
+    hist = torch.bincount(ids[:, 1].cpu(), minlength=d.V).double() / B
+    assert float(prob.max()) < 0.6 and int((prob > 0.02).sum()) >= 5            # a real distribution, several likely words
+    # binomial standard error of a frequency is sqrt(p (1 - p) / B) <= 0.0078: allow 4.5 sigma
+    assert float((hist - prob).abs().max()) < 4.5 * 0.0078, (hist, prob)
