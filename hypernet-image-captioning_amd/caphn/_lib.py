@@ -132,6 +132,8 @@ SIGNATURES = {
                                               c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "caphn_plain_workspace_bytes": (C.c_size_t, [C.POINTER(PlainDims)]),
     "caphn_plain_forward": (C.c_int, [C.POINTER(PlainDims), C.POINTER(PlainParams), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_bahdanau_fwd": (C.c_int, [C.c_int] * 4 + [c_fp] * 8),
+    "caphn_bahdanau_bwd": (C.c_int, [C.c_int] * 4 + [c_fp] * 12),
     "caphn_plain_forward_sampled": (C.c_int, [C.POINTER(PlainDims), C.POINTER(PlainParams), c_fp, c_fp, c_fp, C.c_uint64, c_fp, c_fp,
                                                c_fp, c_fp]),
     "caphn_plain_backward": (C.c_int, [C.POINTER(PlainDims), C.POINTER(PlainParams), c_fp, c_fp, c_fp, c_fp, c_fp,

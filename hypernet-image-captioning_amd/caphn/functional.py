@@ -92,6 +92,49 @@ def attention_gru_forward(dims: ops.DecDims, features: torch.Tensor, captions: t
     return _DecoderFn.apply(dims, features.float(), captions.long(), *[named[n] for n in dims.names()])
 
 
+class _BahdanauFn(torch.autograd.Function):
+    """BahdanauAttention.forward   models/attention.py:21-46: every step a libcaphn call (two GEMMs + the fused score / softmax /
+    context kernel forward; its gradient kernel, two fused weight-gradient GEMMs and two data-gradient GEMMs backward)."""
+
+    @staticmethod
+    def forward(ctx, features, hidden, wa_w, wa_b, ua_w, ua_b, va_w, va_b):
+        f = features.detach().contiguous().float()
+        h = hidden.detach().contiguous().float()
+        B, P, Fd = f.shape
+        waf = ops.gemm(f.view(B * P, Fd), wa_w.detach().contiguous(), False, True, bias=wa_b.detach().contiguous()).view(B, P, -1)
+        uah = ops.gemm(h, ua_w.detach().contiguous(), False, True, bias=ua_b.detach().contiguous())
+        v = va_w.detach().reshape(-1).contiguous()
+        c, alpha = ops.bahdanau_fwd(f, waf, uah, v, va_b.detach().contiguous())
+        ctx.save_for_backward(f, h, wa_w, ua_w, va_w, waf, uah, alpha)
+        ctx.need = (features.requires_grad, hidden.requires_grad)
+        return c, alpha
+
+    @staticmethod
+    def backward(ctx, dctx, dalpha):
+        f, h, wa_w, ua_w, va_w, waf, uah, alpha = ctx.saved_tensors
+        B, P, Fd = f.shape
+        H = uah.shape[1]
+        if dctx is None:
+            dctx = torch.zeros(B, Fd, device=f.device)
+        v = va_w.detach().reshape(-1).contiguous()
+        dwaf, duah, part, df = ops.bahdanau_bwd(f, waf, uah, v, alpha, dctx.contiguous().float(),
+                                                dalpha.contiguous().float() if dalpha is not None else None, ctx.need[0])
+        dWa, dba = ops.linear_wgrad(dwaf.view(B * P, H), f.view(B * P, Fd))
+        dUa, dbu = ops.linear_wgrad(duah, h)
+        dv = ops.colsum(part)
+        if df is not None:      # + the path through W_a
+            ops.gemm(dwaf.view(B * P, H), wa_w.detach().contiguous(), out=df.view(B * P, Fd), accumulate=True)
+        dh = ops.gemm(duah, ua_w.detach().contiguous()) if ctx.need[1] else None
+        return df, dh, dWa, dba, dUa, dbu, dv[:H].view_as(va_w), dv[H:H + 1]
+
+
+def bahdanau_attention(features, hidden, W_a, U_a, v_a):
+    """W_a, U_a, v_a: the module's nn.Linear layers (v_a with one output)."""
+    if not features.is_cuda:
+        raise CaphnError("BahdanauAttention.forward runs on libcaphn's HIP kernels only (no CPU fallback)")
+    return _BahdanauFn.apply(features, hidden, W_a.weight, W_a.bias, U_a.weight, U_a.bias, v_a.weight, v_a.bias)
+
+
 class _HyperFn(torch.autograd.Function):
     """theta = cat_i head_i(hn_base(x))   hypernet_attention.py:111-118"""
 

@@ -141,6 +141,30 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor):
     return dw, db
 
 
+def bahdanau_fwd(f: torch.Tensor, waf: torch.Tensor, uah: torch.Tensor, v_a: torch.Tensor, b_va: torch.Tensor):
+    """(ctx [B,F], alpha [B,P]) from features f [B,P,F], waf [B,P,H] = W_a f + b, uah [B,H] = U_a h + b (models/attention.py:34-46)."""
+    lib = L.load()
+    B, P, Fd = f.shape
+    H = uah.shape[1]
+    ctx, alpha = _f32(B, Fd, device=f.device), _f32(B, P, device=f.device)
+    L.check(lib.caphn_bahdanau_fwd(B, P, Fd, H, L.ptr(f), L.ptr(waf), L.ptr(uah), L.ptr(v_a), L.ptr(b_va), L.ptr(ctx), L.ptr(alpha),
+                                   L.stream_ptr()), "caphn_bahdanau_fwd")
+    return ctx, alpha
+
+
+def bahdanau_bwd(f, waf, uah, v_a, alpha, dctx, dalpha, want_df: bool):
+    """-> (dWaf [B,P,H], duah [B,H], part [B,H+1] (d v_a | d b_va partials per caption), df [B,P,F] or None)."""
+    lib = L.load()
+    B, P, Fd = f.shape
+    H = uah.shape[1]
+    dwaf, duah, part = _f32(B, P, H, device=f.device), _f32(B, H, device=f.device), _f32(B, H + 1, device=f.device)
+    df = _f32(B, P, Fd, device=f.device) if want_df else None
+    L.check(lib.caphn_bahdanau_bwd(B, P, Fd, H, L.ptr(f), L.ptr(waf), L.ptr(uah), L.ptr(v_a), L.ptr(alpha), L.ptr(dctx),
+                                   L.ptr(dalpha, allow_none=True), L.ptr(dwaf), L.ptr(duah), L.ptr(part),
+                                   L.ptr(df, allow_none=True), L.stream_ptr()), "caphn_bahdanau_bwd")
+    return dwaf, duah, part, df
+
+
 def colsum(a: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = L.load()
     M, N = a.shape

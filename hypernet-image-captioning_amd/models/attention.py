@@ -1,13 +1,13 @@
 """BahdanauAttention with the reference's constructor, sub-module names and return tuple
-(models/attention.py:5-46).  Inside AttentionGru's teacher-forced loop the arithmetic is fused
-into libcaphn's persistent recurrent kernel; this stand-alone forward serves callers that step
-the decoder by hand (beam search, hypernet_attention.py:264-272) and composes libcaphn GEMMs
-with torch pointwise ops."""
+(models/attention.py:5-46).  Inside AttentionGru's loops the arithmetic is fused into libcaphn's
+recurrent kernels; this stand-alone forward serves callers that step a decoder by hand (beam search,
+hypernet_attention.py:264-272) and runs on libcaphn too: two GEMMs and one fused score / softmax /
+context kernel, differentiable (caphn.functional.bahdanau_attention)."""
 import torch
 from torch import nn
 from torch.nn import functional as F
 
-from caphn import ops
+from caphn import functional as CF
 
 
 class BahdanauAttention(nn.Module):
@@ -22,16 +22,6 @@ class BahdanauAttention(nn.Module):
 
     def forward(self, features, decoder_hidden):
         """features [B,P,F], decoder_hidden [B,H] -> (context [B,F], atten_weight [B,P])."""
-        if features.is_cuda and not torch.is_grad_enabled():
-            B, P, Fd = features.shape
-            f2 = features.reshape(B * P, Fd).contiguous().float()
-            atten_1 = ops.gemm(f2, self.W_a.weight, False, True, bias=self.W_a.bias).view(B, P, -1)
-            atten_2 = ops.gemm(decoder_hidden.contiguous().float(), self.U_a.weight, False, True,
-                               bias=self.U_a.bias).unsqueeze(1)
-        else:
-            atten_1 = self.W_a(features)
-            atten_2 = self.U_a(decoder_hidden.unsqueeze(1))
-        atten_score = self.v_a(torch.tanh(atten_1 + atten_2))
-        atten_weight = F.softmax(atten_score, dim=1)
-        context = torch.sum(atten_weight * features, dim=1)
-        return context, atten_weight.squeeze(dim=2)
+        if self.output_dim != 1:
+            raise NotImplementedError("BahdanauAttention with output_dim != 1 (the reference only builds 1, models/attention.py:9)")
+        return CF.bahdanau_attention(features, decoder_hidden, self.W_a, self.U_a, self.v_a)

@@ -387,6 +387,19 @@ int caphn_plain_backward(const caphn_plain_dims* d, const caphn_plain_params* p,
                          const caphn_plain_grads* g, void* ws, caphn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Stand-alone BahdanauAttention.forward (models/attention.py:21-46) behind its two Linear layers (callers that step a decoder
+ * by hand; AttentionGru's own loops have it fused in the recurrent kernels):
+ *   Waf [B,P,H] = W_a f + b, uah [B,H] = U_a h + b   ->   alpha [B,P] = softmax_p(v_a . tanh(Waf_p + uah) + b_va),
+ *   ctx [B,F] = sum_p alpha_p f_p.
+ * Backward: dctx [B,F], dalpha [B,P] (or NULL) -> dWaf [B,P,H], duah [B,H], part [B,H+1] (per-caption partials of d v_a and, in
+ * column H, d b_va: the caller sums them over B), df [B,P,F] (or NULL) = alpha_p dctx, the direct path into the features. */
+int caphn_bahdanau_fwd(int B, int P, int F, int H, const float* f, const float* Waf, const float* uah, const float* v_a,
+                       const float* b_va, float* ctx, float* alpha, caphn_stream_t stream);
+int caphn_bahdanau_bwd(int B, int P, int F, int H, const float* f, const float* Waf, const float* uah, const float* v_a,
+                       const float* alpha, const float* dctx, const float* dalpha, float* dWaf, float* duah, float* part,
+                       float* df, caphn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Loss: F.cross_entropy(logits.view(-1,V), caps.view(-1), ignore_index)   [hypernet_attention.py:183,
  * cc_train_hypernet.py:153].  Writes the mean loss to loss_out[0], the number of non-ignored
  * targets to loss_out[1], and d loss / d logits to dlogits (may alias logits).

@@ -492,3 +492,40 @@ def test_host_running_ahead_of_the_gpu_changes_nothing():
     for x, y in zip(la, lb):
         assert abs(x - y) <= 2e-5 * abs(x), (la, lb)
     assert maxdiff(pa.cpu(), pb.cpu()) < 5e-3
+
+
+@pytest.mark.parametrize("B,P,Fd,H", [(5, 49, 200, 200), (3, 7, 13, 19), (2, 130, 24, 70)])
+def test_standalone_bahdanau_attention_forward_backward(B, P, Fd, H):
+    """models.attention.BahdanauAttention.forward stepped by hand (models/attention.py:21-46): context, weights and every
+    gradient (parameters, features, hidden state; through context AND through the returned weights) against the reference's
+    formula evaluated by torch in fp64."""
+    from models.attention import BahdanauAttention
+    torch.manual_seed(B * 100 + P)
+    att = BahdanauAttention(Fd, H).to(DEV)
+    with torch.no_grad():
+        att.v_a.weight.mul_(3.0)
+    feats = torch.randn(B, P, Fd, device=DEV, requires_grad=True)
+    hid = torch.randn(B, H, device=DEV, requires_grad=True)
+    wc, wa = torch.randn(B, Fd, device=DEV), torch.randn(B, P, device=DEV)
+    ctx, alpha = att(feats, hid)
+    assert ctx.shape == (B, Fd) and alpha.shape == (B, P)
+    ((ctx * wc).sum() + (alpha * wa).sum()).backward()
+    # the reference's arithmetic in fp64
+    p64 = {n: q.detach().double().cpu().requires_grad_(True) for n, q in att.named_parameters()}
+    f64, h64 = feats.detach().double().cpu().requires_grad_(True), hid.detach().double().cpu().requires_grad_(True)
+    a1 = F.linear(f64, p64["W_a.weight"], p64["W_a.bias"])
+    a2 = F.linear(h64.unsqueeze(1), p64["U_a.weight"], p64["U_a.bias"])
+    sc = F.linear(torch.tanh(a1 + a2), p64["v_a.weight"], p64["v_a.bias"])
+    w = F.softmax(sc, dim=1)
+    c = torch.sum(w * f64, dim=1)
+    ((c * wc.double().cpu()).sum() + (w.squeeze(2) * wa.double().cpu()).sum()).backward()
+    assert maxdiff(ctx.detach().cpu(), c.detach()) < 5e-6 and maxdiff(alpha.detach().cpu(), w.squeeze(2).detach()) < 2e-6
+    assert abs(float(alpha.sum()) - B) < 1e-4
+    tol = lambda ref: 2e-5 * max(1.0, float(ref.abs().max()))
+    assert maxdiff(feats.grad.cpu(), f64.grad) < tol(f64.grad)
+    assert maxdiff(hid.grad.cpu(), h64.grad) < tol(h64.grad)
+    for n, q in att.named_parameters():
+        assert maxdiff(q.grad.cpu(), p64[n].grad) < tol(p64[n].grad), n
+    with torch.no_grad():
+        c2, a2_ = att(feats, hid)
+    assert torch.equal(c2, ctx.detach()) and torch.equal(a2_, alpha.detach())
