@@ -28,6 +28,8 @@ struct RecFwdArgs {
     const float* WP = nullptr; int wp_pitch = 0;   // [U_a; W_hh] packed to a 128-byte-aligned row pitch (caphn_launch_rec_pair_prep)
     int t0 = 0, t1 = 0;                  // time-step window [t0, t1) of this launch (t1 == 0: T); t0 > 0 continues from Hs / Cs
     float drop_p = 0.f; unsigned long long drop_seed = 0;   // dropout on h_t: element (b, t, k) keeps by the hash of (seed, (b T + t) H + k)
+    int waf_lds = 0;                     // pair forward kernel: its columns of W_a f live in LDS (set by the launcher)
+    int wc_rows = 0;                     // pair forward kernel: weight rows cached in LDS (set by the launcher; -1: no on-chip rows)
     const float* Hsrc = nullptr;         // t0 > 0: h_{t0-1} comes from Hsrc [B,T,H] instead of Hs (multi-layer decoders: Hs receives the
                                          // attention cell's output, the next step continues from the LAST layer's output)
 };
@@ -54,6 +56,7 @@ struct RecBwdArgs {
     const float* WP = nullptr; int wp_pitch = 0;
     int apart_rows = 0;                  // pair kernels: rows of `apart` per caption
     float drop_p = 0.f; unsigned long long drop_seed = 0;
+    int part_rows = 0, wc_rows = 0;      // pair backward kernel (set by the launcher): rows of its slice-partials array, weight rows kept in LDS
     int t0 = 0, t1 = 0;                  // time-step window [t0, t1), walked backwards (t1 == 0: T).  A window starts from dh = 0 (dc
                                          // from dc0 when t1 < T) and leaves dh_{t0-1} in dh0 (dc in dc0): the caller adds it to what
                                          // arrives at step t0 - 1

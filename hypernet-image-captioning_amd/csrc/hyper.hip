@@ -566,6 +566,7 @@ extern int g_tune_gemm_tile;
 extern int g_tune_deterministic;
 extern int g_tune_adam_cap;
 extern int g_tune_chain_main;
+extern int g_tune_rec_cache;
 extern int g_det_vocab;
 int caphn_rec_pair_debug_skip(int v);
 extern "C" int caphn_tune(int key, int value) {
@@ -582,6 +583,7 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 11) { g_tune_gemm_single = value; return CAPHN_OK; }
     if (key == 12) { g_tune_gemm_tile = value; return CAPHN_OK; }
     if (key == 13) { g_tune_deterministic = value > 0; g_det_vocab = value; return CAPHN_OK; }
+    if (key == 16) { g_tune_rec_cache = value != 0; return CAPHN_OK; }
     if (key == 15) { g_tune_chain_main = value != 0; return CAPHN_OK; }
     if (key == 14) { if (value < 64 || value > 65535) return CAPHN_EINVAL; g_tune_adam_cap = value; return CAPHN_OK; }
     return CAPHN_EINVAL;

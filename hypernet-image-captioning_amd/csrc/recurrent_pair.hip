@@ -112,8 +112,8 @@ constexpr int JM = 7;          // chunks per lane per column block: 8 lanes x 7 
 __device__ __forceinline__ const float* pair_row(const float* __restrict__ WP, int pitch, int H, int k0, int qp, int kk) {
     return WP + (size_t)(qp * H + k0 + kk) * pitch;
 }
-__device__ __forceinline__ void pair_matvec(const float* __restrict__ WP, int pitch, const float* __restrict__ b_Ua,
-                                            const float* __restrict__ b_hh, const float* x_s, float* uah_s, float* gh_s,
+__device__ __forceinline__ void pair_matvec(const float* __restrict__ WP, int pitch, const float* bias_s,
+                                            const float* x_s, float* uah_s, float* gh_s,
                                             int H, int nk, int k0, int NR, int vec, int grp, int s) {
     constexpr int RS = NT / 8;                  // rows per sweep
     if (vec) {
@@ -146,9 +146,9 @@ __device__ __forceinline__ void pair_matvec(const float* __restrict__ WP, int pi
             sa += __shfl_xor(sa, 4, 64); sb += __shfl_xor(sb, 4, 64);
             sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
             sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
-            if (s == 0) {
-                if (qa == 0) uah_s[ka] = sa + b_Ua[k0 + ka]; else gh_s[(qa - 1) * nk + ka] = sa + b_hh[(qa - 1) * H + k0 + ka];
-                if (has_b) { if (qb == 0) uah_s[kb] = sb + b_Ua[k0 + kb]; else gh_s[(qb - 1) * nk + kb] = sb + b_hh[(qb - 1) * H + k0 + kb]; }
+            if (s == 0) {       // (biases from LDS: a global load here makes the wave wait for every load issued before it)
+                if (qa == 0) uah_s[ka] = sa + bias_s[ka]; else gh_s[(qa - 1) * nk + ka] = sa + bias_s[qa * nk + ka];
+                if (has_b) { if (qb == 0) uah_s[kb] = sb + bias_s[kb]; else gh_s[(qb - 1) * nk + kb] = sb + bias_s[qb * nk + kb]; }
             }
             qa = qb; ka = kb + RS;              // row r + 2 RS
             while (ka >= nk) { ka -= nk; ++qa; }
@@ -162,12 +162,96 @@ __device__ __forceinline__ void pair_matvec(const float* __restrict__ WP, int pi
             sum += __shfl_xor(sum, 4, 64);
             sum += __shfl_xor(sum, 2, 64);
             sum += __shfl_xor(sum, 1, 64);
-            if (s == 0) { if (qp == 0) uah_s[kk] = sum + b_Ua[k0 + kk]; else gh_s[(qp - 1) * nk + kk] = sum + b_hh[(qp - 1) * H + k0 + kk]; }
+            if (s == 0) { if (qp == 0) uah_s[kk] = sum + bias_s[kk]; else gh_s[(qp - 1) * nk + kk] = sum + bias_s[qp * nk + kk]; }
         }
     }
 }
 
-template <bool LSTM>
+// The same product with part of the rows ON CHIP for the whole kernel (the weights do not change over the time steps, and at
+// ~26 B/clk per CU the 320 KB a half streams per step are 12 k of its 26 k cycles): the rows of the first RC sweeps live in the
+// lane group's own registers (RC x JM dwordx4 per lane), the next `NL` rows (slot = row order after those sweeps) in LDS, the
+// rest streams from L2 as above.  Needs H % 4 == 0 and H <= 32 JM (one column block).
+template <int RC>
+__device__ __forceinline__ void pair_matvec_cached(const float* __restrict__ WP, int pitch, const float* bias_s,
+                                                   const float* x_s, float* uah_s, float* gh_s,
+                                                   int H, int nk, int k0, int NR, int grp, int s, const f32x4 (&wc)[RC][JM],
+                                                   const float* Wc_s, int NL) {
+    constexpr int RS = NT / 8;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x_s);
+    const int n4 = H >> 2;
+    f32x4 xv[JM];
+#pragma unroll
+    for (int j = 0; j < JM; ++j) { const int c = s + 8 * j; xv[j] = c < n4 ? x4[min(c, n4 - 1)] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+    auto dot = [&](const f32x4 (&v)[JM]) {
+        float sa = 0.f;
+#pragma unroll
+        for (int j = 0; j < JM; ++j) sa += v[j][0] * xv[j][0] + v[j][1] * xv[j][1] + v[j][2] * xv[j][2] + v[j][3] * xv[j][3];
+        sa += __shfl_xor(sa, 4, 64); sa += __shfl_xor(sa, 2, 64); sa += __shfl_xor(sa, 1, 64);
+        return sa;
+    };
+    auto emit = [&](int r, float sum) {
+        if (s == 0 && r < NR) {
+            int q = 0, kk = r;
+            while (kk >= nk) { kk -= nk; ++q; }
+            if (q == 0) uah_s[kk] = sum + bias_s[r]; else gh_s[(q - 1) * nk + kk] = sum + bias_s[r];
+        }
+    };
+    // the first two streamed rows are requested BEFORE the on-chip rows are multiplied: their L2 round trip runs under that work
+    f32x4 va[JM], vb[JM];
+    auto request = [&](int i) {
+        int qa = 0, ka = min(RS * i + grp, NR - 1), qb = 0, kb = min(RS * (i + 1) + grp, NR - 1);
+        while (ka >= nk) { ka -= nk; ++qa; }
+        while (kb >= nk) { kb -= nk; ++qb; }
+        const f32x4* pa = reinterpret_cast<const f32x4*>(pair_row(WP, pitch, H, k0, qa, ka));
+        const f32x4* pb = reinterpret_cast<const f32x4*>(pair_row(WP, pitch, H, k0, qb, kb));
+#pragma unroll
+        for (int j = 0; j < JM; ++j) { va[j] = pa[s + 8 * j]; vb[j] = pb[s + 8 * j]; }     // pad columns are zeros
+    };
+    int ig = RC + (NL > grp ? (NL - grp + RS - 1) / RS : 0);       // first streamed sweep of this lane group
+    {   // (one row only: a pair in flight on top of the resident rows does not fit the 256 registers)
+        int qa = 0, ka = min(RS * ig + grp, NR - 1);
+        while (ka >= nk) { ka -= nk; ++qa; }
+        const f32x4* pa = reinterpret_cast<const f32x4*>(pair_row(WP, pitch, H, k0, qa, ka));
+#pragma unroll
+        for (int j = 0; j < JM; ++j) va[j] = pa[s + 8 * j];
+    }
+#pragma unroll
+    for (int i = 0; i < RC; ++i) emit(RS * i + grp, dot(wc[i]));
+    {
+        int i = RC;
+#pragma unroll 1
+        for (int slot = grp; slot < NL; slot += RS, ++i) {
+            const f32x4* row = reinterpret_cast<const f32x4*>(Wc_s + (size_t)slot * H);
+            float sa = 0.f;
+#pragma unroll
+            for (int j = 0; j < JM; ++j) {
+                const f32x4 v = row[min(s + 8 * j, n4 - 1)];
+                sa += v[0] * xv[j][0] + v[1] * xv[j][1] + v[2] * xv[j][2] + v[3] * xv[j][3];
+            }
+            sa += __shfl_xor(sa, 4, 64); sa += __shfl_xor(sa, 2, 64); sa += __shfl_xor(sa, 1, 64);
+            emit(RS * i + grp, sa);
+        }
+    }
+    if (RS * ig + grp < NR) {
+        const float sa = dot(va);
+        const int ra = RS * ig + grp;
+        ig += 1;
+        if (RS * ig + grp < NR) request(ig);
+        emit(ra, sa);
+    }
+#pragma unroll 1
+    while (RS * ig + grp < NR) {
+        const float sa = dot(va), sb = dot(vb);
+        const int ra = RS * ig + grp;
+        ig += 2;
+        if (RS * ig + grp < NR) request(ig);
+        emit(ra, sa); emit(ra + RS, sb);
+    }
+}
+
+// CACHED: part of the weight rows on chip (pair_matvec_cached); its own instantiation, because a kernel that carries both
+// mat-vec variants (and ten positions of D1 in flight) on top of the register-resident rows spills
+template <bool LSTM, bool CACHED>
 __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
     constexpr int NG = LSTM ? 4 : 3;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -186,6 +270,9 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
     float* gh_s = c_s + nkm;                    // [NG][nk]
     float* e_s = gh_s + NG * nkm;               // [Ppad]
     float* part_s = e_s + Ppad;                 // [ng][NG][nk]
+    float* bias_s = part_s + (size_t)kg_map(0, H - nkm > 0 ? H - nkm : 1).ng * NG * nkm;    // [(NG + 1) nkm] b_Ua | b_hh of my rows, row order
+    float* Waf_s = bias_s + (size_t)(NG + 1) * nkm;                                          // [P][nkm] my columns of W_a f (waf_lds)
+    float* Wc_s = Waf_s + (a.waf_lds ? (size_t)P * nkm : 0);                                 // [wc_rows][H] cached weight rows
 
     u64* xmine = a.xch + (size_t)w * xch_stride(P, H);
     u64* xpart = a.xch + (size_t)(w ^ 8) * xch_stride(P, H);
@@ -216,19 +303,41 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
     const float bva = hh == 0 ? a.b_va[0] : 0.f;          // added once: e = e(half 0) + e(half 1)
     const float* Waf_b = a.Waf + (size_t)b * P * H;
     const KG m = kg_map(tid, nk);
+    // my columns of W_a f: t-invariant, 16 values a lane for the whole kernel.  They used to sit in registers; those now hold
+    // weight rows (below), and the 20 KB of LDS this takes would only hold 24 of them
     constexpr int WP = 8, WK = 2;
-    const bool waf_regs = (P <= WP * (NT / 64)) && (nk <= WK * 64);
-    float wreg[WP][WK];
-#pragma unroll
-    for (int i = 0; i < WP; ++i)
-#pragma unroll
-        for (int q = 0; q < WK; ++q) {
-            const int p = wave + i * (NT / 64), kk = lane + 64 * q;
-            wreg[i][q] = (waf_regs && p < P && kk < nk) ? Waf_b[p * H + k0 + kk] : 0.f;
-        }
+    const bool waf_regs = a.waf_lds && (P <= WP * (NT / 64)) && (nk <= WK * 64);
+    for (int r = tid; r < (NG + 1) * nk; r += NT) {
+        const int q = r / nk, kk = r - q * nk;
+        bias_s[r] = q == 0 ? a.b_Ua[k0 + kk] : a.b_hh[(q - 1) * H + k0 + kk];
+    }
+    if (a.waf_lds)
+        for (int i = tid; i < P * nk; i += NT) { const int p = i / nk, kk = i - p * nk; Waf_s[(size_t)p * nkm + kk] = Waf_b[p * H + k0 + kk]; }
     const int NR = (NG + 1) * nk;               // rows of [U_a; W_hh] this half multiplies
     const int grp = tid >> 3, s8 = tid & 7;
     const int vecW = (H % 4) == 0;              // the packed weights are 128-byte aligned; half boundaries are multiples of 4
+    // on-chip part of my rows (pair_matvec_cached): sweeps 0 .. WRC-1 in registers, the next wc_rows rows in LDS
+    constexpr int WRC = CACHED ? 2 : 1;
+    constexpr bool cached = CACHED;             // the launcher checked H % 4 == 0 and H <= 32 JM
+    const int NL = cached ? a.wc_rows : 0;
+    f32x4 wc[WRC][JM];
+    if (cached) {
+        const int n4 = H >> 2;
+#pragma unroll
+        for (int i = 0; i < WRC; ++i) {
+            int q = 0, kk = min((NT / 8) * i + grp, NR - 1);
+            while (kk >= nk) { kk -= nk; ++q; }
+            const f32x4* row = reinterpret_cast<const f32x4*>(pair_row(a.WP, a.wp_pitch, H, k0, q, kk));
+#pragma unroll
+            for (int j = 0; j < JM; ++j) wc[i][j] = row[s8 + 8 * j];
+        }
+        for (int idx = tid; idx < NL * n4; idx += NT) {
+            const int slot = idx / n4, c = idx - slot * n4;
+            int q = 0, kk = min((NT / 8) * (WRC + slot / (NT / 8)) + slot % (NT / 8), NR - 1);
+            while (kk >= nk) { kk -= nk; ++q; }
+            reinterpret_cast<f32x4*>(Wc_s)[idx] = reinterpret_cast<const f32x4*>(pair_row(a.WP, a.wp_pitch, H, k0, q, kk))[c];
+        }
+    }
     __syncthreads();
     PDECL;
 
@@ -244,7 +353,8 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
             __syncthreads();
         }
         PSTAMP(1);
-        pair_matvec(a.WP, a.wp_pitch, a.b_Ua, a.b_hh, h_s, uah_s, gh_s, H, nk, k0, NR, vecW, grp, s8);
+        if constexpr (cached) pair_matvec_cached<WRC>(a.WP, a.wp_pitch, bias_s, h_s, uah_s, gh_s, H, nk, k0, NR, grp, s8, wc, Wc_s, NL);
+        else pair_matvec(a.WP, a.wp_pitch, bias_s, h_s, uah_s, gh_s, H, nk, k0, NR, vecW, grp, s8);
         __syncthreads();
         PSTAMP(2);
         // B: my part of e_p = v_a . tanh(Waf_p + uah) (+ b_va)
@@ -255,8 +365,10 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
 #pragma unroll
             for (int i = 0; i < WP; ++i) {
                 sc[i] = 0.f;
+                const int pc = min(wave + i * (NT / 64), P - 1);                                   // (rows >= P are not stored)
 #pragma unroll
-                for (int q = 0; q < WK; ++q) sc[i] += vq[q] * caphn_tanh(wreg[i][q] + uq[q]);     // v = 0 outside my columns
+                for (int q = 0; q < WK; ++q)
+                    sc[i] += vq[q] * caphn_tanh(Waf_s[(size_t)pc * nkm + min(lane + 64 * q, nk - 1)] + uq[q]);   // v = 0 outside my columns
             }
             const float tot = wave_sum8(sc, lane);          // lane l: total of position wave + 8 (l >> 3)
             const int pw = wave + (lane >> 3) * (NT / 64);
@@ -317,19 +429,23 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
                 float accg[NG];
 #pragma unroll
                 for (int q = 0; q < NG; ++q) accg[q] = 0.f;
-                if (RG == NG && (P + m.ng - 1) / m.ng <= 10) {      // all loads of the (at most 10) positions before any use
-                    float al[10], gv[10][NG];
+                if (RG == NG && (P + m.ng - 1) / m.ng <= 10) {      // all loads of a batch of positions before any use
+                    constexpr int DB = CACHED ? 5 : 10;             // (LDS reads: five in flight hide their latency as well)
+#pragma unroll 1
+                    for (int i0 = 0; i0 < 10; i0 += DB) {
+                        float al[DB], gv[DB][NG];
 #pragma unroll
-                    for (int i = 0; i < 10; ++i) {
-                        const int p = m.g + i * m.ng, pc = min(p, P - 1);
-                        al[i] = p < P ? e_s[pc] : 0.f;
+                        for (int i = 0; i < DB; ++i) {
+                            const int p = m.g + (i0 + i) * m.ng, pc = min(p, P - 1);
+                            al[i] = p < P ? e_s[pc] : 0.f;
 #pragma unroll
-                        for (int q = 0; q < NG; ++q) gv[i][q] = G_s[((size_t)pc * NG + q) * nk + kk];
+                            for (int q = 0; q < NG; ++q) gv[i][q] = G_s[((size_t)pc * NG + q) * nk + kk];
+                        }
+#pragma unroll
+                        for (int i = 0; i < DB; ++i)
+#pragma unroll
+                            for (int q = 0; q < NG; ++q) accg[q] += al[i] * gv[i][q];
                     }
-#pragma unroll
-                    for (int i = 0; i < 10; ++i)
-#pragma unroll
-                        for (int q = 0; q < NG; ++q) accg[q] += al[i] * gv[i][q];
                 } else
                 for (int p = m.g; p < P; p += m.ng) {
                     const float al = e_s[p];
@@ -415,6 +531,7 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
     float* al_s = dal_s + Ppad;
     float* dhp_s = al_s + Ppad;                 // [H4] partial dh_{t-1} over my rows, all columns
     float* part_s = dhp_s + H4;                 // [max(nslices, ng)][H4]
+    float* Wc_s = part_s + (size_t)a.part_rows * H4;     // [wc_rows][H] the first rows of my [U_a; W_hh], resident for the whole kernel
 
     u64* xmine = a.xch + (size_t)w * xch_stride(P, H);
     u64* xpart = a.xch + (size_t)(w ^ 8) * xch_stride(P, H);
@@ -469,6 +586,20 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
                 int r = slice, qp = 0, kk = slice;
                 while (kk >= nk) { kk -= nk; ++qp; }
                 const float* col = a.WP + cb + c * CH;
+                // rows [0, NLb) come from LDS (NLb is a multiple of 4 nsl: a batch of four is on one side or the other)
+                const int NLb = (CH == 4 && cb == 0) ? a.wc_rows : 0;
+                while (r < NLb) {               // (NLb <= NR: all four rows exist)
+                    f32x4 wv[4]; float dj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        wv[u] = *reinterpret_cast<const f32x4*>(Wc_s + (size_t)r * H + c * 4);
+                        dj[u] = dvec_s[r];
+                        r += nsl; kk += nsl;
+                        while (kk >= nk) { kk -= nk; ++qp; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { acc[0] += wv[u][0] * dj[u]; acc[1] += wv[u][1] * dj[u]; acc[2] += wv[u][2] * dj[u]; acc[3] += wv[u][3] * dj[u]; }
+                }
                 while (r < NR) {
                     const float* rp[4]; float dj[4];
 #pragma unroll
@@ -505,6 +636,15 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
 
     // the saved activations of a step are requested one step ahead (seven or eight global loads per k; waited for at the
     // top of a step they cost ~2 k cycles): thread kk < nk holds its k's values, thread p < P alpha_p
+    if (a.wc_rows > 0) {            // (CH == 4 guaranteed by the launcher: H % 4 == 0)
+        const int n4 = H >> 2;
+        for (int idx = tid; idx < a.wc_rows * n4; idx += NT) {
+            const int r = idx / n4, c = idx - r * n4;
+            const int qp = r / nk, kk = r - qp * nk;
+            reinterpret_cast<f32x4*>(Wc_s)[idx] = reinterpret_cast<const f32x4*>(a.WP + (size_t)(qp * H + k0 + kk) * a.wp_pitch)[c];
+        }
+        __syncthreads();
+    }
     const bool pfk = nk <= NT && P <= NT;
     float pf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pfa = 0.f;
     auto prefetch = [&](int t) {
@@ -728,22 +868,29 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(u64* __restrict__ xch, s
     const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
     for (size_t j = i0; j < nxch; j += stride) __hip_atomic_store(xch + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((H & 3) == 0 && caphn_aligned16_dev(U_a) && caphn_aligned16_dev(W_hh)) {
-        const int n4 = H >> 2;
-        for (size_t j = i0; j < (size_t)rows * n4; j += stride) {
-            const int r = (int)(j / n4), c = (int)(j % n4);
+        // whole pitch written: the pad columns hold zeros, so a lane may read its chunk without a bounds clamp (one base address
+        // and immediate offsets instead of an address pair per chunk)
+        const int n4 = H >> 2, p4 = pitch >> 2;
+        for (size_t j = i0; j < (size_t)rows * p4; j += stride) {
+            const int r = (int)(j / p4), c = (int)(j % p4);
             const float* src = r < H ? U_a + (size_t)r * H : W_hh + (size_t)(r - H) * H;
-            reinterpret_cast<f32x4*>(WP + (size_t)r * pitch)[c] = reinterpret_cast<const f32x4*>(src)[c];
+            reinterpret_cast<f32x4*>(WP + (size_t)r * pitch)[c] = c < n4 ? reinterpret_cast<const f32x4*>(src)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     } else {
         for (size_t j = i0; j < (size_t)rows * H; j += stride) {
             const int r = (int)(j / H), c = (int)(j % H);
             WP[(size_t)r * pitch + c] = r < H ? U_a[(size_t)r * H + c] : W_hh[(size_t)(r - H) * H + c];
         }
+        for (size_t j = i0; j < (size_t)rows * (pitch - H); j += stride) {
+            const int r = (int)(j / (pitch - H)), c = H + (int)(j % (pitch - H));
+            WP[(size_t)r * pitch + c] = 0.f;
+        }
     }
 }
 
 }  // namespace
-int caphn_rec_pair_pitch(int H) { return (H + 31) & ~31; }
+// (at least one full column block of the mat-vec, 32 JM floats: see the pad note in pair_prep_kernel)
+int caphn_rec_pair_pitch(int H) { const int p = (H + 31) & ~31; return p < 32 * JM ? 32 * JM : p; }
 size_t caphn_rec_pair_wp_floats(int H, int NG) { return (size_t)(NG + 1) * H * caphn_rec_pair_pitch(H); }
 int caphn_launch_rec_pair_prep(unsigned long long* xch, size_t nxch, const float* U_a, const float* W_hh, int H, int NG, float* WP,
                                hipStream_t s) {
@@ -753,6 +900,7 @@ int caphn_launch_rec_pair_prep(unsigned long long* xch, size_t nxch, const float
 int caphn_rec_pair_debug_skip(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(d_skip_xrecv), &v, sizeof(int)) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH; }
 
 static int kgn(int n) { return n >= NT ? 1 : NT / n; }
+int g_tune_rec_cache = 1;   // 1 (default): part of the recurrent weights on chip for the whole kernel (registers + spare LDS); 0: all streamed
 size_t caphn_rec_pair_xch_bytes(int B, int P, int H) {
     const size_t nwg = 16 * (size_t)((B + 7) / 8);
     return nwg * xch_stride(P, H) * sizeof(u64);
@@ -761,7 +909,8 @@ size_t caphn_rec_pair_fwd_lds_bytes(int P, int H, int NG, int RG) {
     const size_t nkm = half_a(H), Ppad = (P + 63) & ~63;
     const int nkmin = H - half_a(H);
     if (nkmin < 1) return ~(size_t)0;
-    return sizeof(float) * ((size_t)RG * P * nkm + ((H + 3) & ~3) + 3 * nkm + (size_t)NG * nkm + Ppad + (size_t)kgn(nkmin) * NG * nkm);
+    return sizeof(float) * ((size_t)RG * P * nkm + ((H + 3) & ~3) + 3 * nkm + (size_t)NG * nkm + Ppad + (size_t)kgn(nkmin) * NG * nkm +
+                            (size_t)(NG + 1) * nkm);
 }
 size_t caphn_rec_pair_bwd_lds_bytes(int P, int H, int NG, int RG) {
     const size_t nkm = half_a(H), Ppad = (P + 63) & ~63, H4 = (H + 3) & ~3;
@@ -793,28 +942,77 @@ int caphn_rec_pair_bwd_groups(int P, int H) {
 static int set_attr(const void* f) {
     return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
 }
-int caphn_launch_rec_pair_fwd(const RecFwdArgs& a, bool lstm, hipStream_t s) {
-    const size_t lds = caphn_rec_pair_fwd_lds_bytes(a.P, a.H, lstm ? 4 : 3, a.RG);
+// rows of the half's [U_a; W_hh] the forward kernel keeps in the LDS left over (a multiple of 8: wave-uniform; at most what
+// the two register-resident sweeps leave)
+int caphn_rec_pair_fwd_cache_rows(int P, int H, int NG, int RG) {
+    size_t base = caphn_rec_pair_fwd_lds_bytes(P, H, NG, RG);
+    if (base > LDS_LIMIT || g_tune_rec_cache == 0) return g_tune_rec_cache == 0 ? -1 : 0;
+    if (base + sizeof(float) * (size_t)P * half_a(H) <= LDS_LIMIT) base += sizeof(float) * (size_t)P * half_a(H);      // W_a f columns
+    long rows = (long)((LDS_LIMIT - base) / (sizeof(float) * (size_t)H)) & ~7L;
+    const long nr = (long)(NG + 1) * half_a(H), left = nr - 2 * (NT / 8);
+    if (rows > left) rows = left > 0 ? (left + 7) & ~7L : 0;
+    if ((size_t)rows * H * sizeof(float) + base > LDS_LIMIT) rows -= 8;
+    return rows > 0 ? (int)rows : 0;
+}
+int caphn_launch_rec_pair_fwd(const RecFwdArgs& a_, bool lstm, hipStream_t s) {
+    RecFwdArgs a = a_;
+    size_t lds = caphn_rec_pair_fwd_lds_bytes(a.P, a.H, lstm ? 4 : 3, a.RG);
     if (lds > LDS_LIMIT || !a.xch || !a.WP) return CAPHN_ELIMIT;
+    const size_t waf_bytes = sizeof(float) * (size_t)a.P * half_a(a.H);
+    a.waf_lds = lds + waf_bytes <= LDS_LIMIT ? 1 : 0;
+    if (a.waf_lds) lds += waf_bytes;
+    a.wc_rows = ((a.H % 4) == 0 && a.H <= 32 * JM) ? caphn_rec_pair_fwd_cache_rows(a.P, a.H, lstm ? 4 : 3, a.RG) : -1;
+    if (a.wc_rows > 0) lds += sizeof(float) * (size_t)a.wc_rows * a.H;
     static bool attr = false;
     if (!attr) {
-        if (set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true>)) ||
+        if (set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, false>)) ||
+            set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, true>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, true>)) ||
             set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<true>)))
             return CAPHN_ELAUNCH;
         attr = true;
     }
     const unsigned nwg = 16u * (unsigned)((a.B + 7) / 8);
-    if (lstm) hipLaunchKernelGGL(rec_pair_fwd_kernel<true>, dim3(nwg), dim3(NT), lds, s, a);
-    else hipLaunchKernelGGL(rec_pair_fwd_kernel<false>, dim3(nwg), dim3(NT), lds, s, a);
+    const bool cached = a.wc_rows >= 0 && (a.H % 4) == 0 && a.H <= 32 * JM;
+    if (cached) {
+        if (lstm) hipLaunchKernelGGL((rec_pair_fwd_kernel<true, true>), dim3(nwg), dim3(NT), lds, s, a);
+        else hipLaunchKernelGGL((rec_pair_fwd_kernel<false, true>), dim3(nwg), dim3(NT), lds, s, a);
+    } else {
+        if (lstm) hipLaunchKernelGGL((rec_pair_fwd_kernel<true, false>), dim3(nwg), dim3(NT), lds, s, a);
+        else hipLaunchKernelGGL((rec_pair_fwd_kernel<false, false>), dim3(nwg), dim3(NT), lds, s, a);
+    }
     return caphn_launch_status();
 }
-int caphn_launch_rec_pair_bwd(const RecBwdArgs& a, bool lstm, hipStream_t s) {
-    const size_t lds = caphn_rec_pair_bwd_lds_bytes(a.P, a.H, lstm ? 4 : 3, a.RG);
+// rows of part_s the backward kernel lays out (its LDS formula's last term), and the weight rows that fit behind them
+static size_t bwd_part_rows(int H) {
+    const int nkmin = H - half_a(H);
+    size_t nsl = NT / (size_t)(nkmin < NT ? nkmin : NT);
+    const size_t nsl4 = NT / (size_t)(((nkmin + 3) / 4) < NT ? ((nkmin + 3) / 4) : NT);
+    if (nsl4 > nsl) nsl = nsl4;
+    if ((size_t)kgn(nkmin) > nsl) nsl = kgn(nkmin);
+    return nsl;
+}
+int caphn_rec_pair_bwd_cache_rows(int P, int H, int NG, int RG) {
+    const size_t base = caphn_rec_pair_bwd_lds_bytes(P, H, NG, RG);
+    if (base > LDS_LIMIT || g_tune_rec_cache == 0 || (H % 4) != 0 || H / 4 > NT) return 0;
+    const long batch = 4 * (long)(NT / (H / 4));                   // rows a sweep of four loads per thread covers
+    long rows = (long)((LDS_LIMIT - base) / (sizeof(float) * (size_t)H));
+    const long nr = (long)(NG + 1) * (H - half_a(H));               // the narrower half's row count bounds both
+    if (rows > nr) rows = nr;
+    rows -= rows % batch;
+    return rows > 0 ? (int)rows : 0;
+}
+int caphn_launch_rec_pair_bwd(const RecBwdArgs& a_, bool lstm, hipStream_t s) {
+    RecBwdArgs a = a_;
+    size_t lds = caphn_rec_pair_bwd_lds_bytes(a.P, a.H, lstm ? 4 : 3, a.RG);
     if (lds > LDS_LIMIT || !a.xch || !a.WP) return CAPHN_ELIMIT;
+    a.part_rows = (int)bwd_part_rows(a.H);
+    a.wc_rows = caphn_rec_pair_bwd_cache_rows(a.P, a.H, lstm ? 4 : 3, a.RG);
+    lds += sizeof(float) * (size_t)a.wc_rows * a.H;
     if (a.dWaf && (!a.apart || caphn_rec_pair_bwd_groups(a.P, a.H) == 0 || a.apart_rows < caphn_rec_pair_bwd_groups(a.P, a.H))) return CAPHN_EINVAL;
     static bool attr = false;
     if (!attr) {
-        if (set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true>)) ||
+        if (set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, false>)) ||
+            set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, true>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, true>)) ||
             set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<true>)))
             return CAPHN_ELAUNCH;
         attr = true;

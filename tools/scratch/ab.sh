@@ -7,9 +7,9 @@ for l in sys.stdin:
 "; }
 EXTRA=""
 run X=1
-EXTRA="--tune 3=0"
+EXTRA="--tune 16=0"
 run X=1
 EXTRA=""
 run X=1
-EXTRA="--tune 3=0"
+EXTRA="--tune 16=0"
 run X=1
