@@ -129,3 +129,39 @@ def test_layers_are_rejected_for_the_lstm_cell():
     d = ops.DecDims(2, 3, 4, 8, 8, 8, 8, 20, cell="lstm", raw=True, layers=2)
     with pytest.raises(CaphnError):
         ops.decoder_workspace(d, torch.device(DEV))
+
+
+@pytest.mark.parametrize("L,B,T,P,dims", [(2, 5, 9, 10, O.Dims(D=37, F=13, E=11, H=19, V=83, he=5)),
+                                          (4, 3, 4, 5, O.Dims(D=24, F=12, E=10, H=12, V=40, he=4)),
+                                          (2, 9, 6, 49, O.Dims(D=64, F=200, E=200, H=200, V=500, he=8))])
+def test_layers_odd_and_canonical_widths_against_the_oracle(L, B, T, P, dims):
+    """Nothing a multiple of 4 (scalar load paths), the maximum layer count, and the canonical F = E = H = 200 (pair kernels are
+    not used with layers: one launch window per step on the one-workgroup kernels) -- module API vs the oracle (itself pinned on
+    the reference's three-layer vectors)."""
+    from models.decoderlstm import AttentionGru
+    torch.manual_seed(L * 7 + B)
+    m = AttentionGru(dims.D, dims.F, dims.E, dims.H, dims.V, num_layers=L, p=0.0)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    batch = O.synth_batch(dims, B, T, P, seed=3 + L)
+    feats, caps = batch["features"], batch["captions"]
+    m = m.to(DEV).train()
+    logits, alphas = m(feats.to(DEV), caps.to(DEV), 0.0)
+    loss = F.cross_entropy(logits.view(-1, dims.V), caps.to(DEV).view(-1), ignore_index=0)
+    loss.backward()
+    p = {"captioner." + k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.startswith(("gru.", "layers."))}
+    cw = {k[4:]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("gru.")}
+    layers = [{n: sd[f"layers.{l}.{n}"].clone().requires_grad_(True) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
+              for l in range(L - 1)]
+    ref, ra = O.decoder_forward(dims, p, cw, feats, caps, layers=layers)
+    rl = O.caption_loss(ref, caps)
+    rl.backward()
+    assert maxdiff(logits.detach().cpu(), ref.detach()) < 5e-6 and maxdiff(alphas.detach().cpu(), ra.detach()) < 2e-6
+    assert abs(float(loss.detach()) - float(rl.detach())) < 3e-6
+    got = dict(m.named_parameters())
+    for k, v in p.items():
+        assert maxdiff(got[k[len("captioner."):]].grad.cpu(), v.grad) < 5e-6, k
+    for k, v in cw.items():
+        assert maxdiff(got["gru." + k].grad.cpu(), v.grad) < 5e-6, k
+    for l, lw in enumerate(layers):
+        for n, v in lw.items():
+            assert maxdiff(got[f"layers.{l}.{n}"].grad.cpu(), v.grad) < 5e-6, (l, n)
