@@ -17,6 +17,7 @@
 int g_tune_deterministic = 0;   // 1: bit-reproducible gradients -- no split-K (fp32 atomics), embedding gradient by a destination-major scan
 int g_tune_rec_pair = 1;     // 1 (default): two workgroups per caption in the recurrent kernels (recurrent_pair.hip)
 int g_tune_rec_rotate = 1;
+int g_tune_splitk_target = 1024;   // workgroups a split-K weight-gradient GEMM of the composites aims at (caphn_tune 17)
 int g_tune_chain_main = 0;  // 1: with the hypernet VJP hooked in, the chain to it runs on the caller's stream (see "after BPTT");
                             // measured 30 us per step WORSE than 0 (2.026/2.023 vs 1.996/1.994 ms, same box, alternating)
 int g_tune_fork = 4;        // 0: one stream; 1: independent branches on side streams, the vocabulary weight gradient (dW_fc) starting
@@ -265,7 +266,7 @@ inline int pick_splitk(int M, int N, int K) {
     if (t128 >= 1024) return 1;
     const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
     const int nslab = (K + 31) / 32;
-    long s = (1024 + t64 - 1) / t64;
+    long s = (g_tune_splitk_target + t64 - 1) / t64;
     if (s > nslab / 8) s = nslab / 8;
     if (s < 1) s = 1;
     if (s > 64) s = 64;

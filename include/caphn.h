@@ -490,7 +490,10 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * bit-identical from run to run, at a cost in speed; 0 = off), key 14: workgroup cap of one rank-1 Adam launch (64..65535, default
  * 4096), key 15: 1 = caphn_decoder_hyper_backward runs the chain to the hypernet VJP on the caller's stream and the
  * attention / feature_fc chain on a side stream, 0 (default) = the other way round; key 4 values: 0 one stream, 1 vocabulary weight
- * gradient after BPTT, 2 beside BPTT, 3 big leaves held back, 4 (default) 2 with the pair recurrent kernels else 1.
+ * gradient after BPTT, 2 beside BPTT, 3 big leaves held back, 4 (default) 2 with the pair recurrent kernels else 1; key 16:
+ * 1 (default) = the pair recurrent kernels keep part of [U_a; W_hh] on chip (registers + spare LDS) for the whole kernel, 0 = all
+ * rows streamed from L2 every time step; key 17: workgroups a split-K weight-gradient GEMM of the composites aims at (default
+ * 1024; 256 / 512 / 2048 measured slower).
  * Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
