@@ -16,6 +16,19 @@
 #include "split3.h"
 #include <type_traits>
 
+// per-phase shader-clock stamps of workgroup (0,0,0), wave 0 (tools/gemm_phase_profile.py): compile with -DCAPHN_GEMM_PROFILE
+#ifdef CAPHN_GEMM_PROFILE
+__device__ unsigned long long d_gemm_prof[10];
+#define GSTAMP(i) do { if (gprof) { unsigned long long _n = clock64(); gpc[i] += _n - glast; glast = _n; } } while (0)
+extern "C" int caphn_debug_gemm_prof(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(d_gemm_prof), sizeof(unsigned long long) * 10) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(d_gemm_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int BK = 32;
@@ -229,6 +242,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, kh = lane >> 5;
+#ifdef CAPHN_GEMM_PROFILE
+    const unsigned long long gstart = clock64();
+#endif
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so neighbouring tiles
     // -- which share an operand panel -- would land on eight different L2s and each fetch the panel from HBM.  Give
     // every XCD a contiguous run of the (n fastest, then m, then k-split) tile order instead (bijective remap for
@@ -239,7 +255,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         const int orig = bx + nx * (by + ny * bz);
         const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        bx = wgid % nx; by = (wgid / nx) % ny; bz = wgid / (nx * ny);
+        if (g.flags & (1 << 22)) { by = wgid % ny; bx = (wgid / ny) % nx; }     // m fastest: the B panel of a tile column is reused
+        else { bx = wgid % nx; by = (wgid / nx) % ny; }                          // n fastest: the A panel of a tile row is reused
+        bz = wgid / (nx * ny);
     }
     const int m0 = by * BM, n0 = bx * BN;
     // row subset: effective extents come from device memory (no host round trip)
@@ -373,29 +391,47 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         // before staging a set becomes vmcnt(#loads of the newer set) instead of vmcnt(0).
         constexpr bool F = decltype(fc)::value;
         const int last = slab1 - 1;
+#ifdef CAPHN_GEMM_PROFILE
+        const bool gprof = tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+        unsigned long long gpc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, glast = gprof ? clock64() : 0;
+#endif
         gload(ra0, rb0, slab0, fc);
         if (F || slab0 + 1 < slab1) gload(ra1, rb1, min(slab0 + 1, last), fc);
         stage(ra0, rb0, slab0, fc);
         __syncthreads();
+        GSTAMP(0);                                  // prologue: first loads, first stage
         for (int slab = slab0; slab < slab1; slab += 2) {
             // LDS: slab.  set 1: slab+1 (in flight).  set 0: free
             if (F || slab + 2 < slab1) gload(ra0, rb0, min(slab + 2, last), fc);
+            GSTAMP(1);                              // issue of the look-ahead loads
             multiply(slab);
             __builtin_amdgcn_sched_barrier(0);      // keep the staging (and its vmcnt wait) behind the MFMAs
+            GSTAMP(2);                              // fragment reads + MFMAs
             __syncthreads();
+            GSTAMP(3);                              // barrier after the multiply
             if (slab + 1 >= slab1) break;
             stage(ra1, rb1, slab + 1, fc);
+            GSTAMP(4);                              // wait for the older register set, split, LDS stores
             __syncthreads();
+            GSTAMP(5);                              // barrier after the stage
             // LDS: slab+1.  set 0: slab+2 (in flight).  set 1: free
             if (F || slab + 3 < slab1) gload(ra1, rb1, min(slab + 3, last), fc);
+            GSTAMP(1);
             multiply(slab + 1);
             __builtin_amdgcn_sched_barrier(0);
+            GSTAMP(2);
             __syncthreads();
+            GSTAMP(3);
             if (slab + 2 < slab1) {
                         stage(ra0, rb0, slab + 2, fc);
+                GSTAMP(4);
                 __syncthreads();
+                GSTAMP(5);
             }
         }
+#ifdef CAPHN_GEMM_PROFILE
+        if (gprof) { for (int i = 0; i < 6; ++i) atomicAdd(&d_gemm_prof[i], gpc[i]); atomicAdd(&d_gemm_prof[6], (unsigned long long)(slab1 - slab0)); atomicAdd(&d_gemm_prof[7], 1ull); }
+#endif
     };
     // fused bias gradient from the planes: x = hi + mid + lo
     float csum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -495,6 +531,58 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     // epilogue: acc register r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
     const bool atomic = g.splitk > 1;
     const bool add_bias = (g.flags & CAPHN_GEMM_BIAS) && (!atomic || bz == 0);
+    // Interior tiles (every tile but the last row / column of tiles): straight-line code -- the flags are tested once per
+    // workgroup, the row pointers are formed once per 32-row block.  The general loop below (a bounds test, four flag tests and
+    // a 64-bit multiply PER ELEMENT, under a changing EXEC mask) took 34 k of a vocabulary-logits workgroup's 72 k cycles, as
+    // much as its whole main loop; this path takes 12 k.
+    if (m0 + BM <= g.M && n0 + BN <= g.N) {
+        const bool relu = (g.flags & CAPHN_GEMM_RELU) != 0, lrelu = (g.flags & CAPHN_GEMM_LRELU) != 0;
+        const bool accum = (g.flags & CAPHN_GEMM_ACCUM) != 0, masked = (g.flags & CAPHN_GEMM_MASK) != 0;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int row0 = m0 + wm * WM + a * 32 + 4 * kh;        // register r holds row row0 + (r & 3) + 8 (r >> 2)
+            float* crow[16];
+            if (rmapA) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) crow[r] = g.C + (size_t)rmapA[row0 + (r & 3) + 8 * (r >> 2)] * g.ldc;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) crow[r] = g.C + (size_t)(row0 + (r & 3) + 8 * (r >> 2)) * g.ldc;
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = n0 + wn * WN + b * 32 + li;
+                const float bv = add_bias ? g.bias[col] : 0.f;
+                if (atomic) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) atomicAdd(crow[r] + col, acc[a][b][r] + bv);
+                } else {
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc[a][b][r] + bv;
+                    if (accum) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] += crow[r][col];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    if (lrelu) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.01f * v[r];
+                    }
+                    if (masked) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            v[r] = (g.mask[(size_t)(row0 + (r & 3) + 8 * (r >> 2)) * g.ldmask + col] > 0.f) ? v[r] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) crow[r][col] = v[r];
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -516,6 +604,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                 *c = v;
             }
         }
+#ifdef CAPHN_GEMM_PROFILE
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        __builtin_amdgcn_s_waitcnt(0);          // the epilogue's stores have left the wave
+        atomicAdd(&d_gemm_prof[8], clock64() - gstart);
+    }
+#endif
 }
 
 template <int BM, int BN, bool TA, bool TB, int PL>
@@ -549,6 +643,7 @@ int launch_cfg(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 extern int g_tune_gemm_planes;
 int g_tune_gemm_tile = 0;     // 0: automatic tile choice; 64 / 128: forced (experiments)
 int g_tune_gemm_single = 0;   // 1: reduced-precision side mode -- one bf16 product per contraction instead of six (caphn_tune key 11)
+int g_tune_gemm_order = 1;    // tile walk inside an XCD: 0 n fastest always, 1 (default) m fastest when B outgrows L2 and A is the smaller, 2 m fastest always
 int g_tune_gemm_xcd = 1;      // 1 (default): XCD-aware tile order
 int g_tune_gemm_fast = 1;     // 1 (default): branch-free loads (static vmcnt) where alignment allows
 // Tile choice: 128x128 when that alone gives >= 512 workgroups, else 64x64 (five workgroups per CU).  Measured and
@@ -576,6 +671,13 @@ int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
         if (ints <= 4096) g.kmap_lds = ints;      // 16 KB at most next to the 30 KB of tiles (64x64 configuration)
     }
     if (!g_tune_gemm_fast) g.flags |= 1 << 21;
+    // Walk order inside an XCD's run of tiles.  n fastest re-reads every B panel once per tile row: fine while all of B
+    // (N x K) stays in the XCD's 4 MB L2, but the vocabulary projection's B is 7.7 MB while its A is 2 MB -- every tile row
+    // streamed B again from beyond L2 (160 MB of fills for a 99 MB output).  m fastest keeps A resident and reads B once.
+    if (g_tune_gemm_order != 0 && g.splitk <= 1) {
+        const double abytes = 4.0 * (double)g.M * g.K, bbytes = 4.0 * (double)g.N * g.K, l2 = 3.0 * 1024 * 1024;
+        if (g_tune_gemm_order == 2 || (bbytes > l2 && abytes < bbytes)) g.flags |= 1 << 22;
+    }
     long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.splitk;
     if (g_tune_gemm_tile == 64) tiles128 = 0; else if (g_tune_gemm_tile == 128) tiles128 = 1 << 20;      // A/B experiments (caphn_tune key 12)
     const bool pl = caphn_gemm_planes_ok(g, ta, tb);
