@@ -99,6 +99,33 @@ struct TileS {
     // the bounds checks as branches it had to drain everything (vmcnt(0)), which cancelled the look-ahead.
     // kl (K-slow operands only): LDS copy of the row map for logical k in [kbase, ...): the physical row comes from a
     // ds_read, so the number of VMEM loads stays static
+    // byte offsets of this thread's NV loads for the branch-free path, formed ONCE per workgroup: the per-slab address is then the
+    // uniform base plus a 32-bit offset (the launcher takes this path only while an operand spans < 4 GB); a 64-bit multiply
+    // per load and slab was 0.5 k of a 128x128 slab's 4.9 k cycles
+    __device__ static __forceinline__ void fast_bases(unsigned (&bo)[NV], int ld, int rows, int r0, int tid, const int (&pr)[NV]) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            if (KC) bo[i] = ((unsigned)pr[i] * (unsigned)ld + (unsigned)((idx & 7) * 4)) * 4u;          // + clamped k0
+            else bo[i] = (unsigned)min(r0 + (idx % (BMN / 4)) * 4, rows - 4) * 4u;                       // + physical k row * ld
+        }
+    }
+    __device__ static __forceinline__ void load_fast_b(f32x4 (&r)[NV], const float* __restrict__ G, const unsigned (&bo)[NV], int ld,
+                                                       int K, int k0, int tid, const int* kl, int kbase) {
+        const char* base = reinterpret_cast<const char*>(G);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            unsigned off;
+            if (KC) off = bo[i] + (unsigned)min(k0, K - 4 - (idx & 7) * 4) * 4u;
+            else {
+                int kc = min(k0 + idx / (BMN / 4), K - 1);
+                if (kl) kc = kl[kc - kbase];
+                off = bo[i] + (unsigned)kc * (unsigned)ld * 4u;
+            }
+            issue(r[i], reinterpret_cast<const float*>(base + off));
+        }
+    }
     __device__ static __forceinline__ void load_fast(f32x4 (&r)[NV], const float* __restrict__ G, int ld,
                                                      int rows, int K, int r0, int k0, int tid, const int (&pr)[NV],
                                                      const int* kl, int kbase) {
@@ -306,10 +333,18 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     }
     TileA::phys_rows(pra, g.M, m0, tid, rmapA, fast);
     TileB::phys_rows(prb, g.N, n0, tid, nullptr, fast);
+    unsigned boa[TileA::NV], bob[TileB::NV];
+    if (fast) { TileA::fast_bases(boa, g.lda, g.M, m0, tid, pra); TileB::fast_bases(bob, g.ldb, g.N, n0, tid, prb); }
+    else {
+#pragma unroll
+        for (int i = 0; i < TileA::NV; ++i) boa[i] = 0;
+#pragma unroll
+        for (int i = 0; i < TileB::NV; ++i) bob[i] = 0;
+    }
     auto gload = [&](f32x4 (&ra)[TileA::NV], f32x4 (&rb)[TileB::NV], int slab, auto fast_c) {
         if constexpr (decltype(fast_c)::value) {
-            TileA::load_fast(ra, g.A, g.lda, g.M, g.K, m0, slab * BK, tid, pra, kl, kbase);
-            TileB::load_fast(rb, g.B, g.ldb, g.N, g.K, n0, slab * BK, tid, prb, kl, kbase);
+            TileA::load_fast_b(ra, g.A, boa, g.lda, g.K, slab * BK, tid, kl, kbase);
+            TileB::load_fast_b(rb, g.B, bob, g.ldb, g.K, slab * BK, tid, kl, kbase);
         } else {
             TileA::load(ra, g.A, g.lda, g.M, g.K, m0, slab * BK, g.vecA, tid, pra, kmap);
             TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, slab * BK, g.vecB, tid, prb, kmap);
@@ -671,6 +706,10 @@ int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
         if (ints <= 4096) g.kmap_lds = ints;      // 16 KB at most next to the 30 KB of tiles (64x64 configuration)
     }
     if (!g_tune_gemm_fast) g.flags |= 1 << 21;
+    {   // the branch-free path addresses with 32-bit byte offsets: operands of 4 GB or more take the general path
+        const double ea = ta ? (double)g.K * g.lda : (double)g.M * g.lda, eb = tb ? (double)g.N * g.ldb : (double)g.K * g.ldb;
+        if (ea * 4.0 >= 4.0e9 || eb * 4.0 >= 4.0e9) g.flags |= 1 << 21;
+    }
     // Walk order inside an XCD's run of tiles.  n fastest re-reads every B panel once per tile row: fine while all of B
     // (N x K) stays in the XCD's 4 MB L2, but the vocabulary projection's B is 7.7 MB while its A is 2 MB -- every tile row
     // streamed B again from beyond L2 (160 MB of fills for a 99 MB output).  m fastest keeps A resident and reads B once.
