@@ -17,7 +17,8 @@
 int g_tune_deterministic = 0;   // 1: bit-reproducible gradients -- no split-K (fp32 atomics), embedding gradient by a destination-major scan
 int g_tune_rec_pair = 1;     // 1 (default): two workgroups per caption in the recurrent kernels (recurrent_pair.hip)
 int g_tune_rec_rotate = 1;
-int g_tune_splitk_target = 1024;   // workgroups a split-K weight-gradient GEMM of the composites aims at (caphn_tune 17)
+int g_tune_splitk_target = 1280;   // workgroups a split-K GEMM of the composites aims at (caphn_tune 17): five 64x64 workgroups per CU.
+                                   // Same-box A/B: 1024 1.907/1.911, 1152 1.909/1.904, 1280 1.897/1.901 ms (256, 512, 2048: slower)
 int g_tune_chain_main = 0;  // 1: with the hypernet VJP hooked in, the chain to it runs on the caller's stream (see "after BPTT");
                             // measured 30 us per step WORSE than 0 (2.026/2.023 vs 1.996/1.994 ms, same box, alternating)
 int g_tune_fork = 4;        // 0: one stream; 1: independent branches on side streams, the vocabulary weight gradient (dW_fc) starting

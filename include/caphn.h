@@ -492,8 +492,9 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * attention / feature_fc chain on a side stream, 0 (default) = the other way round; key 4 values: 0 one stream, 1 vocabulary weight
  * gradient after BPTT, 2 beside BPTT, 3 big leaves held back, 4 (default) 2 with the pair recurrent kernels else 1; key 16:
  * 1 (default) = the pair recurrent kernels keep part of [U_a; W_hh] on chip (registers + spare LDS) for the whole kernel, 0 = all
- * rows streamed from L2 every time step; key 17: workgroups a split-K weight-gradient GEMM of the composites aims at (default
- * 1024; 256 / 512 / 2048 measured slower).
+ * rows streamed from L2 every time step; key 17: workgroups a split-K GEMM of the composites aims at (default 1280; 256 / 512 /
+ * 1024 / 2048 measured slower); key 18: tile walk of the split-bf16 GEMM inside an XCD (0 n fastest, 1 (default) m fastest when
+ * B outgrows the L2 and A is the smaller operand, 2 m fastest always).
  * Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
