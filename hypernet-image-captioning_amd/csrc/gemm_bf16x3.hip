@@ -32,7 +32,12 @@ extern "C" int caphn_debug_gemm_prof(unsigned long long* out, int reset) {
 namespace {
 
 constexpr int BK = 32;
-constexpr int PITCH = 40;          // bf16 elements per LDS row (32 + 8 pad): 80 B = 5 x 16 B
+constexpr int PITCH = 32;          // bf16 elements per LDS row of a K-contiguous operand: no pad -- the four 16-byte chunks of
+                                   // row r are stored at chunk ^ ((r >> 2) & 3), which makes the 16-lane groups of a
+                                   // ds_read_b128 fragment read (rows r, r+1, .. of one chunk) hit 16 distinct 16-byte slots of
+                                   // the 256-byte bank row, and the staging stores of two rows fill one 128-byte half.
+                                   // (The 80-byte padded pitch this replaces showed 33 % bank-conflict cycles in SQ_LDS_BANK_CONFLICT.)
+__device__ __forceinline__ int kc_off(int row, int k) { return row * PITCH + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7); }
 
 // LDS image of one operand tile: three bf16 planes.
 //  KC (K contiguous in memory): [BMN rows][PITCH] -- a fragment is one ds_read_b128 of a row.
@@ -156,7 +161,7 @@ struct TileS {
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + 256 * i;
             const bf16x4 v = {(__bf16)r[i][0], (__bf16)r[i][1], (__bf16)r[i][2], (__bf16)r[i][3]};
-            __bf16* p = KC ? S + (idx >> 3) * PITCH + (idx & 7) * 4
+            __bf16* p = KC ? S + kc_off(idx >> 3, (idx & 7) * 4)
                            : S + (idx / (BMN / 4)) * PITCHM + (idx % (BMN / 4)) * 4;
             *reinterpret_cast<bf16x4*>(p) = v;
         }
@@ -166,7 +171,7 @@ struct TileS {
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + 256 * i;
             const Split4 s = split3(r[i]);
-            __bf16* p = KC ? S + (idx >> 3) * PITCH + (idx & 7) * 4
+            __bf16* p = KC ? S + kc_off(idx >> 3, (idx & 7) * 4)
                            : S + (idx / (BMN / 4)) * PITCHM + (idx % (BMN / 4)) * 4;
             *reinterpret_cast<bf16x4*>(p) = s.hi;
             *reinterpret_cast<bf16x4*>(p + PLANE) = s.mid;
@@ -220,7 +225,7 @@ struct TileS {
             const int idx = tid + 256 * i;
             const int k = KC ? k0 + (idx & 3) * 8 : k0 + idx / (BMN / 8);
             const bool dead = k >= K;                 // K tail of the last slab: zeros (K % 8 == 0, so whole chunks)
-            __bf16* p = KC ? S + (idx >> 2) * PITCH + (idx & 3) * 8
+            __bf16* p = KC ? S + kc_off(idx >> 2, (idx & 3) * 8)
                            : S + (idx / (BMN / 8)) * PITCHM + (idx % (BMN / 8)) * 8;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
@@ -233,7 +238,7 @@ struct TileS {
     // MFMA operand of lane l (r = l&31, h = l>>5) for k-step ks: elements k = 16 ks + 8 h + (0..7) of row `row0 + r`
     __device__ static __forceinline__ bf16x8 frag(const __bf16* __restrict__ S, int plane, int row0, int ks, int lane) {
         if (KC) {
-            return *reinterpret_cast<const bf16x8*>(S + plane * PLANE + (row0 + (lane & 31)) * PITCH + ks * 16 + (lane >> 5) * 8);
+            return *reinterpret_cast<const bf16x8*>(S + plane * PLANE + kc_off(row0 + (lane & 31), ks * 16 + (lane >> 5) * 8));
         } else {
             // 16-lane group g reads a 4(k) x 16(m) block; lane 4q+p supplies the address of k-row q, columns 4p..4p+3
             // and receives column (lane&15) of the four rows.
