@@ -17,6 +17,7 @@
 int g_tune_deterministic = 0;   // 1: bit-reproducible gradients -- no split-K (fp32 atomics), embedding gradient by a destination-major scan
 int g_tune_rec_pair = 1;     // 1 (default): two workgroups per caption in the recurrent kernels (recurrent_pair.hip)
 int g_tune_rec_rotate = 1;
+int g_tune_branch_mask = 7;         // side branches of the composites in use (bit i: branch i; a cleared branch runs on the caller's stream)
 int g_tune_splitk_target = 1280;   // workgroups a split-K GEMM of the composites aims at (caphn_tune 17): five 64x64 workgroups per CU.
                                    // Same-box A/B: 1024 1.907/1.911, 1152 1.909/1.904, 1280 1.897/1.901 ms (256, 512, 2048: slower)
 int g_tune_chain_main = 0;  // 1: with the hypernet VJP hooked in, the chain to it runs on the caller's stream (see "after BPTT");
@@ -63,10 +64,10 @@ struct Side {
         main = m; on = enable;
         return init();
     }
-    hipStream_t s(int i) const { return on ? st[i] : main; }
+    hipStream_t s(int i) const { return (on && ((g_tune_branch_mask >> i) & 1)) ? st[i] : main; }
     // branch i starts after everything enqueued on main so far
     int forkto(int i) {
-        if (!on) return CAPHN_OK;
+        if (!on || !((g_tune_branch_mask >> i) & 1)) return CAPHN_OK;
         if (hipEventRecord(fork, main) != hipSuccess) return CAPHN_ELAUNCH;
         if (hipStreamWaitEvent(st[i], fork, 0) != hipSuccess) return CAPHN_ELAUNCH;
         forked[i] = true;
@@ -78,6 +79,7 @@ struct Side {
         if (!on) return CAPHN_OK;
         if (hipEventRecord(fork, main) != hipSuccess) return CAPHN_ELAUNCH;
         for (int i : ids) {
+            if (!((g_tune_branch_mask >> i) & 1)) continue;       // branch folded into the caller's stream
             if (hipStreamWaitEvent(st[i], fork, 0) != hipSuccess) return CAPHN_ELAUNCH;
             forked[i] = true;
         }
@@ -85,7 +87,7 @@ struct Side {
     }
     // main continues only after branch i's work so far
     int jointo(int i) {
-        if (!on) return CAPHN_OK;
+        if (!on || !((g_tune_branch_mask >> i) & 1)) return CAPHN_OK;
         forked[i] = false;
         if (hipEventRecord(join[i], st[i]) != hipSuccess) return CAPHN_ELAUNCH;
         return hipStreamWaitEvent(main, join[i], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
@@ -98,12 +100,15 @@ struct Side {
         ~Scope() { for (int i = 0; i < 3; ++i) if (s.on && s.forked[i]) (void)s.jointo(i); }
     };
     // cross-branch dependency in two halves: record slot k at the producer's current tail, wait later on the consumer
+    // (a record remembers its stream: a wait on that same stream is dropped -- stream order already gives it)
+    hipStream_t xfrom[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int record(int k, hipStream_t from) {
         if (!on) return CAPHN_OK;
+        xfrom[k] = from;
         return hipEventRecord(x[k], from) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
     }
     int wait(int k, hipStream_t to) {
-        if (!on) return CAPHN_OK;
+        if (!on || xfrom[k] == to) return CAPHN_OK;
         return hipStreamWaitEvent(to, x[k], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
     }
     // `to` waits for what `from` has enqueued so far (cross-branch dependency), via event slot k

@@ -494,7 +494,8 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * 1 (default) = the pair recurrent kernels keep part of [U_a; W_hh] on chip (registers + spare LDS) for the whole kernel, 0 = all
  * rows streamed from L2 every time step; key 17: workgroups a split-K GEMM of the composites aims at (default 1280; 256 / 512 /
  * 1024 / 2048 measured slower); key 18: tile walk of the split-bf16 GEMM inside an XCD (0 n fastest, 1 (default) m fastest when
- * B outgrows the L2 and A is the smaller operand, 2 m fastest always).
+ * B outgrows the L2 and A is the smaller operand, 2 m fastest always); key 20: bit mask of the composites' side branches in
+ * use (default 7 = all three; a cleared branch runs on the caller's stream -- every smaller set measured 10-70 us slower).
  * Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
