@@ -17,6 +17,7 @@
 int g_tune_deterministic = 0;   // 1: bit-reproducible gradients -- no split-K (fp32 atomics), embedding gradient by a destination-major scan
 int g_tune_rec_pair = 1;     // 1 (default): two workgroups per caption in the recurrent kernels (recurrent_pair.hip)
 int g_tune_rec_rotate = 1;
+int g_tune_vocab_order = 1;         // fork mode 2: 0 vocabulary gradients start beside the dHs GEMM, 1 after it (beside BPTT only)
 int g_tune_branch_mask = 7;         // side branches of the composites in use (bit i: branch i; a cleared branch runs on the caller's stream)
 int g_tune_splitk_target = 1280;   // workgroups a split-K GEMM of the composites aims at (caphn_tune 17): five 64x64 workgroups per CU.
                                    // Same-box A/B: 1024 1.907/1.911, 1152 1.909/1.904, 1280 1.897/1.901 ms (256, 512, 2048: slower)
@@ -606,7 +607,8 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     const int fork_mode = g_tune_fork == 4 ? (pair ? 2 : 1) : g_tune_fork;
     const bool late = fork_mode != 2;
     const bool gz = d->grads_zeroed != 0;
-    if (!late) {
+    const bool wg_first = !late && g_tune_vocab_order == 0;     // vocabulary gradients beside the dHs GEMM (and BPTT after it)
+    if (wg_first) {
         RUN(sd.forkto(0));
         RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, sd.s(0), gz));
         RUN(sd.milestone(CAPHN_MS_VOCAB, sd.s(0)));
@@ -617,6 +619,13 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
                               rmap + 4, rmap, 1, s));
     } else
     RUN(gemm_auto(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, s));
+    if (!late && !wg_first) {
+        // ... or only beside BPTT: dHs = dlogits W_fc sits on the chain into BPTT and ran 135 instead of ~105 us with the
+        // vocabulary gradients streaming the same 99 MB of d logits next to it; BPTT alone is long enough to cover them
+        RUN(sd.forkto(0));
+        RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, sd.s(0), gz));
+        RUN(sd.milestone(CAPHN_MS_VOCAB, sd.s(0)));
+    }
 
     RecBwdArgs a;
     a.B = B; a.T = T; a.P = P; a.H = H; a.RG = RG;

@@ -570,6 +570,7 @@ extern int g_tune_rec_cache;
 extern int g_tune_splitk_target;
 extern int g_tune_gemm_order;
 extern int g_tune_branch_mask;
+extern int g_tune_vocab_order;
 extern int g_det_vocab;
 int caphn_rec_pair_debug_skip(int v);
 extern "C" int caphn_tune(int key, int value) {
@@ -586,6 +587,7 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 11) { g_tune_gemm_single = value; return CAPHN_OK; }
     if (key == 12) { g_tune_gemm_tile = value; return CAPHN_OK; }
     if (key == 13) { g_tune_deterministic = value > 0; g_det_vocab = value; return CAPHN_OK; }
+    if (key == 21) { g_tune_vocab_order = value != 0; return CAPHN_OK; }
     if (key == 20) { if (value < 0 || value > 7) return CAPHN_EINVAL; g_tune_branch_mask = value; return CAPHN_OK; }
     if (key == 18) { if (value < 0 || value > 2) return CAPHN_EINVAL; g_tune_gemm_order = value; return CAPHN_OK; }
     if (key == 17) { if (value < 1 || value > 65536) return CAPHN_EINVAL; g_tune_splitk_target = value; return CAPHN_OK; }

@@ -495,7 +495,8 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * rows streamed from L2 every time step; key 17: workgroups a split-K GEMM of the composites aims at (default 1280; 256 / 512 /
  * 1024 / 2048 measured slower); key 18: tile walk of the split-bf16 GEMM inside an XCD (0 n fastest, 1 (default) m fastest when
  * B outgrows the L2 and A is the smaller operand, 2 m fastest always); key 20: bit mask of the composites' side branches in
- * use (default 7 = all three; a cleared branch runs on the caller's stream -- every smaller set measured 10-70 us slower).
+ * use (default 7 = all three; a cleared branch runs on the caller's stream -- every smaller set measured 10-70 us slower); key 21:
+ * with the vocabulary weight gradient beside BPTT (key 4 = 2), 1 (default) starts it after the dHs GEMM, 0 beside it.
  * Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
