@@ -19,6 +19,10 @@
 // per-phase shader-clock stamps of workgroup (0,0,0), wave 0 (tools/gemm_phase_profile.py): compile with -DCAPHN_GEMM_PROFILE
 #ifdef CAPHN_GEMM_PROFILE
 __device__ unsigned long long d_gemm_prof[10];
+__device__ unsigned long long d_gemm_wgt[2 * 8192];     // per workgroup: wall-clock (100 MHz) at entry and after the epilogue
+extern "C" int caphn_debug_gemm_wgtimes(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(d_gemm_wgt), sizeof(unsigned long long) * 2 * (n < 8192 ? n : 8192)) == hipSuccess ? 0 : -1;
+}
 #define GSTAMP(i) do { if (gprof) { unsigned long long _n = clock64(); gpc[i] += _n - glast; glast = _n; } } while (0)
 extern "C" int caphn_debug_gemm_prof(unsigned long long* out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(d_gemm_prof), sizeof(unsigned long long) * 10) != hipSuccess) return -1;
@@ -276,6 +280,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     const int li = lane & 31, kh = lane >> 5;
 #ifdef CAPHN_GEMM_PROFILE
     const unsigned long long gstart = clock64();
+    const unsigned gwg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (tid == 0 && gwg < 8192) d_gemm_wgt[2 * gwg] = wall_clock64();
 #endif
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so neighbouring tiles
     // -- which share an operand panel -- would land on eight different L2s and each fetch the panel from HBM.  Give
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         const int last = slab1 - 1;
 #ifdef CAPHN_GEMM_PROFILE
         const bool gprof = tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-        unsigned long long gpc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, glast = gprof ? clock64() : 0;
+        unsigned long long gpc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, glast = gprof ? clock64() : 0;
 #endif
         gload(ra0, rb0, slab0, fc);
         if (F || slab0 + 1 < slab1) gload(ra1, rb1, min(slab0 + 1, last), fc);
@@ -450,6 +456,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             __syncthreads();
             GSTAMP(3);                              // barrier after the multiply
             if (slab + 1 >= slab1) break;
+#ifdef CAPHN_GEMM_PROFILE
+            if constexpr (F) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TileA::NV + TileB::NV)); GSTAMP(9); }   // pure wait for the older set
+#endif
             stage(ra1, rb1, slab + 1, fc);
             GSTAMP(4);                              // wait for the older register set, split, LDS stores
             __syncthreads();
@@ -463,6 +472,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             __syncthreads();
             GSTAMP(3);
             if (slab + 2 < slab1) {
+#ifdef CAPHN_GEMM_PROFILE
+                if constexpr (F) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TileA::NV + TileB::NV)); GSTAMP(9); }
+#endif
                         stage(ra0, rb0, slab + 2, fc);
                 GSTAMP(4);
                 __syncthreads();
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             }
         }
 #ifdef CAPHN_GEMM_PROFILE
-        if (gprof) { for (int i = 0; i < 6; ++i) atomicAdd(&d_gemm_prof[i], gpc[i]); atomicAdd(&d_gemm_prof[6], (unsigned long long)(slab1 - slab0)); atomicAdd(&d_gemm_prof[7], 1ull); }
+        if (gprof) { for (int i = 0; i < 6; ++i) atomicAdd(&d_gemm_prof[i], gpc[i]); atomicAdd(&d_gemm_prof[9], gpc[9]); atomicAdd(&d_gemm_prof[6], (unsigned long long)(slab1 - slab0)); atomicAdd(&d_gemm_prof[7], 1ull); }
 #endif
     };
     // fused bias gradient from the planes: x = hi + mid + lo
@@ -645,9 +657,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             }
         }
 #ifdef CAPHN_GEMM_PROFILE
-    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    if (tid == 0) {
         __builtin_amdgcn_s_waitcnt(0);          // the epilogue's stores have left the wave
-        atomicAdd(&d_gemm_prof[8], clock64() - gstart);
+        if (gwg < 8192) d_gemm_wgt[2 * gwg + 1] = wall_clock64();
+        if (gwg == 0) atomicAdd(&d_gemm_prof[8], clock64() - gstart);
     }
 #endif
 }
@@ -723,6 +736,10 @@ int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
         if (g_tune_gemm_order == 2 || (bbytes > l2 && abytes < bbytes)) g.flags |= 1 << 22;
     }
     long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.splitk;
+    // K of a few slabs (the vocabulary projection, K = 200): the product is output-bound, a workgroup lives ~20 us and the
+    // kernel time is rounds x lifetime -- 1140 128x128 workgroups on 512 slots are 2.2 rounds, the same tiles as 64x64 fill the
+    // chip evenly (step 1.771/1.822 -> 1.762/1.811 ms).  The big tile pays off when K is long enough to amortise its epilogue.
+    if (g.K < 512) tiles128 = 0;
     if (g_tune_gemm_tile == 64) tiles128 = 0; else if (g_tune_gemm_tile == 128) tiles128 = 1 << 20;      // A/B experiments (caphn_tune key 12)
     const bool pl = caphn_gemm_planes_ok(g, ta, tb);
     if (pl) {

@@ -47,7 +47,8 @@ for sh in shapes:
     print(f"   {names[0]:34s} {v[0] / max(launches, 1):9.0f} cycles per launch")
     for n, c in zip(names[1:], v[1:6]):
         print(f"   {n:34s} {c / max(slabs, 1):9.0f} cycles per slab")
-    print(f"   {'sum per slab':34s} {sum(v[1:6]) / max(slabs, 1):9.0f}")
+    print(f"   {'  of which: pure wait for loads':34s} {v[9] / max(slabs, 1):9.0f} cycles per slab (counted apart from the stage line above)")
+    print(f"   {'sum per slab':34s} {(sum(v[1:6]) + v[9]) / max(slabs, 1):9.0f}")
     tot = v[8] / max(launches, 1)
     print(f"   {'workgroup 0 lifetime':34s} {tot:9.0f} cycles; outside prologue and loop (epilogue, setup) "
           f"{tot - v[0] / max(launches, 1) - sum(v[1:6]) / max(launches, 1):9.0f}")
