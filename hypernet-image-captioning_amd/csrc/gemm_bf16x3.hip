@@ -699,9 +699,10 @@ int g_tune_gemm_single = 0;   // 1: reduced-precision side mode -- one bf16 prod
 int g_tune_gemm_order = 1;    // tile walk inside an XCD: 0 n fastest always, 1 (default) m fastest when B outgrows L2 and A is the smaller, 2 m fastest always
 int g_tune_gemm_xcd = 1;      // 1 (default): XCD-aware tile order
 int g_tune_gemm_fast = 1;     // 1 (default): branch-free loads (static vmcnt) where alignment allows
-// Tile choice: 128x128 when that alone gives >= 512 workgroups, else 64x64 (five workgroups per CU).  Measured and
-// dropped: 64x256 / 256x64 tiles spanning the whole short side of the N = 200 problems (the long operand is read once,
-// but two workgroups per CU hide far less latency: 1.3-2x slower) and 128x64 (no change).
+// Tile choice: 128x128 when that alone gives >= 512 workgroups and K >= 512, else 64x64 (four workgroups per CU:
+// caphn_debug_gemm_occupancy).  Measured and dropped: 64x256 / 256x64 tiles spanning the whole short side of the N = 200 problems
+// (the long operand is read once, but two workgroups per CU hide far less latency: 1.3-2x slower) and 128x64 (round 1: no change;
+// round 2, after the epilogue fix: three workgroups per CU, +50 us per step).
 // pre-split operands: usable when every 16-byte chunk is aligned and whole (K % 8 == 0; K-slow extents may end inside
 // the padding of their leading dimension) and, with a K map, when its slice fits the LDS (the branch-free path)
 bool caphn_gemm_planes_ok(const GemmArgs& g, int ta, int tb) {
@@ -714,6 +715,20 @@ bool caphn_gemm_planes_ok(const GemmArgs& g, int ta, int tb) {
         if (!(ta && !tb) || ((nslab + sk - 1) / sk) * 32 > 4096) pl = false;
     }
     return pl;
+}
+// resident workgroups per CU of the default-mode kernel for an operand layout (tools: how many rounds a launch takes)
+template <int BM, int BN, bool TA, bool TB>
+static int occ_one() {
+    using TileA = TileS<BM, !TA>;
+    using TileB = TileS<BN, TB>;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(gemm_bf16x3_kernel<BM, BN, TA, TB, 0>), 256,
+                                                     sizeof(__bf16) * (TileA::ELEMS + TileB::ELEMS)) != hipSuccess) return -1;
+    return n;
+}
+extern "C" int caphn_debug_gemm_occupancy(int ta, int tb, int tile) {
+    if (tile == 128) return !ta && tb ? occ_one<128, 128, false, true>() : !ta ? occ_one<128, 128, false, false>() : !tb ? occ_one<128, 128, true, false>() : occ_one<128, 128, true, true>();
+    return !ta && tb ? occ_one<64, 64, false, true>() : !ta ? occ_one<64, 64, false, false>() : !tb ? occ_one<64, 64, true, false>() : occ_one<64, 64, true, true>();
 }
 int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
     if (g_tune_gemm_xcd) g.flags |= 1 << 20;
