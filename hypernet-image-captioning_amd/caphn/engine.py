@@ -410,9 +410,15 @@ class FusedTrainer:
             torch.cuda.current_stream().wait_event(self._pre_done)      # even if the announced batch did not come
             if pre == 7:
                 rows_done = True
-            if pre:
-                import dataclasses
-                fdims = dataclasses.replace(dims, pre=pre)
+        # bit 8 on both sides of the step: the forward zero-fills the backward's d Hs accumulator inside a kernel it launches
+        # anyway, the backward skips its own fill (it sat on the chain between the loss and the first backward GEMM)
+        dv = buf.get("dims_variants") if dims is buf["dims"] else None
+        if dv is None:
+            import dataclasses
+            dv = {p: dataclasses.replace(dims, pre=p | 8) for p in (0, 1, 5, 7)}
+            if dims is buf["dims"]:          # (with decoder dropout the dims carry a fresh seed every step: not cached)
+                buf["dims_variants"] = dv
+        fdims = dv[pre]
         if dims.rows and not rows_done:
             ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
         ops.decoder_forward(fdims, params, features, captions, buf["ws"], logits=buf["logits"], want_alphas=False,
@@ -440,7 +446,7 @@ class FusedTrainer:
                                          dtype=torch.uint8, device=self.dev)
         # decoder backward with the hypernet VJP hooked in: it starts on a side stream as soon as dtheta is
         # complete and streams the 576 MB of second-layer weights beside the attention / feature_fc chain
-        gx = ops.decoder_hyper_backward(dims, params, features, captions, dlogits, grads, buf["ws"],
+        gx = ops.decoder_hyper_backward(dv[0], params, features, captions, dlogits, grads, buf["ws"],
                                         self.shape, hp, self._acts, hg, self._hyper_ws,
                                         want_x=style_token is not None or domain_input is not None)
         if domain_input is not None:    # the input row's gradient goes on through the front-end, before the exchange is issued

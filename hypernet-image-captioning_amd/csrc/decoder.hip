@@ -519,7 +519,7 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
         a.xch = reinterpret_cast<unsigned long long*>(ws + w.xch);
         a.WP = ws + w.wp; a.wp_pitch = caphn_rec_pair_pitch(H);
         RUN(caphn_launch_rec_pair_prep(a.xch, 2 * w.xch_floats * sizeof(float) / sizeof(unsigned long long), p->Ua_w, p->w_hh, H, w.NG,
-                                       ws + w.wp, s));
+                                       ws + w.wp, (pc & 8) ? ws + w.dHs : nullptr, (size_t)BT * H, s));
         RUN(caphn_launch_rec_pair_fwd(a, lstm, s));
     } else if (w.L1 > 0) {
         // num_layers > 1: one launch window per step.  The attention cell writes its h_t to H0s, the extra cells take it to
@@ -533,6 +533,7 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
         }
     } else
     RUN(caphn_launch_rec_fwd(a, lstm, s));
+    if ((pc & 8) && !pair) RUN(caphn_zero_f32(ws + w.dHs, (size_t)BT * H, s));      // (the pair path folded it into its prep kernel)
 
     // vocab projection for all (b,t) at once      decoderlstm.py:105
     if (d->row_subset)     // only rows with a live target (caphn_decoder_prepare_rows)
@@ -613,12 +614,13 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
         RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, sd.s(0), gz));
         RUN(sd.milestone(CAPHN_MS_VOCAB, sd.s(0)));
     }
+    const bool dhs_zero = (d->precomputed & 8) != 0;      // the forward of this step left d Hs zero-filled (dims.precomputed bit 8)
     if (rmap) {   // rows of ignored targets have d logits == 0: dHs of those rows is zero, the others are gathered
-        RUN(caphn_zero_f32(ws + w.dHs, (size_t)BT * H, s));
+        if (!dhs_zero) RUN(caphn_zero_f32(ws + w.dHs, (size_t)BT * H, s));
         RUN(caphn_gemm_mapped(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, pick_splitk(BT, H, V),
                               rmap + 4, rmap, 1, s));
     } else
-    RUN(gemm_auto(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, s));
+    RUN(gemm_auto(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, s, nullptr, 0, dhs_zero));
     if (!late && !wg_first) {
         // ... or only beside BPTT: dHs = dlogits W_fc sits on the chain into BPTT and ran 135 instead of ~105 us with the
         // vocabulary gradients streaming the same 99 MB of d logits next to it; BPTT alone is long enough to cover them
@@ -873,7 +875,7 @@ extern "C" int caphn_decoder_forward_sampled_train(const caphn_decoder_dims* d, 
         a.xch = reinterpret_cast<unsigned long long*>(ws + w.xch);
         a.WP = ws + w.wp; a.wp_pitch = caphn_rec_pair_pitch(H);
         RUN(caphn_launch_rec_pair_prep(a.xch, 2 * w.xch_floats * sizeof(float) / sizeof(unsigned long long), p->Ua_w, p->w_hh, H, w.NG,
-                                       ws + w.wp, s));
+                                       ws + w.wp, nullptr, 0, s));
     }
     if (w.L1 > 0) {     // as in caphn_decoder_forward
         RUN(layers_forward(d, p, w, ws, 0, ws + w.h0, H, ws + w.h0L, H, s));

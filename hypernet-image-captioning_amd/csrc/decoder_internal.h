@@ -101,7 +101,7 @@ int caphn_rec_pair_bwd_groups(int P, int H);
 int caphn_rec_pair_pitch(int H);
 size_t caphn_rec_pair_wp_floats(int H, int NG);
 int caphn_launch_rec_pair_prep(unsigned long long* xch, size_t nxch, const float* U_a, const float* W_hh, int H, int NG, float* WP,
-                               hipStream_t s);
+                               float* zbuf, size_t nz, hipStream_t s);      // zbuf (optional): nz floats zero-filled on the way
 int caphn_launch_rec_pair_fwd(const RecFwdArgs& a, bool lstm, hipStream_t s);
 int caphn_launch_rec_pair_bwd(const RecBwdArgs& a, bool lstm, hipStream_t s);
 int caphn_rec_bwd_groups(int P, int H);     // > 0: the backward kernel can fuse the attention parameter gradients (rows of `apart` per caption)

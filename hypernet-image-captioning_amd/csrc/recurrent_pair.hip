@@ -864,9 +864,13 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 // one launch in front of the pair forward: the exchange areas (forward and backward of this step) get tag 0 in every
 // granule -- written through (agent scope), like every later store to them -- and [U_a; W_hh] is packed to the aligned pitch
 __global__ __launch_bounds__(256) void pair_prep_kernel(u64* __restrict__ xch, size_t nxch, const float* __restrict__ U_a,
-                                                        const float* __restrict__ W_hh, int H, int rows, int pitch, float* __restrict__ WP) {
+                                                        const float* __restrict__ W_hh, int H, int rows, int pitch, float* __restrict__ WP,
+                                                        float* __restrict__ zbuf, size_t nz) {
     const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
     for (size_t j = i0; j < nxch; j += stride) __hip_atomic_store(xch + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a buffer the backward wants zero-filled -- d Hs, accumulated by split-K atomics -- rides along: its own launch sat on the
+    //  chain between the loss and the first backward GEMM)
+    for (size_t j = i0; j < nz; j += stride) zbuf[j] = 0.f;
     if ((H & 3) == 0 && caphn_aligned16_dev(U_a) && caphn_aligned16_dev(W_hh)) {
         // whole pitch written: the pad columns hold zeros, so a lane may read its chunk without a bounds clamp (one base address
         // and immediate offsets instead of an address pair per chunk)
@@ -893,8 +897,9 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(u64* __restrict__ xch, s
 int caphn_rec_pair_pitch(int H) { const int p = (H + 31) & ~31; return p < 32 * JM ? 32 * JM : p; }
 size_t caphn_rec_pair_wp_floats(int H, int NG) { return (size_t)(NG + 1) * H * caphn_rec_pair_pitch(H); }
 int caphn_launch_rec_pair_prep(unsigned long long* xch, size_t nxch, const float* U_a, const float* W_hh, int H, int NG, float* WP,
-                               hipStream_t s) {
-    hipLaunchKernelGGL(pair_prep_kernel, dim3(256), dim3(256), 0, s, xch, nxch, U_a, W_hh, H, (NG + 1) * H, caphn_rec_pair_pitch(H), WP);
+                               float* zbuf, size_t nz, hipStream_t s) {
+    hipLaunchKernelGGL(pair_prep_kernel, dim3(256), dim3(256), 0, s, xch, nxch, U_a, W_hh, H, (NG + 1) * H, caphn_rec_pair_pitch(H), WP,
+                       zbuf, zbuf ? nz : 0);
     return caphn_launch_status();
 }
 int caphn_rec_pair_debug_skip(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(d_skip_xrecv), &v, sizeof(int)) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH; }

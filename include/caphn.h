@@ -190,7 +190,9 @@ typedef struct caphn_decoder_dims {
                            skips it: 1 = feature_fc / init_hidden / W_a f (caphn_decoder_precompute), 2 = G (the same call
                            given captions, i.e. after the generated W_ih is final), 4 = embedding lookup + x-side gate
                            pre-activations (caphn_decoder_inputs, or that same call).  7: the forward starts at the
-                           recurrent kernel */
+                           recurrent kernel.  Bit 8, given to BOTH caphn_decoder_forward and the backward of the same step on the
+                           same workspace: the forward leaves the backward's d Hs accumulator zero-filled (inside a kernel it
+                           launches anyway) and the backward skips its own zero fill */
     int layers;         /* num_layers of AttentionGru (models/decoderlstm.py:34-36): 1 (or 0) = the cell alone; L > 1 adds L - 1 GRUCells
                            applied as h = layer(h, h) after the attention cell at every time step (:101-103).  Then the time loop
                            runs one launch window per step (the extra cells are small batched GEMMs + a gate kernel between the
