@@ -406,8 +406,10 @@ class FusedTrainer:
                     ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
                     rows_done = True
                 ops.decoder_inputs(dims, params, captions, buf["ws"])
-                pre = 5
-            torch.cuda.current_stream().wait_event(self._pre_done)      # even if the announced batch did not come
+                pre = 5 | 16      # bit 16: the forward composite waits for the side stream's precompute itself, piecewise
+                                  # (feature_fc output before G, the rest before the recurrent kernel)
+            if not (pre & 16):
+                torch.cuda.current_stream().wait_event(self._pre_done)      # even if the announced batch did not come
             if pre == 7:
                 rows_done = True
         # bit 8 on both sides of the step: the forward zero-fills the backward's d Hs accumulator inside a kernel it launches
@@ -415,7 +417,7 @@ class FusedTrainer:
         dv = buf.get("dims_variants") if dims is buf["dims"] else None
         if dv is None:
             import dataclasses
-            dv = {p: dataclasses.replace(dims, pre=p | 8) for p in (0, 1, 5, 7)}
+            dv = {p: dataclasses.replace(dims, pre=p | 8) for p in (0, 1, 5, 7, 21)}
             if dims is buf["dims"]:          # (with decoder dropout the dims carry a fresh seed every step: not cached)
                 buf["dims_variants"] = dv
         fdims = dv[pre]

@@ -40,6 +40,8 @@ struct Side {
     hipStream_t st[3];
     hipEvent_t fork, join[3], x[6];
     hipEvent_t ms[CAPHN_MS_COUNT];     // milestones of the last backward composite (caphn_decoder_backward_milestone)
+    hipEvent_t pre_f, pre_all;         // last caphn_decoder_precompute on this device: feature_fc output ready / everything ready
+    bool pre_valid = false;
     bool ready = false, on = false;
     bool forked[3] = {false, false, false};
     hipStream_t main = nullptr;
@@ -53,6 +55,8 @@ struct Side {
         for (auto& e : join) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
         for (auto& e : x) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
         for (auto& e : ms) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
+        if (hipEventCreateWithFlags(&pre_f, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
+        if (hipEventCreateWithFlags(&pre_all, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
         ready = true;
         return CAPHN_OK;
     }
@@ -315,7 +319,7 @@ inline int wgrad_bias(int M, int N, int K, const float* A, int lda, const float*
 // part 1 (theta-independent: feature_fc, init_hidden, W_a f) can be issued ahead of time by caphn_decoder_precompute
 // (dims.precomputed = 1 then skips it here); part 2 is the G GEMM, which needs the generated W_ih.
 static int decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_params* p, const Ws& w, float* ws,
-                              const float* features, const float** f_out, hipStream_t s, int parts = 3) {
+                              const float* features, const float** f_out, hipStream_t s, int parts = 3, bool mark = false) {
     const int B = d->B, P = d->P, D = d->D, F = d->F, E = d->E, H = d->H;
     const bool lstm = d->cell == CAPHN_CELL_LSTM, raw = d->raw_features != 0;
     const int BP = B * P, GH = w.NG * H, EF = E + F;
@@ -332,6 +336,7 @@ static int decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_p
     Side& sd = *sdp;
     RUN(sd.begin(s, g_tune_fork != 0 && (parts & 1)));
     Side::Scope scope(sd);
+    if (mark && hipEventRecord(sd.pre_f, s) != hipSuccess) return CAPHN_ELAUNCH;      // f exists: a later forward's G GEMM may go
     if (parts & 1) {
         RUN(sd.fork_many({0, 1}));
         // branch 0 -- init_hidden: mean over positions -> Linear(F,H) (and init_c for the LSTM)      :122-135 / :255-260
@@ -468,8 +473,11 @@ extern "C" int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float* f = nullptr;
     // captions given: the generated W_ih / b_ih are final too, so G and the x-side gates can be done as well
-    RUN(decoder_precompute(d, p, w, static_cast<float*>(ws_), features, &f, s, captions ? 3 : 1));
+    RUN(decoder_precompute(d, p, w, static_cast<float*>(ws_), features, &f, s, captions ? 3 : 1, true));
     if (captions) RUN(decoder_inputs(d, p, w, static_cast<float*>(ws_), captions, s));
+    Side* sd = side_here();
+    if (!sd || hipEventRecord(sd->pre_all, s) != hipSuccess) return CAPHN_ELAUNCH;
+    sd->pre_valid = true;
     return caphn_launch_status();
 }
 
@@ -502,7 +510,17 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     // precomputed bits: 1 the theta-independent part, 2 G, 4 the x side (embedding lookup + gate pre-activations)
     const int pc = d->precomputed;
     if (!(pc & 4)) RUN(decoder_inputs(d, p, w, ws, captions, s));
+    // bit 16: part 1 was issued by caphn_decoder_precompute on ANOTHER stream and the caller has not waited for it -- this
+    // composite waits itself, and only where it must: for f before the G GEMM, for init_hidden / W_a f before the recurrent
+    // kernel (the G GEMM then runs beside them instead of behind them)
+    Side* sdw = (pc & 16) ? side_here() : nullptr;
+    if (pc & 16) {
+        if (!sdw || !sdw->pre_valid) return CAPHN_EINVAL;
+        if (hipStreamWaitEvent(s, sdw->pre_f, 0) != hipSuccess) return CAPHN_ELAUNCH;
+    }
     RUN(decoder_precompute(d, p, w, ws, features, &f, s, ((pc & 1) ? 0 : 1) | ((pc & 2) ? 0 : 2)));
+    if (pc & 16)
+        if (hipStreamWaitEvent(s, sdw->pre_all, 0) != hipSuccess) return CAPHN_ELAUNCH;
 
     RecFwdArgs a;
     a.B = B; a.T = T; a.P = P; a.H = H; a.RG = RG;

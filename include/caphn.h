@@ -192,7 +192,10 @@ typedef struct caphn_decoder_dims {
                            pre-activations (caphn_decoder_inputs, or that same call).  7: the forward starts at the
                            recurrent kernel.  Bit 8, given to BOTH caphn_decoder_forward and the backward of the same step on the
                            same workspace: the forward leaves the backward's d Hs accumulator zero-filled (inside a kernel it
-                           launches anyway) and the backward skips its own zero fill */
+                           launches anyway) and the backward skips its own zero fill.  Bit 16 (with bit 1): the
+                           caphn_decoder_precompute call ran on another stream and the caller did NOT wait for it: the forward
+                           waits for it itself -- for the feature_fc output before its G GEMM, for the rest before the
+                           recurrent kernel (not inside a stream capture) */
     int layers;         /* num_layers of AttentionGru (models/decoderlstm.py:34-36): 1 (or 0) = the cell alone; L > 1 adds L - 1 GRUCells
                            applied as h = layer(h, h) after the attention cell at every time step (:101-103).  Then the time loop
                            runs one launch window per step (the extra cells are small batched GEMMs + a gate kernel between the
