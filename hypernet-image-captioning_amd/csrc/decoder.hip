@@ -246,12 +246,14 @@ __global__ void copy2_kernel(const float* __restrict__ src, int n, float* __rest
     else if (i == n) b[0] = src[n];
 }
 
-__global__ void build_idx_kernel(int B, int T, const int64_t* __restrict__ caps, int64_t* __restrict__ idx) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * T) return;
-    const int t = i % T;
-    // x_0 = x_1 = 0 (in-place zero of a view, decoderlstm.py:82-84), x_t = embed[caps[:,t-1]] for t >= 2
-    idx[i] = t < 2 ? (int64_t)-1 : caps[i - 1];
+// the teacher-forced input rows in one launch: idx[i] (kept for the backward's scatter) and Xe row i = embed[idx[i]] or zeros
+// x_0 = x_1 = 0 (in-place zero of a view, decoderlstm.py:82-84), x_t = embed[caps[:,t-1]] for t >= 2
+__global__ __launch_bounds__(256) void teacher_inputs_kernel(int T, int E, const int64_t* __restrict__ caps, const float* __restrict__ table,
+                                                            int64_t* __restrict__ idx, float* __restrict__ out, int ostride) {
+    const int i = blockIdx.x, t = i % T;
+    const int64_t id = t < 2 ? (int64_t)-1 : caps[i - 1];
+    if (threadIdx.x == 0) idx[i] = id;
+    for (int e = threadIdx.x; e < E; e += 256) out[(size_t)i * ostride + e] = id < 0 ? 0.f : table[(size_t)id * E + e];
 }
 
 inline bool dims_ok(const caphn_decoder_dims* d) {
@@ -457,8 +459,7 @@ static int decoder_inputs(const caphn_decoder_dims* d, const caphn_decoder_param
                           const int64_t* captions, hipStream_t s) {
     const int BT = d->B * d->T, E = d->E, GH = w.NG * d->H, EF = d->E + d->F;
     int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
-    hipLaunchKernelGGL(build_idx_kernel, dim3((BT + 255) / 256), dim3(256), 0, s, d->B, d->T, captions, idx);
-    RUN(caphn_embedding_gather_strided(BT, E, p->embed_w, idx, 1, ws + w.Xe, EF, s));
+    hipLaunchKernelGGL(teacher_inputs_kernel, dim3(BT), dim3(256), 0, s, d->T, E, captions, p->embed_w, idx, ws + w.Xe, EF);
     RUN(caphn_gemm_f32(0, 1, BT, GH, E, ws + w.Xe, EF, p->w_ih, EF, ws + w.Xg, GH, p->b_ih, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
     return CAPHN_OK;
 }
