@@ -95,6 +95,8 @@ class FusedTrainer:
         self._next_key = None
         # next-step feature_fc / init_hidden / W_a f issued on a side stream beside the small Adam passes
         self._pre_stream = torch.cuda.Stream(device=dev)
+        self._fork_ev = None
+        self.fork_late = os.environ.get("CAPHN_FORK_LATE", "1") == "1"
         self._pre_key = None
         self._pre_hold = None
         self._next_hold = None
@@ -586,10 +588,19 @@ class FusedTrainer:
             ops.adam_rank(self.W2[i].data, self.W2_m[i], self.W2_v[i], gi, ai, self._coef, self.lr, step,
                           self.betas, self.eps, dev_scalars=self._adam_dev if self._graph_scalars else None, **kw)
             if i == fork_after and next_batch is not None:
-                self._precompute_next(*next_batch, level=2 if full else 1)
+                # the side stream starts HERE on the device (an event), but its launches are enqueued after the remaining passes:
+                # the host otherwise spends ~50 us on the precompute's launches before it gets to the next pass
+                if self._fork_ev is None:
+                    self._fork_ev = torch.cuda.Event()
+                self._fork_ev.record()
+                fork_level = 2 if full else 1
+            if i == fork_after and next_batch is not None and not self.fork_late:
+                self._precompute_next(*next_batch, level=fork_level)
+        if next_batch is not None and fork_after >= 0 and fork_after in order and self.fork_late:
+            self._precompute_next(*next_batch, level=fork_level, after=self._fork_ev)
         return self._coef
 
-    def _precompute_next(self, features, captions, T, level=1):
+    def _precompute_next(self, features, captions, T, level=1, after=None):
         """The decoder's dense parameters are final (adam_dense ran) and the workspace is free (backward is done):
         run the front of the next minibatch's forward on a side stream while the remaining Adam pass streams the
         hypernet (HBM-bound).  level 1: feature_fc / init_hidden / W_a f (theta-independent).  level 2 (next theta's
@@ -603,7 +614,10 @@ class FusedTrainer:
                                                      else torch.empty(self.theta_size, device=self.dev))
         params = self._dec_tensors(theta, grads=False)
         main = torch.cuda.current_stream()
-        self._pre_stream.wait_stream(main)
+        if after is not None:
+            self._pre_stream.wait_event(after)
+        else:
+            self._pre_stream.wait_stream(main)
         with torch.cuda.stream(self._pre_stream):
             if level == 2:
                 cl = captions
