@@ -96,6 +96,7 @@ class FusedTrainer:
         # next-step feature_fc / init_hidden / W_a f issued on a side stream beside the small Adam passes
         self._pre_stream = torch.cuda.Stream(device=dev)
         self._fork_ev = None
+        self._pre_token = None
         self.fork_late = os.environ.get("CAPHN_FORK_LATE", "1") == "1"
         self._pre_key = None
         self._pre_hold = None
@@ -408,8 +409,11 @@ class FusedTrainer:
                     ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
                     rows_done = True
                 ops.decoder_inputs(dims, params, captions, buf["ws"])
-                pre = 5 | 16      # bit 16: the forward composite waits for the side stream's precompute itself, piecewise
-                                  # (feature_fc output before G, the rest before the recurrent kernel)
+                pre = 5
+                if self._pre_token is not None and ops.precompute_epoch(self.dev) == self._pre_token:
+                    pre |= 16     # bit 16: the forward composite waits for the side stream's precompute itself, piecewise
+                                  # (feature_fc output before G, the rest before the recurrent kernel).  The library keeps those
+                                  # events per DEVICE: only valid while nobody has issued another precompute since ours
             if not (pre & 16):
                 torch.cuda.current_stream().wait_event(self._pre_done)      # even if the announced batch did not come
             if pre == 7:
@@ -627,6 +631,7 @@ class FusedTrainer:
             else:
                 ops.decoder_precompute(dims, params, features, buf["ws"])
             self._pre_done.record(self._pre_stream)
+        self._pre_token = ops.precompute_epoch(self.dev)
         self._theta_pre = theta if level == 2 else None
         self._pre_key = (_tkey(features), _tkey(captions) if (level == 2 and captions is not None) else None, B, T, P, level)
         self._pre_hold = (features, captions)         # announced tensors stay alive: their addresses cannot be recycled

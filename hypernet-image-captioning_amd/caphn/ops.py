@@ -399,6 +399,15 @@ def decoder_workspace(dims: DecDims, device) -> torch.Tensor:
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
+_PRE_EPOCH: Dict[int, int] = {}      # device index -> number of caphn_decoder_precompute calls issued from this process
+
+
+def precompute_epoch(device) -> int:
+    """The library keeps the events of the LAST caphn_decoder_precompute per device; a forward that lets the composite wait on
+    them (DecDims.pre bit 16) must know that its own call is still the last one."""
+    return _PRE_EPOCH.get(torch.device(device).index or 0, 0)
+
+
 def decoder_precompute(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor, ws: torch.Tensor,
                        captions: Optional[torch.Tensor] = None) -> None:
     """feature_fc, init_hidden and W_a f of the forward for `features` (models/decoderlstm.py:61-63, attention.py:34),
@@ -411,6 +420,7 @@ def decoder_precompute(dims: DecDims, params: Dict[str, torch.Tensor], features:
         raise L.CaphnError(f"captions {tuple(captions.shape)} do not match {dims}")
     cd = dims.c()
     ps = _dec_struct(L.DecoderParams, dims, params)
+    _PRE_EPOCH[features.device.index or 0] = _PRE_EPOCH.get(features.device.index or 0, 0) + 1
     L.check(lib.caphn_decoder_precompute(C.byref(cd), C.byref(ps), L.ptr(features),
                                          L.ptr(captions, torch.int64, allow_none=True), C.c_void_p(ws.data_ptr()),
                                          L.stream_ptr()), "caphn_decoder_precompute")
