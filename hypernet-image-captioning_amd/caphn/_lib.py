@@ -88,6 +88,7 @@ class SearchCfg(C.Structure):
 SIGNATURES = {
     "caphn_abi_version": (C.c_int, []),
     "caphn_device_arch": (C.c_int, [C.c_char_p, C.c_int]),
+    "caphn_device_error": (C.c_int, [C.c_int]),
     "caphn_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_int,
                                  c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]),
     "caphn_split3_bf16": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_size_t, C.c_int, c_fp]),
@@ -175,7 +176,9 @@ SIGNATURES = {
 }
 
 _ERR = {-1: "CAPHN_EINVAL (bad argument)", -2: "CAPHN_ELAUNCH (HIP launch error)",
-        -3: "CAPHN_ELIMIT (problem exceeds a hardware limit, e.g. 160 KB LDS)"}
+        -3: "CAPHN_ELIMIT (problem exceeds a hardware limit, e.g. 160 KB LDS)",
+        -4: "CAPHN_ETIMEOUT (a recurrent kernel's partner workgroup never answered: that step's results are NaN; "
+            "sticky until caphn_device_error(1))"}
 
 _lib = None
 

@@ -390,6 +390,12 @@ def _dec_struct(cls, dims: DecDims, t: Dict[str, torch.Tensor]):
     return s
 
 
+def device_error(clear: bool = False) -> int:
+    """The current device's sticky failure word (include/caphn.h caphn_device_error): 0 or CAPHN_ETIMEOUT (-4).  Kernels write it
+    asynchronously: synchronise first if the question is about work already enqueued."""
+    return int(L.load().caphn_device_error(1 if clear else 0))
+
+
 def decoder_workspace(dims: DecDims, device) -> torch.Tensor:
     lib = L.load()
     cd = dims.c()

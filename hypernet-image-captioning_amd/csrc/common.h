@@ -10,8 +10,14 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// status.hip: the current device's sticky failure word (include/caphn.h, caphn_device_error)
+int caphn_sticky_error();               // CAPHN_OK / CAPHN_ETIMEOUT, one plain host read
+int* caphn_errword();                   // device-visible address of the word (allocated on first use; nullptr if that failed)
+extern long long g_tune_xch_timeout;    // hand-off time bound of the pair recurrent kernels, in 100 MHz wall-clock ticks
+
 static inline int caphn_launch_status() {
-    return hipGetLastError() == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+    if (hipGetLastError() != hipSuccess) return CAPHN_ELAUNCH;
+    return caphn_sticky_error();
 }
 static inline bool caphn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 __device__ __forceinline__ bool caphn_aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

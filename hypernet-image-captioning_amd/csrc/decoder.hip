@@ -42,6 +42,7 @@ struct Side {
     hipEvent_t ms[CAPHN_MS_COUNT];     // milestones of the last backward composite (caphn_decoder_backward_milestone)
     hipEvent_t pre_f, pre_all;         // last caphn_decoder_precompute on this device: feature_fc output ready / everything ready
     bool pre_valid = false;
+    const void* pre_ws = nullptr;      // workspace of that precompute: a forward that waits on pre_f / pre_all itself (bit 16) must own it
     bool ready = false, on = false;
     bool forked[3] = {false, false, false};
     hipStream_t main = nullptr;
@@ -479,6 +480,7 @@ extern "C" int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn
     Side* sd = side_here();
     if (!sd || hipEventRecord(sd->pre_all, s) != hipSuccess) return CAPHN_ELAUNCH;
     sd->pre_valid = true;
+    sd->pre_ws = ws_;
     return caphn_launch_status();
 }
 
@@ -516,7 +518,8 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     // kernel (the G GEMM then runs beside them instead of behind them)
     Side* sdw = (pc & 16) ? side_here() : nullptr;
     if (pc & 16) {
-        if (!sdw || !sdw->pre_valid) return CAPHN_EINVAL;
+        // the events are per device: they belong to this call only if the last precompute issued on this device filled THIS workspace
+        if (!sdw || !sdw->pre_valid || sdw->pre_ws != ws_) return CAPHN_EINVAL;
         if (hipStreamWaitEvent(s, sdw->pre_f, 0) != hipSuccess) return CAPHN_ELAUNCH;
     }
     RUN(decoder_precompute(d, p, w, ws, features, &f, s, ((pc & 1) ? 0 : 1) | ((pc & 2) ? 0 : 2)));

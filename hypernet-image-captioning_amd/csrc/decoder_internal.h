@@ -30,6 +30,8 @@ struct RecFwdArgs {
     float drop_p = 0.f; unsigned long long drop_seed = 0;   // dropout on h_t: element (b, t, k) keeps by the hash of (seed, (b T + t) H + k)
     int waf_lds = 0;                     // pair forward kernel: its columns of W_a f live in LDS (set by the launcher)
     int wc_rows = 0;                     // pair forward kernel: weight rows cached in LDS (set by the launcher; -1: no on-chip rows)
+    unsigned epoch = 0; int* err = nullptr; long long xlimit = 0;   // pair kernels (set by the launcher): tag epoch of this launch, the
+                                         // device's sticky failure word, hand-off time bound in 100 MHz wall-clock ticks
     const float* Hsrc = nullptr;         // t0 > 0: h_{t0-1} comes from Hsrc [B,T,H] instead of Hs (multi-layer decoders: Hs receives the
                                          // attention cell's output, the next step continues from the LAST layer's output)
 };
@@ -56,6 +58,7 @@ struct RecBwdArgs {
     const float* WP = nullptr; int wp_pitch = 0;
     int apart_rows = 0;                  // pair kernels: rows of `apart` per caption
     float drop_p = 0.f; unsigned long long drop_seed = 0;
+    unsigned epoch = 0; int* err = nullptr; long long xlimit = 0;   // pair kernels (set by the launcher), as in RecFwdArgs
     int part_rows = 0, wc_rows = 0;      // pair backward kernel (set by the launcher): rows of its slice-partials array, weight rows kept in LDS
     int t0 = 0, t1 = 0;                  // time-step window [t0, t1), walked backwards (t1 == 0: T).  A window starts from dh = 0 (dc
                                          // from dc0 when t1 < T) and leaves dh_{t0-1} in dh0 (dc in dc0): the caller adds it to what

@@ -593,6 +593,7 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 17) { if (value < 1 || value > 65536) return CAPHN_EINVAL; g_tune_splitk_target = value; return CAPHN_OK; }
     if (key == 16) { g_tune_rec_cache = value != 0; return CAPHN_OK; }
     if (key == 15) { g_tune_chain_main = value != 0; return CAPHN_OK; }
+    if (key == 22) { if (value < 1) return CAPHN_EINVAL; g_tune_xch_timeout = 100ll * value; return CAPHN_OK; }
     if (key == 14) { if (value < 64 || value > 65535) return CAPHN_EINVAL; g_tune_adam_cap = value; return CAPHN_OK; }
     return CAPHN_EINVAL;
 }

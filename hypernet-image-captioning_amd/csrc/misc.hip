@@ -641,6 +641,85 @@ int g_tune_adam_cap = 4096;   // workgroups of one rank-1 Adam launch (grid-stri
 int g_tune_adam = 6;   // measured on 240000x480 after the occupancy fix: 6 (non-temporal, 2 rows/iteration) 497 us,
                        // 3 (non-temporal, 1 row) 508 us, 0 (plain) 541 us
 namespace {
+// ------------------------------------------------------------------ multi-tensor forms (caphn.optim.FusedAdam: parameters of a module
+// that live in separate allocations).  One launch covers up to MT_MAX tensors: the descriptors travel as kernel arguments
+// (gradient addresses change every step), a block finds its tensor by a scan over the block prefix.
+constexpr int MT_MAX = 48;
+struct MTDesc { float* p; float* m; float* v; const float* g; size_t n; };
+struct MTJobs { int n; unsigned blk0[MT_MAX + 1]; MTDesc t[MT_MAX]; };
+__device__ __forceinline__ int mt_find(const MTJobs& J, unsigned bid) {
+    int i = 0;
+    while (i + 1 < J.n && bid >= J.blk0[i + 1]) ++i;
+    return i;
+}
+// blocks [0, nb_s): one SUMSQ_CHUNK of one gradient tensor each -> part[blk]; then the Gram-dot chunks, exactly as in
+// grad_norm_partials_kernel (same slot layout behind nb_s, so grad_norm_finish_kernel finishes both)
+__global__ __launch_bounds__(256) void grad_norm_multi_partials_kernel(MTJobs T, int nb_s, int part0, int R, GramJobs jobs,
+                                                                       double* __restrict__ part) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x;
+    double mine = 0.0;
+    if (bid < nb_s) {
+        const int ti = mt_find(T, (unsigned)bid);
+        const float* x = T.t[ti].g;
+        const size_t n = T.t[ti].n, base = (size_t)(bid - T.blk0[ti]) * SUMSQ_CHUNK;
+        float s = 0.f;
+        if (caphn_aligned16_dev(x) && base + SUMSQ_CHUNK <= n) {
+            const f32x4* x4 = reinterpret_cast<const f32x4*>(x + base);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { f32x4 v = x4[tid + 256 * i]; s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+        } else {
+            for (size_t i = base + tid; i < n && i < base + SUMSQ_CHUNK; i += 256) s += x[i] * x[i];
+        }
+        mine = (double)s;
+    } else {
+        int q = bid - nb_s;
+        const int chunk = q % NORM_CHUNKS; q /= NORM_CHUNKS;
+        const int pair = q % (R * R); q /= (R * R);
+        const int which = q & 1, job = q >> 1;
+        const GramJob& J = jobs.j[job];
+        const int r = pair / R, sidx = pair % R;
+        const float* u = which ? J.afac + (size_t)r * J.lda : J.gfac + (size_t)r * J.ldg;
+        const float* v = which ? J.afac + (size_t)sidx * J.lda : J.gfac + (size_t)sidx * J.ldg;
+        const int len = which ? J.k : J.rows;
+        const int per = (len + NORM_CHUNKS - 1) / NORM_CHUNKS;
+        const int i0 = chunk * per, i1 = min(len, i0 + per);
+        for (int i = i0 + tid; i < i1; i += 256) mine += (double)u[i] * (double)v[i];
+    }
+    mine = wave_sum_d(mine);
+    if ((tid & 63) == 0) red[tid >> 6] = mine;
+    __syncthreads();
+    if (tid == 0) part[(bid < nb_s ? part0 : 0) + bid] = red[0] + red[1] + red[2] + red[3];
+}
+constexpr int MT_CHUNK = 256 * 4 * 4;      // elements per block of the multi-tensor Adam
+__global__ __launch_bounds__(256) void adam_multi_kernel(MTJobs T, const float* __restrict__ coef, AdamK k) {
+    const float c = coef[0];
+    if (k.dev) { k.lr_bc1 = k.dev[0]; k.sqrt_bc2 = k.dev[1]; }
+    const int ti = mt_find(T, blockIdx.x);
+    const MTDesc d = T.t[ti];
+    const size_t base = (size_t)(blockIdx.x - T.blk0[ti]) * MT_CHUNK;
+    const bool vec = caphn_aligned16_dev(d.p) && caphn_aligned16_dev(d.m) && caphn_aligned16_dev(d.v) && caphn_aligned16_dev(d.g);
+    if (vec && base + MT_CHUNK <= d.n) {
+        f32x4* p4 = reinterpret_cast<f32x4*>(d.p + base); f32x4* m4 = reinterpret_cast<f32x4*>(d.m + base);
+        f32x4* v4 = reinterpret_cast<f32x4*>(d.v + base); const f32x4* g4 = reinterpret_cast<const f32x4*>(d.g + base);
+        f32x4 pp[4], mm[4], vv[4], gg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int j = threadIdx.x + 256 * i; pp[i] = p4[j]; mm[i] = m4[j]; vv[i] = v4[j]; gg[i] = g4[j]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float me = mm[i][e], ve = vv[i][e]; pp[i][e] = adam_elem(pp[i][e], gg[i][e] * c, me, ve, k); mm[i][e] = me; vv[i][e] = ve; }
+            const int j = threadIdx.x + 256 * i;
+            p4[j] = pp[i]; m4[j] = mm[i]; v4[j] = vv[i];
+        }
+    } else {
+        for (size_t i = base + threadIdx.x; i < d.n && i < base + MT_CHUNK; i += 256) {
+            float me = d.m[i], ve = d.v[i]; d.p[i] = adam_elem(d.p[i], d.g[i] * c, me, ve, k); d.m[i] = me; d.v[i] = ve;
+        }
+    }
+}
+
 inline AdamK make_adam(const caphn_adam_hparams* hp) {
     AdamK k;
     const double bc1 = 1.0 - pow((double)hp->beta1, (double)hp->step);
@@ -934,4 +1013,83 @@ extern "C" int caphn_device_arch(char* buf, int buflen) {
     for (; i < buflen - 1 && prop.gcnArchName[i] && prop.gcnArchName[i] != ':'; ++i) buf[i] = prop.gcnArchName[i];
     buf[i] = 0;
     return CAPHN_OK;
+}
+
+// ---- multi-tensor clip coefficient and Adam (parameters in separate allocations: caphn.optim.FusedAdam) ----
+static size_t mt_norm_blocks(int nt, const size_t* n) {
+    size_t b = 0;
+    for (int i = 0; i < nt; ++i) b += (n[i] + SUMSQ_CHUNK - 1) / SUMSQ_CHUNK;
+    return b;
+}
+extern "C" size_t caphn_grad_norm_multi_workspace_bytes(int ntensors, const size_t* n, int R, int njobs) {
+    if (ntensors < 0 || (ntensors > 0 && !n) || R <= 0 || R > RMAX || njobs < 0 || njobs > CAPHN_MAX_HEADS) return 0;
+    return sizeof(double) * (mt_norm_blocks(ntensors, n) + (size_t)njobs * 2 * R * R * NORM_CHUNKS);
+}
+extern "C" int caphn_grad_norm_multi(int ntensors, const float* const* g, const size_t* n, int R, int njobs, const int* rows,
+                                     const int* k, const float* const* gfac, const size_t* ldg, const float* const* afac,
+                                     const size_t* lda, double max_norm, double scale, float* coef_out, void* ws,
+                                     caphn_stream_t stream) {
+    if (ntensors < 0 || (ntensors > 0 && (!g || !n)) || R <= 0 || R > RMAX || njobs < 0 || njobs > CAPHN_MAX_HEADS || !coef_out || !ws ||
+        ntensors + njobs == 0) return CAPHN_EINVAL;
+    GramJobs jobs; jobs.n = njobs;
+    for (int i = 0; i < njobs; ++i) {
+        if (!rows || !k || !gfac || !ldg || !afac || !lda || rows[i] <= 0 || k[i] <= 0 || !gfac[i] || !afac[i]) return CAPHN_EINVAL;
+        jobs.j[i] = GramJob{gfac[i], ldg[i], afac[i], lda[i], rows[i], k[i]};
+    }
+    for (int i = 0; i < ntensors; ++i) if (!g[i] || n[i] == 0) return CAPHN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nb_total = mt_norm_blocks(ntensors, n);
+    const unsigned ngram = (unsigned)(njobs * 2 * R * R * NORM_CHUNKS);
+    double* part = static_cast<double*>(ws);          // [nb_total dense slots | gram slots]
+    // slot layout seen by the finish kernel: dense slots first, gram slots behind them.  Launches of at most MT_MAX tensors; the
+    // gram blocks ride in the last one (their slot index is bid - nb_s of that launch + nb_total: the kernel writes gram slots at
+    // part[bid] relative to a base shifted so that the first gram block lands on part[nb_total])
+    size_t done = 0;
+    int t0 = 0;
+    do {
+        MTJobs T; T.n = 0;
+        unsigned b = 0;
+        while (t0 + T.n < ntensors && T.n < MT_MAX) {
+            const int i = t0 + T.n;
+            T.t[T.n] = MTDesc{nullptr, nullptr, nullptr, g[i], n[i]};
+            T.blk0[T.n] = b;
+            b += (unsigned)((n[i] + SUMSQ_CHUNK - 1) / SUMSQ_CHUNK);
+            ++T.n;
+        }
+        T.blk0[T.n] = b;
+        t0 += T.n;
+        const bool last = t0 >= ntensors;
+        const unsigned nb = b + (last ? ngram : 0u);
+        if (nb > 0)
+            // dense blocks write part[part0 + bid]; gram blocks part[bid] on a base moved so that bid == b lands on slot nb_total
+            hipLaunchKernelGGL(grad_norm_multi_partials_kernel, dim3(nb), dim3(256), 0, s, T, (int)b, (int)0, R, jobs,
+                               part + done + 0) , (void)0;
+        done += b;
+        if (last) break;
+    } while (true);
+    hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(256), 0, s, (int)nb_total, R, njobs, static_cast<const double*>(ws), max_norm,
+                       scale, coef_out);
+    return caphn_launch_status();
+}
+extern "C" int caphn_adam_multi_f32(int ntensors, float* const* p, float* const* m, float* const* v, const float* const* g,
+                                    const size_t* n, const float* coef, const caphn_adam_hparams* hp, caphn_stream_t stream) {
+    if (ntensors <= 0 || !p || !m || !v || !g || !n || !coef || !hp || hp->step < 1) return CAPHN_EINVAL;
+    for (int i = 0; i < ntensors; ++i) if (!p[i] || !m[i] || !v[i] || !g[i] || n[i] == 0) return CAPHN_EINVAL;
+    const AdamK K = make_adam(hp);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int t0 = 0; t0 < ntensors;) {
+        MTJobs T; T.n = 0;
+        unsigned b = 0;
+        while (t0 + T.n < ntensors && T.n < MT_MAX) {
+            const int i = t0 + T.n;
+            T.t[T.n] = MTDesc{p[i], m[i], v[i], g[i], n[i]};
+            T.blk0[T.n] = b;
+            b += (unsigned)((n[i] + MT_CHUNK - 1) / MT_CHUNK);
+            ++T.n;
+        }
+        T.blk0[T.n] = b;
+        t0 += T.n;
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(b), dim3(256), 0, s, T, coef, K);
+    }
+    return caphn_launch_status();
 }

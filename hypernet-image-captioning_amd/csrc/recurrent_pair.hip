@@ -10,17 +10,22 @@
 // Exchange protocol (MI355X_MICROARCH.md, "handoff-1to1": data-tagged granules): every value travels as ONE naturally
 // aligned 8-byte {float, tag} written by a single agent-scope (sc1, write-through) store and polled with agent-scope
 // loads by the lane that needs it; the tag is 2 t + 1 / 2 t + 2 for the two exchanges of time step t, unique within a
-// launch, and the exchange area is zero when the launch starts (the composite clears it in build_idx_kernel, which
-// precedes every teacher-forced forward on the same stream), so a stale granule never matches.  No fences: a granule
+// launch, under a per-LAUNCH epoch in the tag's upper half (a host counter, 1 .. 32768: a second backward on the same workspace, or
+// any relaunch without the clearing launch in between, never matches what an earlier launch left behind), and the exchange
+// area is zero when a forward starts (pair_prep_kernel, which precedes every teacher-forced forward on the same stream, clears
+// the forward's and the backward's area), so a stale or uninitialised granule never matches.  No fences: a granule
 // is self-validating.  Nothing depends on where the two workgroups run; partners are blocks w and w ^ 8, which the
-// dispatcher usually places on one XCD (a speed matter only).  Every poll is bounded (a partner that never arrives
-// ends in garbage the parity tests would show, not in a hung GPU).
+// dispatcher usually places on one XCD (a speed matter only) -- but both must be RESIDENT for either to advance (co-residency
+// assumption, include/caphn.h caphn_device_error).  Every poll is bounded in wall-clock time: a partner that never answers
+// makes the lane set the device's sticky failure word (the host sees CAPHN_ETIMEOUT at its next call) and continue with NaN,
+// so the step's loss and gradients are NaN, not plausible garbage; it never hangs the GPU.
 //
 // The half that receives overlaps the hand-off with work that does not need it: the forward multiplies its rows with
 // ITS OWN half of h while the partner's half is in flight; the backward computes the partner's columns of the
 // transposed product first, sends them, and does its own columns while waiting.
 #include "common.h"
 #include "decoder_internal.h"
+#include <atomic>
 
 namespace {
 
@@ -45,16 +50,34 @@ __device__ __forceinline__ void xsend(u64* slot, float v, unsigned tag) {
     const u64 bits = ((u64)tag << 32) | (u64)__float_as_uint(v);
     __hip_atomic_store(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ int d_skip_xrecv = 0;      // timing experiments only (caphn_tune key 10): 1 = do not wait for the partner (WRONG results)
-__device__ __forceinline__ float xrecv(u64* slot, unsigned tag) {
-    u64 bits = 0;
-    if (d_skip_xrecv) return 0.f;
-    for (int spin = 0; spin < (1 << 22); ++spin) {
-        bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(bits >> 32) == tag) break;
+// tag of exchange x (1: h / dh, 2: scores / d alpha) of time step t in the launch with epoch `ep` (already shifted)
+__device__ __forceinline__ unsigned xtag(unsigned ep, int t, int x) { return ep | (2u * (unsigned)t + (unsigned)x); }
+// caphn_tune key 10 -- experiments and tests only: 1 = do not wait for the partner (timing; WRONG results), 2 = half 1 never
+// sends (its partner must time out: tests/test_gpu_pair_envelope.py)
+__device__ int d_skip_xrecv = 0;
+struct XCtl { int* err; long long limit; };
+// slow path of xrecv, out of line: the first poll almost always misses (the partner is a few hundred cycles behind), so this is
+// where every hand-off spends its time, but it must not cost the callers registers
+__device__ __noinline__ float xrecv_wait(u64* slot, unsigned tag, int* err, long long limit) {
+    const long long t0 = wall_clock64();
+    for (int spin = 1;; ++spin) {
         __builtin_amdgcn_s_sleep(1);
+        const u64 bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(bits >> 32) == tag) return __uint_as_float((unsigned)bits);
+        if ((spin & 1023) == 0) {
+            // somebody on this device already gave up (the word is sticky): nobody waits out a second bound
+            if (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+            if (wall_clock64() - t0 > limit) break;
+        }
     }
-    return __uint_as_float((unsigned)bits);
+    if (err) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return __builtin_nanf("");
+}
+__device__ __forceinline__ float xrecv(u64* slot, unsigned tag, const XCtl& c) {
+    if (d_skip_xrecv == 1) return 0.f;
+    const u64 bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(bits >> 32) == tag) return __uint_as_float((unsigned)bits);
+    return xrecv_wait(slot, tag, c.err, c.limit);
 }
 
 // sums of EIGHT values over the 64 lanes in 10 shuffles instead of 48: three halving exchanges (after them lane l holds
@@ -278,6 +301,9 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
     u64* xpart = a.xch + (size_t)(w ^ 8) * xch_stride(P, H);
     u64* xh_mine = xmine; u64* xe_mine = xmine + nkm;
     u64* xh_part = xpart; u64* xe_part = xpart + nkm;
+    const unsigned ep = a.epoch << 16;
+    const XCtl xc{a.err, a.xlimit};
+    const bool mute = d_skip_xrecv == 2 && hh == 1;
 
     const float* Gb = a.G + (size_t)b * P * GH;
     const int vecS = a.vecS && (nk % 4 == 0) && (k0 % 4 == 0);
@@ -349,7 +375,7 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
         for (int q = 0; q < NG; ++q) xgq[q] = tid < nk ? a.Xg[bt * GH + q * H + k0 + tid] : 0.f;
         // A: the partner's half of h arrives (sent at the end of its previous step), then my rows of U_a h + b_Ua and W_hh h + b_hh
         if (t > t0) {
-            for (int j = tid; j < hk.nkp; j += NT) h_s[hk.k0p + j] = xrecv(xh_part + j, 2u * (unsigned)(t - 1) + 1u);
+            for (int j = tid; j < hk.nkp; j += NT) h_s[hk.k0p + j] = xrecv(xh_part + j, xtag(ep, t - 1, 1), xc);
             __syncthreads();
         }
         PSTAMP(1);
@@ -390,8 +416,8 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
                 float e = -INFINITY;
                 if (lane < P) {
                     const float mine = e_s[lane];
-                    xsend(xe_mine + lane, mine, 2u * (unsigned)t + 2u);
-                    const float theirs = xrecv(xe_part + lane, 2u * (unsigned)t + 2u);
+                    if (!mute) xsend(xe_mine + lane, mine, xtag(ep, t, 2));
+                    const float theirs = xrecv(xe_part + lane, xtag(ep, t, 2), xc);
                     e = hh == 0 ? mine + theirs : theirs + mine;
                 }
                 const float mx = wave_max(e);
@@ -403,8 +429,8 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
         } else {
         for (int p = tid; p < P; p += NT) {
             const float mine = e_s[p];
-            xsend(xe_mine + p, mine, 2u * (unsigned)t + 2u);
-            const float theirs = xrecv(xe_part + p, 2u * (unsigned)t + 2u);
+            if (!mute) xsend(xe_mine + p, mine, xtag(ep, t, 2));
+            const float theirs = xrecv(xe_part + p, xtag(ep, t, 2), xc);
             e_s[p] = hh == 0 ? mine + theirs : theirs + mine;
         }
         __syncthreads();
@@ -497,7 +523,7 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
             a.Hs[bt * H + k] = hnew;
             a.uah[bt * H + k] = uah_s[kk];
             h_s[k] = hnew;
-            if (t + 1 < t1) xsend(xh_mine + kk, hnew, 2u * (unsigned)t + 1u);
+            if (t + 1 < t1 && !mute) xsend(xh_mine + kk, hnew, xtag(ep, t, 1));
         }
         __syncthreads();
         PSTAMP(7);
@@ -537,6 +563,9 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
     u64* xpart = a.xch + (size_t)(w ^ 8) * xch_stride(P, H);
     u64* xh_mine = xmine; u64* xe_mine = xmine + nkm;
     u64* xh_part = xpart; u64* xe_part = xpart + nkm;
+    const unsigned ep = a.epoch << 16;
+    const XCtl xc{a.err, a.xlimit};
+    const bool mute = d_skip_xrecv == 2 && hh == 1;
 
     const float* Gb = a.G + (size_t)b * P * GH;
     const int vecS = a.vecS && (nk % 4 == 0) && (k0 % 4 == 0);
@@ -748,9 +777,9 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
                 float da = 0.f, al = 0.f;
                 if (lane < P) {
                     const float mine = dal_s[lane];
-                    xsend(xe_mine + lane, mine, 2u * (unsigned)t + 2u);
+                    if (!mute) xsend(xe_mine + lane, mine, xtag(ep, t, 2));
                     al = al_s[lane];
-                    const float theirs = xrecv(xe_part + lane, 2u * (unsigned)t + 2u);
+                    const float theirs = xrecv(xe_part + lane, xtag(ep, t, 2), xc);
                     da = hh == 0 ? mine + theirs : theirs + mine;
                 }
                 const float dot = wave_sum(al * da);
@@ -759,8 +788,8 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
         } else {
         for (int p = tid; p < P; p += NT) {
             const float mine = dal_s[p];
-            xsend(xe_mine + p, mine, 2u * (unsigned)t + 2u);
-            const float theirs = xrecv(xe_part + p, 2u * (unsigned)t + 2u);
+            if (!mute) xsend(xe_mine + p, mine, xtag(ep, t, 2));
+            const float theirs = xrecv(xe_part + p, xtag(ep, t, 2), xc);
             dal_s[p] = hh == 0 ? mine + theirs : theirs + mine;
         }
         __syncthreads();
@@ -823,11 +852,11 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
         //  the hand-off it would have hidden costs ~1 k cycles, the second sweep cost 8 k)
         tmatvec(0, H);
         PSTAMP(5);
-        for (int j = tid; j < hk.nkp; j += NT) xsend(xh_mine + j, dhp_s[hk.k0p + j], 2u * (unsigned)t + 1u);
+        if (!mute) for (int j = tid; j < hk.nkp; j += NT) xsend(xh_mine + j, dhp_s[hk.k0p + j], xtag(ep, t, 1));
         PSTAMP(6);
         for (int kk = tid; kk < nk; kk += NT) {
             const float mine = dhp_s[k0 + kk];
-            const float theirs = xrecv(xh_part + kk, 2u * (unsigned)t + 1u);
+            const float theirs = xrecv(xh_part + kk, xtag(ep, t, 1), xc);
             dh_s[kk] += hh == 0 ? mine + theirs : theirs + mine;
         }
         __syncthreads();
@@ -947,6 +976,30 @@ int caphn_rec_pair_bwd_groups(int P, int H) {
 static int set_attr(const void* f) {
     return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
 }
+// the 160 KB dynamic-LDS opt-in is a per-DEVICE function attribute: one guard per device, not per process
+static int set_attrs_here() {
+    static bool done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CAPHN_ELAUNCH;
+    if (done[dev]) return CAPHN_OK;
+    if (set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, false>)) ||
+        set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, true>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, true>)) ||
+        set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<true>)))
+        return CAPHN_ELAUNCH;
+    done[dev] = true;
+    return CAPHN_OK;
+}
+#define RUN_ATTR() do { if (set_attrs_here() != CAPHN_OK) return CAPHN_ELAUNCH; } while (0)
+// per-launch hand-off control: a fresh tag epoch (1 .. 32768 in the tag's upper 16 bits; the lower 16 carry 2 t + x, so T < 32767),
+// the device's sticky failure word and the time bound
+static int prepare_xch(int T, unsigned* epoch, int** err, long long* limit) {
+    static std::atomic<unsigned> ctr{0};
+    if (T >= 32767) return CAPHN_ELIMIT;
+    *epoch = (ctr.fetch_add(1, std::memory_order_relaxed) & 0x7fffu) + 1u;
+    *err = caphn_errword();
+    *limit = g_tune_xch_timeout;
+    return CAPHN_OK;
+}
 // rows of the half's [U_a; W_hh] the forward kernel keeps in the LDS left over (a multiple of 8: wave-uniform; at most what
 // the two register-resident sweeps leave)
 int caphn_rec_pair_fwd_cache_rows(int P, int H, int NG, int RG) {
@@ -968,14 +1021,8 @@ int caphn_launch_rec_pair_fwd(const RecFwdArgs& a_, bool lstm, hipStream_t s) {
     if (a.waf_lds) lds += waf_bytes;
     a.wc_rows = ((a.H % 4) == 0 && a.H <= 32 * JM) ? caphn_rec_pair_fwd_cache_rows(a.P, a.H, lstm ? 4 : 3, a.RG) : -1;
     if (a.wc_rows > 0) lds += sizeof(float) * (size_t)a.wc_rows * a.H;
-    static bool attr = false;
-    if (!attr) {
-        if (set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, false>)) ||
-            set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, true>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, true>)) ||
-            set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<true>)))
-            return CAPHN_ELAUNCH;
-        attr = true;
-    }
+    RUN_ATTR();
+    if (prepare_xch(a.T, &a.epoch, &a.err, &a.xlimit) != CAPHN_OK) return CAPHN_ELIMIT;
     const unsigned nwg = 16u * (unsigned)((a.B + 7) / 8);
     const bool cached = a.wc_rows >= 0 && (a.H % 4) == 0 && a.H <= 32 * JM;
     if (cached) {
@@ -1014,14 +1061,8 @@ int caphn_launch_rec_pair_bwd(const RecBwdArgs& a_, bool lstm, hipStream_t s) {
     a.wc_rows = caphn_rec_pair_bwd_cache_rows(a.P, a.H, lstm ? 4 : 3, a.RG);
     lds += sizeof(float) * (size_t)a.wc_rows * a.H;
     if (a.dWaf && (!a.apart || caphn_rec_pair_bwd_groups(a.P, a.H) == 0 || a.apart_rows < caphn_rec_pair_bwd_groups(a.P, a.H))) return CAPHN_EINVAL;
-    static bool attr = false;
-    if (!attr) {
-        if (set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, false>)) ||
-            set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, true>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, true>)) ||
-            set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<true>)))
-            return CAPHN_ELAUNCH;
-        attr = true;
-    }
+    RUN_ATTR();
+    if (prepare_xch(a.T, &a.epoch, &a.err, &a.xlimit) != CAPHN_OK) return CAPHN_ELIMIT;
     const unsigned nwg = 16u * (unsigned)((a.B + 7) / 8);
     if (lstm) hipLaunchKernelGGL(rec_pair_bwd_kernel<true>, dim3(nwg), dim3(NT), lds, s, a);
     else hipLaunchKernelGGL(rec_pair_bwd_kernel<false>, dim3(nwg), dim3(NT), lds, s, a);

@@ -41,9 +41,23 @@ typedef void* caphn_stream_t; /* hipStream_t */
 #define CAPHN_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define CAPHN_ELAUNCH (-2)   /* HIP reported a launch error */
 #define CAPHN_ELIMIT (-3)    /* problem does not fit a hardware limit (e.g. LDS) */
+#define CAPHN_ETIMEOUT (-4)  /* a kernel gave up waiting for a partner workgroup (see caphn_device_error); STICKY: every later
+                                call on that device returns it until caphn_device_error(1) clears the word */
 
 /* Library / device probe.  Returns the ABI version (>0).  */
 int caphn_abi_version(void);
+/* Device-side failure word of the CURRENT device (one int in pinned host memory per device, written by kernels with a
+ * system-scope store, read by the host without synchronising).  The only writer today: the two-workgroups-per-caption recurrent
+ * kernels (teacher-forced caphn_decoder_forward / _backward at T > 1).  Their halves hand partial vectors to each other through
+ * tagged 8-byte granules in the workspace and ASSUME CO-RESIDENCY: workgroups w and w ^ 8 of one launch must both be running for
+ * either to finish a time step.  An in-order dispatcher with at least 9 free workgroup slots guarantees progress; a partner that
+ * does not answer within the time bound (about 1 s of the 100 MHz wall clock; caphn_tune key 22 sets it in microseconds) makes
+ * the waiting lane store 1 here and continue with NaN, so the loss and every gradient of that step are NaN as well -- never a
+ * plausible wrong value -- and every workgroup still polling gives up within a millisecond of the first one.
+ * Returns CAPHN_OK or CAPHN_ETIMEOUT; clear != 0 resets the word after reading it.  Every libcaphn call that launches work
+ * also returns CAPHN_ETIMEOUT while the word is set (the launch itself is not skipped), so a host that never synchronises
+ * still learns of the failure at its next call after the kernel has written it. */
+int caphn_device_error(int clear);
 /* Writes the gfx arch name of the current device into buf (host); 0 on success. */
 int caphn_device_arch(char* buf, int buflen);
 
@@ -285,7 +299,10 @@ int caphn_decoder_forward_sampled_train(const caphn_decoder_dims* d, const caphn
                                         const unsigned char* use_sampling,
                                         float* logits, float* alphas, void* ws, caphn_stream_t stream);
 /* dlogits [B,T,V] (may be overwritten) -> parameter gradients.  ws must be the workspace the
- * matching forward filled.  dalphas (gradient w.r.t. the returned attention weights) may be NULL. */
+ * matching forward filled.  dalphas (gradient w.r.t. the returned attention weights) may be NULL.
+ * The backward may be repeated on the same workspace (it only reads the forward's saved state; the hand-off granules of the
+ * pair recurrent kernels carry a per-launch epoch, so a second backward never accepts what the first one left behind) as long as
+ * dlogits is supplied again -- the first call may have overwritten it -- and, with dims.precomputed bit 8, d Hs is zero again. */
 int caphn_decoder_backward(const caphn_decoder_dims* d, const caphn_decoder_params* p,
                            const float* features, const int64_t* captions,
                            float* dlogits, const float* dalphas,
