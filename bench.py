@@ -14,6 +14,11 @@ Extra objects on that line:
   roofline     the dominant kernel (adam_rank_kernel on hn_heads.0.2.weight, 115.2 M parameters):
                algorithmic bytes = 24 B/parameter (read W,m,v + write W,m,v) / its measured duration
                (HIP events on the launch stream), against 8 TB/s HBM peak.
+               copy_ceiling_gbps: this box's device-to-device copy rate, measured in the same run.
+  module_api   SIDE figure (never `value`): the unchanged-driver loop training_step -> backward -> optimizer.step on the
+               module API with the optimiser configure_optimizers() returns (caphn.optim.FusedAdam).
+  collectives  what the data-parallel exchange issued: backend, world size, collectives per step, the time the main stream
+               waited for them in front of the optimiser (exposed_us).
   cpu_baseline the CPU oracle (oracle/caphn_oracle.py, a port of the reference's PyTorch path) timed
                on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -34,6 +39,7 @@ import torch  # noqa: E402
 METRIC = "training images/sec at 1/2/4/8 MI355X, Flickr30k GRU+hypernet bs=128"
 HBM_PEAK = 8.0e12           # B/s, MI355X_MICROARCH.md chip table
 STEP_ALGO_BYTES = 5.228e9   # whole-step algorithmic HBM bytes at B=128
+DOMINANT_KERNEL_SYMBOL = "adam_rank_kernel<2, true, true, 2, false>"   # instantiation that runs hn_heads.0.2.weight (k = 480) in the step
 
 
 class _Vocab:
@@ -112,6 +118,67 @@ def cpu_baseline(B, T, P, budget_s=25.0, max_steps=5):
             "value_without_adam": B / medn,
             "sample": f"{len(ts)} full steps (fwd+bwd+clip+Adam) at B={B}, T={T}, fp32, after 2 warm-ups; "
                       f"median {med * 1e3:.0f} ms/step; {len(tn)} steps without the optimiser: median {medn * 1e3:.0f} ms"}
+
+
+def copy_ceiling(dev, nbytes=1_382_400_000, reps=6):
+    """Device-to-device copy rate of this box, read + write bytes per second: what a kernel that
+    streams as many bytes in as out -- the rank-1 Adam pass reads 12 B and writes 12 B per parameter -- can reach at best.
+    Boxes differ by up to 16 % in it; reported beside the 8 TB/s data-sheet peak so that a slow HBM is told apart from a slow kernel."""
+    n = nbytes // 4
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    from caphn import _lib
+    lib = _lib.load()
+
+    def cp():
+        _lib.check(lib.caphn_stream_copy_f32(n, _lib.ptr(a), _lib.ptr(b), _lib.stream_ptr()), "caphn_stream_copy_f32")
+    cp()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(reps):
+        s.record(); cp(); e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    del a, b
+    return 2.0 * nbytes / (min(ts) * 1e-3) / 1e9
+
+
+def module_api_loop(dev, dims, batches, steps=10, warmup=3):
+    """SIDE measurement, never `value`: the loop an UNCHANGED reference driver runs (hypernet_attention.py:136-204 training_step,
+    Lightning's backward / gradient_clip_val / optimizer.step, cc_train_hypernet.py:405, :120) on this package's module API --
+    HyperNet.training_step() -> loss.backward() -> optimizer.step(), with the optimiser configure_optimizers() returns
+    (caphn.optim.FusedAdam: torch.optim.Optimizer subclass, clip inside step, hypernet second-layer weights from rank-1 factors)."""
+    from hypernet_attention import HyperNet
+    B, T, P, D, F, E, H, V = dims
+    torch.manual_seed(4321)
+    net = HyperNet(F, E, H, V, _Vocab()).to(dev)
+    (opt,), _ = net.configure_optimizers()
+    for g in opt.param_groups:
+        g["lr"] = 1e-3
+    net.configure_gradient_clipping(opt, gradient_clip_val=5.0, gradient_clip_algorithm="norm")
+    styles = ["factual", "humorous", "romantic"]
+
+    def one(i):
+        f, c = batches[i % len(batches)]
+        opt.zero_grad()
+        loss = net.training_step((f, (styles[i % 3], (c, None))), i)
+        loss.backward()
+        opt.step()
+        return loss
+    for i in range(warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = one(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"ms_per_step": dt * 1e3, "images_s": B / dt, "steps": steps, "final_loss": float(loss),
+           "optimizer": type(opt).__module__ + "." + type(opt).__name__,
+           "loop": "HyperNet.training_step -> loss.backward -> optimizer.step (clip 5.0 inside step), one style per step"}
+    del net, opt
+    torch.cuda.empty_cache()
+    return out
 
 
 def launch_ranks(n, argv):
@@ -193,6 +260,10 @@ def main():
     ap.add_argument("--no-spinup", action="store_true", help="skip the untimed spin-up windows after --warmup")
     ap.add_argument("--from-host", action="store_true", help="side measurement (DESIGN.md): every minibatch starts in pinned HOST "
                     "memory and crosses PCIe on a copy stream, two batches ahead, into one of three device slots")
+    ap.add_argument("--no-module-api", action="store_true", help="skip the side measurement of the unchanged-driver loop "
+                    "(training_step -> backward -> clip -> optimizer.step with the optimiser configure_optimizers() returns)")
+    ap.add_argument("--fixed-style", action="store_true", help="one style token per rank for the whole run (rounds 1-2); default: "
+                    "the style rotates over the three domains step by step, so the fused next-theta GEMV sees a changing input row")
     ap.add_argument("--no-overlap", action="store_true", help="do not issue the next batch's caption-independent "
                     "precompute beside the optimiser")
     args = ap.parse_args()
@@ -251,7 +322,11 @@ def main():
     if os.environ.get("CAPHN_OVERLAP_AFTER_HEAD"):
         tr.overlap_after_head = int(os.environ["CAPHN_OVERLAP_AFTER_HEAD"])
     batches = synth_batches(4, B, T, P, D, V, dev, seed=1234 + rank)
-    style = 4 + (rank % 3)                        # one style domain per rank-batch
+    # one style domain per rank-batch; it rotates over the three domains step by step (every rank starts at its own), so the
+    # next-theta GEMV fused into the Adam pass and the style row's embedding gradient see a changing row
+    def style_at(j):
+        return 4 + ((rank + (0 if args.fixed_style else j)) % 3)
+    style = style_at(0)
 
     def barrier():
         if world > 1:
@@ -313,17 +388,26 @@ def main():
         seq = feed.slots if feed else batches
         nxt = {seq[i][0].data_ptr(): seq[(i + 1) % len(seq)] for i in range(len(seq))}
 
-        def do_step(f, c, style_token):
+        def do_step(f, c, style_token, next_style=None):
             nf, nc = (None, None) if args.no_overlap else nxt[f.data_ptr()]
-            return tr.step(f, c, style_token=style_token, next_style_token=style_token, next_features=nf, next_captions=nc)
+            return tr.step(f, c, style_token=style_token, next_style_token=style_token if next_style is None else next_style,
+                           next_features=nf, next_captions=nc)
     if use_graph:                                  # two passes over the batch buffers: eager, then capture
         for _ in range(2):
             for f, c in batches:
                 do_step(f, c, style_token=style)
+    rot = not (use_graph or args.no_prefetch)      # (those two step functions take no announced next style)
+
+    def run_step(j):
+        f, c = batch_at(j)
+        if rot:
+            out = do_step(f, c, style_token=style_at(j), next_style=style_at(j + 1))
+        else:
+            out = do_step(f, c, style_token=style)
+        after_step(j)
+        return out
     for i in range(args.warmup):
-        f, c = batch_at(i)
-        do_step(f, c, style_token=style)
-        after_step(i)
+        run_step(i)
     # Spin-up (untimed, additional to --warmup; reported as config.spinup_steps).  The first process on a freshly
     # acquired box stalls ONCE on the host for ~37 ms around its 1200th kernel launch (step 12-13 here; the GPU idles,
     # every kernel keeps its normal duration, a second process on the same box never shows it --
@@ -336,9 +420,7 @@ def main():
             torch.cuda.synchronize()
             t = time.perf_counter()
             for j in range(n):
-                f, c = batch_at(args.warmup + spin["steps"] + j)
-                do_step(f, c, style_token=style)
-                after_step(args.warmup + spin["steps"] + j)
+                run_step(args.warmup + spin["steps"] + j)
             torch.cuda.synchronize()
             spin["steps"] += n
             dtw = (time.perf_counter() - t) / n
@@ -384,9 +466,7 @@ def main():
     t0 = time.perf_counter()
     off = args.warmup + spin["steps"]          # continue the batch cycle, so the announced next batch is the one that comes
     for i in range(args.steps):
-        f, c = batch_at(off + i)
-        loss = do_step(f, c, style_token=style)
-        after_step(off + i)
+        loss = run_step(off + i)
     barrier()
     dt = time.perf_counter() - t0
     ops.adam_rank = orig
@@ -407,12 +487,14 @@ def main():
         # HBM bytes of one launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # gfx950 corrections applied) -- collected separately, summary committed under profiles/
         traffic = None
+        # (the file names the kernel symbol it was collected on: a figure for another instantiation is not reported)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_adam_rank.json")))
-            if int(pmc["algorithmic_bytes"]) == int(kbytes):
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_adam_rank.json")))
+            if int(pmc["algorithmic_bytes"]) == int(kbytes) and pmc.get("kernel", "").startswith(DOMINANT_KERNEL_SYMBOL):
                 traffic = pmc["traffic_bytes"]
         except Exception:  # noqa: BLE001
             pass
+        ceiling = copy_ceiling(dev) if B == 128 else None
         ms_step = dt / args.steps * 1e3
         line = {
             "metric": METRIC, "value": B * world * args.steps / dt, "unit": "images/s",
@@ -436,8 +518,12 @@ def main():
                          "frac": (achieved / (HBM_PEAK / 1e9)) if achieved else None, "traffic": traffic,
                          "kernel_launches_timed": len(kts), "kernel_ms": kern_ms, "kernel_ms_median": float(np.median(kts)) if kts else None,
                          "kernel_ms_min": float(np.min(kts)) if kts else None, "algorithmic_bytes": kbytes,
+                         "copy_ceiling_gbps": ceiling, "frac_of_copy_ceiling": (achieved / ceiling) if (achieved and ceiling) else None,
                          "step_frac": STEP_ALGO_BYTES / (ms_step * 1e-3) / HBM_PEAK if B == 128 else None},
         }
+        line["collectives"] = tr.collective_report()
+        if world == 1 and not forced and not args.no_module_api and args.cell == "gru" and args.dtype == "f32":
+            line["module_api"] = module_api_loop(dev, (B, T, P, D, F, E, H, V), batches)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B, T, P)
         sys.stdout.flush()

@@ -108,6 +108,7 @@ class FusedTrainer:
         # data-parallel exchange: collectives are issued from this stream, which waits on the backward's milestones
         self._comm_stream = torch.cuda.Stream(device=dev)
         self._works = []
+        self._xstat = {"steps": 0, "collectives": 0, "timed": []}      # collective_report()
         self._gfac_all = None
         self._acts_all = None
         self.overlap_after_head = 0      # the side stream forks after this head's Adam pass (-1: before the first)
@@ -515,10 +516,35 @@ class FusedTrainer:
         """Joins the exchange _issue_exchange started.  Returns (gfac [R,theta], acts_all [R,L])."""
         if not dp.active(self.group):
             return self.flat_g[:self.theta_size].view(1, -1), self._acts.view(1, -1)
+        xs = self._xstat
+        xs["steps"] += 1
+        xs["collectives"] += len(self._works)
+        timed = xs["steps"] % 8 == 0 and len(xs["timed"]) < 64       # event pairs cost queue time: every 8th step only
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         dp.wait_all(self._works)
         torch.cuda.current_stream().wait_stream(self._comm_stream)
+        if timed:
+            e1.record()
+            xs["timed"].append((e0, e1))
         self._works = []
         return self._gfac_all, self._acts_all
+
+    def collective_report(self) -> dict:
+        """What the data-parallel exchange did so far: backend, world size, collectives issued per step, and the time the main
+        stream spent waiting for them in front of the optimiser (HIP events around the join; the part of the exchange that
+        the backward did not hide)."""
+        import torch.distributed as dist
+        if not dp.active(self.group):
+            return {"backend": None, "world": 1, "per_step": 0, "exposed_us": 0.0}
+        xs = self._xstat
+        torch.cuda.synchronize()
+        ts = [a.elapsed_time(b) * 1e3 for a, b in xs["timed"]]
+        return {"backend": dist.get_backend(self.group), "world": dp.world(self.group),
+                "per_step": xs["collectives"] / max(1, xs["steps"]),
+                "exposed_us": (sum(ts) / len(ts)) if ts else None, "exposed_us_max": max(ts) if ts else None,
+                "steps_observed": xs["steps"], "steps_timed": len(ts)}
 
     def _begin_step(self):
         self.step_count += 1

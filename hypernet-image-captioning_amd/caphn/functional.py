@@ -162,7 +162,8 @@ class _HyperFn(torch.autograd.Function):
             o = 0
             for i, (k, w) in enumerate(shape.heads):
                 ao, an = layout[f"a{i}"]
-                sink[f"hn_heads.{i}.2.weight"] = (dtheta[o:o + w], ctx.acts[ao:ao + an])
+                # (a list: several backward passes before one optimiser step -- gradient accumulation -- make a rank-R member)
+                sink.setdefault(f"hn_heads.{i}.2.weight", []).append((dtheta[o:o + w], ctx.acts[ao:ao + an]))
                 skip.add(f"hn_heads.{i}.2.weight")
                 o += w
         grads = {n: torch.empty(s, dtype=torch.float32, device=dev) for n, s in shape.param_shapes().items() if n not in skip}

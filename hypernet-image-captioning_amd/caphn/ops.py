@@ -701,6 +701,45 @@ class GradNorm:
         return out
 
 
+def grad_norm_multi(grads, pairs, max_norm: float, scale: float, out: torch.Tensor, ws: Optional[torch.Tensor] = None):
+    """clip_grad_norm_'s coefficient over a LIST of dense gradient tensors plus rank-R members given as (gfac [R,rows],
+    afac [R,k]) pairs (caphn_grad_norm_multi).  Returns (out, ws): out[0] = coefficient * scale, out[1] = the total norm."""
+    lib = L.load()
+    nt, nj = len(grads), len(pairs)
+    R = pairs[0][0].shape[0] if nj else 1
+    for g in grads:
+        L.ptr(g)
+    for g, a in pairs:
+        assert g.stride(1) == 1 and a.stride(1) == 1 and g.dtype == torch.float32 and a.dtype == torch.float32 and g.shape[0] == R
+    ns = (C.c_size_t * max(nt, 1))(*[g.numel() for g in grads])
+    need = lib.caphn_grad_norm_multi_workspace_bytes(nt, ns, R, nj)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=out.device)
+    gp = (C.c_void_p * max(nt, 1))(*[g.data_ptr() for g in grads])
+    m = max(nj, 1)
+    L.check(lib.caphn_grad_norm_multi(nt, gp, ns, R, nj, (C.c_int * m)(*[g.shape[1] for g, _ in pairs]),
+                                      (C.c_int * m)(*[a.shape[1] for _, a in pairs]),
+                                      (C.c_void_p * m)(*[g.data_ptr() for g, _ in pairs]), (C.c_size_t * m)(*[g.stride(0) for g, _ in pairs]),
+                                      (C.c_void_p * m)(*[a.data_ptr() for _, a in pairs]), (C.c_size_t * m)(*[a.stride(0) for _, a in pairs]),
+                                      float(max_norm), float(scale), L.ptr(out), C.c_void_p(ws.data_ptr()), L.stream_ptr()),
+            "caphn_grad_norm_multi")
+    return out, ws
+
+
+def adam_multi(ps, ms, vs, gs, coef, lr, step, betas=(0.9, 0.999), eps=1e-8) -> None:
+    """Adam on a list of (contiguous fp32) tensors in one launch per 48 tensors (caphn_adam_multi_f32)."""
+    lib = L.load()
+    n = len(ps)
+    hp = _hp(lr, betas, eps, step)
+    for p, m, v, g in zip(ps, ms, vs, gs):
+        L.ptr(p); L.ptr(m); L.ptr(v); L.ptr(g)
+        if not (m.numel() == p.numel() == v.numel() == g.numel()):
+            raise L.CaphnError("adam_multi: parameter / state / gradient sizes differ")
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    L.check(lib.caphn_adam_multi_f32(n, arr(ps), arr(ms), arr(vs), arr(gs), (C.c_size_t * n)(*[p.numel() for p in ps]),
+                                     L.ptr(coef), C.byref(hp), L.stream_ptr()), "caphn_adam_multi_f32")
+
+
 def decoder_hyper_backward(dims: DecDims, params, features, captions, dlogits, grads, ws,
                            shape: HyperShape, hyper_params, acts, hyper_grads, hyper_ws, want_x: bool = False):
     """decoder_backward + hyper_backward in one call; the hypernet VJP overlaps the decoder's tail.

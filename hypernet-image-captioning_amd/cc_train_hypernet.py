@@ -13,6 +13,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from caphn import config
 from caphn import functional as CF
 
 from hypernet_attention import HyperNet, _Base, pl
@@ -111,13 +112,22 @@ class HyperNetCC(_Base):
         params.extend(list(self.hypernet.captioner.fc.parameters()))
         params.extend(list(self.hypernet.captioner.attention.parameters()))
         params.extend(list(self.hypernet.captioner.init_h.parameters()))
-        optimizer = torch.optim.Adam(params, lr=self.hparams['lr'])
+        optimizer = config.make_adam(params, self.hparams['lr'], hypernet=self.hypernet)
         scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, cooldown=2, factor=0.5)
         return [optimizer], [{'scheduler': scheduler, 'monitor': 'val_loss with TF', 'interval': 'epoch'}]
 
     def _loss(self, caps_pred, caps):
         return CF.cross_entropy(caps_pred.view(-1, self.hparams['vocab_size']), caps.view(-1).long(),
                                 ignore_index=self.vocab.w2i['<pad>'])
+
+    def configure_gradient_clipping(self, optimizer, optimizer_idx=None, gradient_clip_val=None, gradient_clip_algorithm=None):
+        """Lightning's hook (automatic optimisation calls it between backward and optimizer.step; 1.x passes an optimizer index
+        as well, 2.x does not): the Trainer's gradient_clip_val (cc_train_hypernet.py:405: 5.0) is applied inside the fused
+        optimiser's step, over the dense gradients and the rank-1 members torch's clip_grad_norm_ cannot see."""
+        if isinstance(optimizer_idx, float) and gradient_clip_val is None:       # 2.x called positionally
+            optimizer_idx, gradient_clip_val, gradient_clip_algorithm = None, optimizer_idx, gradient_clip_val
+        if not config.lightning_gradient_clipping(optimizer, gradient_clip_val, gradient_clip_algorithm):
+            self.clip_gradients(optimizer, gradient_clip_val=gradient_clip_val, gradient_clip_algorithm=gradient_clip_algorithm)
 
     def training_step(self, train_batch, batch_idx):
         """:134-166 without the text metrics / logging."""

@@ -654,8 +654,8 @@ __device__ __forceinline__ int mt_find(const MTJobs& J, unsigned bid) {
 }
 // blocks [0, nb_s): one SUMSQ_CHUNK of one gradient tensor each -> part[blk]; then the Gram-dot chunks, exactly as in
 // grad_norm_partials_kernel (same slot layout behind nb_s, so grad_norm_finish_kernel finishes both)
-__global__ __launch_bounds__(256) void grad_norm_multi_partials_kernel(MTJobs T, int nb_s, int part0, int R, GramJobs jobs,
-                                                                       double* __restrict__ part) {
+__global__ __launch_bounds__(256) void grad_norm_multi_partials_kernel(MTJobs T, int nb_s, int R, GramJobs jobs,
+                                                                       double* __restrict__ dense_part, double* __restrict__ gram_part) {
     __shared__ double red[4];
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void grad_norm_multi_partials_kernel(MTJobs T,
     mine = wave_sum_d(mine);
     if ((tid & 63) == 0) red[tid >> 6] = mine;
     __syncthreads();
-    if (tid == 0) part[(bid < nb_s ? part0 : 0) + bid] = red[0] + red[1] + red[2] + red[3];
+    if (tid == 0) { if (bid < nb_s) dense_part[bid] = red[0] + red[1] + red[2] + red[3]; else gram_part[bid - nb_s] = red[0] + red[1] + red[2] + red[3]; }
 }
 constexpr int MT_CHUNK = 256 * 4 * 4;      // elements per block of the multi-tensor Adam
 __global__ __launch_bounds__(256) void adam_multi_kernel(MTJobs T, const float* __restrict__ coef, AdamK k) {
@@ -717,6 +717,19 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(MTJobs T, const float* 
         for (size_t i = base + threadIdx.x; i < d.n && i < base + MT_CHUNK; i += 256) {
             float me = d.m[i], ve = d.v[i]; d.p[i] = adam_elem(d.p[i], d.g[i] * c, me, ve, k); d.m[i] = me; d.v[i] = ve;
         }
+    }
+}
+
+// Copy microbenchmark (bench.py: roofline.copy_ceiling_gbps): what this box's HBM gives a kernel that streams as many bytes in as
+// out with the access pattern of the rank-1 Adam pass (non-temporal dwordx4 loads and stores, four in flight per lane)
+__global__ __launch_bounds__(256) void stream_copy_kernel(size_t n4, const f32x4* __restrict__ src, f32x4* __restrict__ dst) {
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + 256 * u < n4) v[u] = __builtin_nontemporal_load(src + i + 256 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + 256 * u < n4) __builtin_nontemporal_store(v[u], dst + i + 256 * u);
     }
 }
 
@@ -1040,13 +1053,11 @@ extern "C" int caphn_grad_norm_multi(int ntensors, const float* const* g, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t nb_total = mt_norm_blocks(ntensors, n);
     const unsigned ngram = (unsigned)(njobs * 2 * R * R * NORM_CHUNKS);
-    double* part = static_cast<double*>(ws);          // [nb_total dense slots | gram slots]
-    // slot layout seen by the finish kernel: dense slots first, gram slots behind them.  Launches of at most MT_MAX tensors; the
-    // gram blocks ride in the last one (their slot index is bid - nb_s of that launch + nb_total: the kernel writes gram slots at
-    // part[bid] relative to a base shifted so that the first gram block lands on part[nb_total])
+    double* part = static_cast<double*>(ws);          // [nb_total dense slots | gram slots]: what grad_norm_finish_kernel reads
+    // launches of at most MT_MAX tensors each; the Gram-dot blocks ride in the last one
     size_t done = 0;
     int t0 = 0;
-    do {
+    for (;;) {
         MTJobs T; T.n = 0;
         unsigned b = 0;
         while (t0 + T.n < ntensors && T.n < MT_MAX) {
@@ -1061,12 +1072,10 @@ extern "C" int caphn_grad_norm_multi(int ntensors, const float* const* g, const 
         const bool last = t0 >= ntensors;
         const unsigned nb = b + (last ? ngram : 0u);
         if (nb > 0)
-            // dense blocks write part[part0 + bid]; gram blocks part[bid] on a base moved so that bid == b lands on slot nb_total
-            hipLaunchKernelGGL(grad_norm_multi_partials_kernel, dim3(nb), dim3(256), 0, s, T, (int)b, (int)0, R, jobs,
-                               part + done + 0) , (void)0;
+            hipLaunchKernelGGL(grad_norm_multi_partials_kernel, dim3(nb), dim3(256), 0, s, T, (int)b, R, jobs, part + done, part + nb_total);
         done += b;
         if (last) break;
-    } while (true);
+    }
     hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(256), 0, s, (int)nb_total, R, njobs, static_cast<const double*>(ws), max_norm,
                        scale, coef_out);
     return caphn_launch_status();
@@ -1091,5 +1100,11 @@ extern "C" int caphn_adam_multi_f32(int ntensors, float* const* p, float* const*
         t0 += T.n;
         hipLaunchKernelGGL(adam_multi_kernel, dim3(b), dim3(256), 0, s, T, coef, K);
     }
+    return caphn_launch_status();
+}
+extern "C" int caphn_stream_copy_f32(size_t n, const float* src, float* dst, caphn_stream_t stream) {
+    if (n == 0 || (n & 3) || !src || !dst || !caphn_aligned16(src) || !caphn_aligned16(dst)) return CAPHN_EINVAL;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(stream), n >> 2,
+                       reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst));
     return caphn_launch_status();
 }

@@ -14,6 +14,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from caphn import config
 from caphn import functional as CF
 from caphn import ops
 from models.decoderlstm import DecoderGRU, DecoderRNN
@@ -78,7 +79,7 @@ class HyperNet(_Base):
 
     def forward(self, x):
         """hypernet.py:104-114."""
-        heads_out = CF.hyper_forward(self._shape, x, self.hyper_named_tensors())
+        heads_out = CF.hyper_forward(self._shape, x, self.hyper_named_tensors(), factor_sink=self.__dict__.get('rank1_factors'))
         flip_parameters_to_tensors(self.captioner)
         set_all_parameters(self.captioner, heads_out.reshape(1, -1))
         return self.captioner
@@ -89,9 +90,18 @@ class HyperNet(_Base):
         params.extend(list(self.hn_base.parameters()))
         params.extend(list(self.captioner.embed.parameters()))
         params.extend(list(self.image_encoder.fc.parameters()))
-        optimizer = torch.optim.Adam(params, lr=self.hparams['lr'])
+        optimizer = config.make_adam(params, self.hparams['lr'], hypernet=self)
         scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, cooldown=2)
         return [optimizer], [{'scheduler': scheduler, 'monitor': 'val_loss'}]
+
+    def configure_gradient_clipping(self, optimizer, optimizer_idx=None, gradient_clip_val=None, gradient_clip_algorithm=None):
+        """Lightning's hook (automatic optimisation calls it between backward and optimizer.step; 1.x passes an optimizer index
+        as well, 2.x does not): the Trainer's gradient_clip_val (cc_train_hypernet.py:405: 5.0) is applied inside the fused
+        optimiser's step, over the dense gradients and the rank-1 members torch's clip_grad_norm_ cannot see."""
+        if isinstance(optimizer_idx, float) and gradient_clip_val is None:       # 2.x called positionally
+            optimizer_idx, gradient_clip_val, gradient_clip_algorithm = None, optimizer_idx, gradient_clip_val
+        if not config.lightning_gradient_clipping(optimizer, gradient_clip_val, gradient_clip_algorithm):
+            self.clip_gradients(optimizer, gradient_clip_val=gradient_clip_val, gradient_clip_algorithm=gradient_clip_algorithm)
 
     def training_step(self, train_batch, batch_idx):
         """hypernet.py:126-152 with teacher forcing (the sampled branch is torch.multinomial per step) and without

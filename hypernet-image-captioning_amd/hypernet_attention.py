@@ -9,6 +9,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from caphn import config
 from caphn import functional as CF
 from caphn import ops
 from models.decoderlstm import AttentionGru, AttentionLstm
@@ -90,7 +91,7 @@ class HyperNet(_Base):
 
     def forward(self, x):
         """hypernet_attention.py:111-121.  x: [1,he] (Flickr) or [he] (CC one-hot row)."""
-        heads_out = CF.hyper_forward(self._shape, x, self.hyper_named_tensors())
+        heads_out = CF.hyper_forward(self._shape, x, self.hyper_named_tensors(), factor_sink=self.__dict__.get('rank1_factors'))
         flip_parameters_to_tensors(self.cell_module)
         set_all_parameters(self.cell_module, heads_out.reshape(1, -1))
         return self.captioner
@@ -104,9 +105,18 @@ class HyperNet(_Base):
         params.extend(list(self.captioner.fc.parameters()))
         params.extend(list(self.captioner.attention.parameters()))
         params.extend(list(self.captioner.init_h.parameters()))
-        optimizer = torch.optim.Adam(params, lr=self.hparams['lr'])
+        optimizer = config.make_adam(params, self.hparams['lr'], hypernet=self)
         scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, cooldown=2, factor=0.5)
         return [optimizer], [{'scheduler': scheduler, 'monitor': 'val_loss with TF', 'interval': 'epoch'}]
+
+    def configure_gradient_clipping(self, optimizer, optimizer_idx=None, gradient_clip_val=None, gradient_clip_algorithm=None):
+        """Lightning's hook (automatic optimisation calls it between backward and optimizer.step; 1.x passes an optimizer index
+        as well, 2.x does not): the Trainer's gradient_clip_val (cc_train_hypernet.py:405: 5.0) is applied inside the fused
+        optimiser's step, over the dense gradients and the rank-1 members torch's clip_grad_norm_ cannot see."""
+        if isinstance(optimizer_idx, float) and gradient_clip_val is None:       # 2.x called positionally
+            optimizer_idx, gradient_clip_val, gradient_clip_algorithm = None, optimizer_idx, gradient_clip_val
+        if not config.lightning_gradient_clipping(optimizer, gradient_clip_val, gradient_clip_algorithm):
+            self.clip_gradients(optimizer, gradient_clip_val=gradient_clip_val, gradient_clip_algorithm=gradient_clip_algorithm)
 
     def training_step(self, train_batch, batch_idx):
         """hypernet_attention.py:136-204 without the mixup/BERT and text-metric parts."""

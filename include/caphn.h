@@ -486,6 +486,19 @@ typedef struct caphn_adam_hparams {
 /* p,m,v,g flat [n]; g is multiplied by coef[0] (device) first. */
 int caphn_adam_dense_f32(size_t n, float* p, float* m, float* v, const float* g, const float* coef,
                          const caphn_adam_hparams* hp, caphn_stream_t stream);
+/* The same two operations for parameters that live in SEPARATE allocations (a torch.optim.Optimizer over a module's
+ * parameter list: cc_train_hypernet.py:110-120 builds Adam over ~30 tensors, Lightning clips their global norm to 5.0, :405).
+ * All arrays are HOST arrays of ntensors entries holding device pointers / element counts (they travel as kernel arguments;
+ * gradient addresses change every step).
+ * caphn_grad_norm_multi: clip_grad_norm_'s coefficient over ntensors dense gradients plus njobs rank-R members given by their
+ * factors (arguments as caphn_grad_norm_coef), two launches per 48 tensors; ws: caphn_grad_norm_multi_workspace_bytes.
+ * caphn_adam_multi_f32: Adam on every tensor, g multiplied by coef[0] (device) first, one launch per 48 tensors. */
+size_t caphn_grad_norm_multi_workspace_bytes(int ntensors, const size_t* n, int R, int njobs);
+int caphn_grad_norm_multi(int ntensors, const float* const* g, const size_t* n, int R, int njobs, const int* rows, const int* k,
+                          const float* const* gfac, const size_t* ldg, const float* const* afac, const size_t* lda,
+                          double max_norm, double scale, float* coef_out, void* ws, caphn_stream_t stream);
+int caphn_adam_multi_f32(int ntensors, float* const* p, float* const* m, float* const* v, const float* const* g, const size_t* n,
+                         const float* coef, const caphn_adam_hparams* hp, caphn_stream_t stream);
 /* W,m,v [rows,k]; gradient = coef[0] * sum_r gfac[r,row] * afac[r,col], never materialised. */
 int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, float* v,
                         const float* gfac, size_t ldg, const float* afac, size_t lda,
@@ -497,6 +510,9 @@ int caphn_adam_rank_gemv_f32(int R, int rows, int k, float* W, float* m, float* 
                              const float* gfac, size_t ldg, const float* afac, size_t lda,
                              const float* coef, const caphn_adam_hparams* hp,
                              const float* next_a, const float* next_bias, float* next_theta, caphn_stream_t stream);
+/* dst[0..n) = src[0..n) (n % 4 == 0, 16-byte aligned) with the access pattern of the streaming kernels (non-temporal dwordx4): the
+ * copy microbenchmark behind bench.py's roofline.copy_ceiling_gbps. */
+int caphn_stream_copy_f32(size_t n, const float* src, float* dst, caphn_stream_t stream);
 /* dense outer product out[rows,k] = g[rows] (x) a[k]  (module API: torch optimisers want dW2 dense) */
 int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out, caphn_stream_t stream);
 
