@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcaphn.so")
+LIB_PATH = os.environ.get("CAPHN_LIB_PATH") or os.path.join(_HERE, "libcaphn.so")      # (override: profiling builds, tools/ only)
 MAX_HEADS = 8
 
 c_fp = C.c_void_p  # device pointers travel as void*

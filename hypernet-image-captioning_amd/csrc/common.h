@@ -48,6 +48,26 @@ __device__ __forceinline__ float caphn_keep_scale(unsigned long long seed, unsig
     return u < p ? 0.f : inv_keep;
 }
 
+// ---- sums over aligned groups of 8 lanes on the DPP path (no LDS round trip: __shfl_xor compiles to ds_bpermute_b32, ~100 cycles
+// of dependent latency per stage -- three stages per row were the larger part of a register-resident mat-vec sweep).
+// Pairing: lanes l ^ 1 (quad_perm [1,0,3,2]), l ^ 2 (quad_perm [2,3,0,1]), then l <-> 7 - l inside each half row
+// (row_half_mirror: the partner sits in the other quad of the group); every lane of a group ends with the group's total.
+__device__ __forceinline__ float caphn_dpp(float v, int ctrl_b1_4e_141) {
+    // (ctrl must be a literal: dispatched below)
+    const int x = __builtin_bit_cast(int, v);
+    int y;
+    if (ctrl_b1_4e_141 == 0xB1) y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+    else if (ctrl_b1_4e_141 == 0x4E) y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);
+    else y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);
+    return __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ float group8_sum(float v) {
+    v += caphn_dpp(v, 0xB1);
+    v += caphn_dpp(v, 0x4E);
+    v += caphn_dpp(v, 0x141);
+    return v;
+}
+
 // ---- wave reductions (64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -268,12 +268,16 @@ template <int BM, int BN, bool TA, bool TB, int MODE>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     constexpr bool PL = MODE == 1;
     constexpr bool SINGLE = MODE == 2;
+    constexpr bool DB = MODE == 3;          // MODE 0 with TWO LDS images of a slab (ping-pong): see mainloop_db
     using TileA = TileS<BM, !TA>;
     using TileB = TileS<BN, TB>;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];      // TileA::ELEMS + TileB::ELEMS (up to 77 KB)
+    constexpr int TILE_ELEMS = TileA::ELEMS + TileB::ELEMS;
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];      // TILE_ELEMS (up to 77 KB), twice that with DB
     __bf16* As = lds;
     __bf16* Bs = lds + TileA::ELEMS;
+    __bf16* As1 = DB ? lds + TILE_ELEMS : As;
+    __bf16* Bs1 = DB ? lds + TILE_ELEMS + TileA::ELEMS : Bs;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     if (kmap) {
         const int need = (slab1 - slab0) * BK;
         if (fast && TA && !TB && g.kmap_lds >= need) {
-            int* kls = reinterpret_cast<int*>(lds + TileA::ELEMS + TileB::ELEMS);
+            int* kls = reinterpret_cast<int*>(lds + (DB ? 2 : 1) * TILE_ELEMS);
             for (int i = tid; i < need; i += 256) kls[i] = kmap[min(kbase + i, g.K - 1)];
             __syncthreads();
             kl = kls;
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             TileB::load(rb, g.B, g.ldb, g.N, g.K, n0, slab * BK, g.vecB, tid, prb, kmap);
         }
     };
-    auto multiply = [&](int slab) {
+    auto multiply = [&](int slab, const __bf16* As, const __bf16* Bs) {
         const int nks = (g.K - slab * BK) > 16 ? 2 : 1;      // skip the all-zero second k-step of a short tail
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     // always holds the same four columns: 256 % (BM / 4) == 0)
     const bool do_cs = TA && g.colsum_a != nullptr && bx == 0;
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-    auto stage = [&](f32x4 (&ra)[TileA::NV], f32x4 (&rb)[TileB::NV], int slab, auto fast_c) {
+    auto stage = [&](f32x4 (&ra)[TileA::NV], f32x4 (&rb)[TileB::NV], int slab, auto fast_c, __bf16* As, __bf16* Bs) {
         if constexpr (decltype(fast_c)::value) {
             TileA::mask_tail(ra, tid, slab * BK, g.K);
             TileB::mask_tail(rb, tid, slab * BK, g.K);
@@ -443,14 +447,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 #endif
         gload(ra0, rb0, slab0, fc);
         if (F || slab0 + 1 < slab1) gload(ra1, rb1, min(slab0 + 1, last), fc);
-        stage(ra0, rb0, slab0, fc);
+        stage(ra0, rb0, slab0, fc, As, Bs);
         __syncthreads();
         GSTAMP(0);                                  // prologue: first loads, first stage
         for (int slab = slab0; slab < slab1; slab += 2) {
             // LDS: slab.  set 1: slab+1 (in flight).  set 0: free
             if (F || slab + 2 < slab1) gload(ra0, rb0, min(slab + 2, last), fc);
             GSTAMP(1);                              // issue of the look-ahead loads
-            multiply(slab);
+            multiply(slab, As, Bs);
             __builtin_amdgcn_sched_barrier(0);      // keep the staging (and its vmcnt wait) behind the MFMAs
             GSTAMP(2);                              // fragment reads + MFMAs
             __syncthreads();
@@ -459,14 +463,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 #ifdef CAPHN_GEMM_PROFILE
             if constexpr (F) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TileA::NV + TileB::NV)); GSTAMP(9); }   // pure wait for the older set
 #endif
-            stage(ra1, rb1, slab + 1, fc);
+            stage(ra1, rb1, slab + 1, fc, As, Bs);
             GSTAMP(4);                              // wait for the older register set, split, LDS stores
             __syncthreads();
             GSTAMP(5);                              // barrier after the stage
             // LDS: slab+1.  set 0: slab+2 (in flight).  set 1: free
             if (F || slab + 3 < slab1) gload(ra1, rb1, min(slab + 3, last), fc);
             GSTAMP(1);
-            multiply(slab + 1);
+            multiply(slab + 1, As, Bs);
             __builtin_amdgcn_sched_barrier(0);
             GSTAMP(2);
             __syncthreads();
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 #ifdef CAPHN_GEMM_PROFILE
                 if constexpr (F) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TileA::NV + TileB::NV)); GSTAMP(9); }
 #endif
-                        stage(ra0, rb0, slab + 2, fc);
+                        stage(ra0, rb0, slab + 2, fc, As, Bs);
                 GSTAMP(4);
                 __syncthreads();
                 GSTAMP(5);
@@ -526,14 +530,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         __syncthreads();
         for (int slab = slab0; slab < slab1; slab += 2) {
             pload(pa0, pb0, min(slab + 2, last));
-            multiply(slab);
+            multiply(slab, As, Bs);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             if (slab + 1 >= slab1) break;
             pstage(pa1, pb1, slab + 1);
             __syncthreads();
             pload(pa1, pb1, min(slab + 3, last));
-            multiply(slab + 1);
+            multiply(slab + 1, As, Bs);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             if (slab + 2 < slab1) {
@@ -541,6 +545,34 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                 __syncthreads();
             }
         }
+    } else if constexpr (DB) {
+        // Ping-pong LDS: slab s is multiplied out of image s & 1 while slab s + 1 is split and stored into the other image -- no
+        // barrier between a slab's MFMAs and the next slab's staging, ONE barrier per slab instead of two, and a wave that has
+        // issued its MFMAs goes on to the split arithmetic of the next slab while the matrix pipe (its own and the other waves')
+        // is still busy.  (Phase stamps of the single-image loop: per slab 1.8 k cycles of fragment reads + MFMAs, 1.9 k of wait +
+        // split + LDS stores, back to back, plus two barriers.)
+        auto loop = [&](auto fc) {
+            constexpr bool F = decltype(fc)::value;
+            const int last = slab1 - 1;
+            gload(ra0, rb0, slab0, fc);
+            if (F || slab0 + 1 < slab1) gload(ra1, rb1, min(slab0 + 1, last), fc);
+            stage(ra0, rb0, slab0, fc, As, Bs);
+            __syncthreads();
+            for (int slab = slab0; slab < slab1; slab += 2) {
+                if (F || slab + 2 < slab1) gload(ra0, rb0, min(slab + 2, last), fc);
+                multiply(slab, As, Bs);
+                __builtin_amdgcn_sched_barrier(0);
+                if (slab + 1 < slab1) stage(ra1, rb1, slab + 1, fc, As1, Bs1);
+                __syncthreads();
+                if (slab + 1 >= slab1) break;
+                if (F || slab + 3 < slab1) gload(ra1, rb1, min(slab + 3, last), fc);
+                multiply(slab + 1, As1, Bs1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (slab + 2 < slab1) stage(ra0, rb0, slab + 2, fc, As, Bs);
+                __syncthreads();
+            }
+        };
+        if (fast) loop(std::true_type{}); else loop(std::false_type{});
     } else {
         if (fast) mainloop(std::true_type{}); else mainloop(std::false_type{});
     }
@@ -669,7 +701,7 @@ template <int BM, int BN, bool TA, bool TB, int PL>
 int launch_one(const GemmArgs& g, hipStream_t s) {
     using TileA = TileS<BM, !TA>;
     using TileB = TileS<BN, TB>;
-    constexpr size_t lds_tiles = sizeof(__bf16) * (TileA::ELEMS + TileB::ELEMS);
+    constexpr size_t lds_tiles = sizeof(__bf16) * (TileA::ELEMS + TileB::ELEMS) * (PL == 3 ? 2 : 1);
     size_t lds = lds_tiles;
     if (g.kmap_lds > 0) lds += sizeof(int) * (size_t)g.kmap_lds;
     static bool attr_set = false;          // one flag per instantiation; one host thread drives one device
@@ -698,6 +730,7 @@ int g_tune_gemm_tile = 0;     // 0: automatic tile choice; 64 / 128: forced (exp
 int g_tune_gemm_single = 0;   // 1: reduced-precision side mode -- one bf16 product per contraction instead of six (caphn_tune key 11)
 int g_tune_gemm_order = 1;    // tile walk inside an XCD: 0 n fastest always, 1 (default) m fastest when B outgrows L2 and A is the smaller, 2 m fastest always
 int g_tune_gemm_xcd = 1;      // 1 (default): XCD-aware tile order
+int g_tune_gemm_db = 0;       // layouts that run the 64x64 tile with ping-pong LDS images (MODE 3): bit 0 NT, bit 1 NN, bit 2 TN
 int g_tune_gemm_fast = 1;     // 1 (default): branch-free loads (static vmcnt) where alignment allows
 // Tile choice: 128x128 when that alone gives >= 512 workgroups and K >= 512, else 64x64 (four workgroups per CU:
 // caphn_debug_gemm_occupancy).  Measured and dropped: 64x256 / 256x64 tiles spanning the whole short side of the N = 200 problems
@@ -766,6 +799,9 @@ int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
         return launch_cfg<64, 64, 2>(g, ta, tb, s);
     }
     if (tiles128 >= 512) return launch_cfg<128, 128, 0>(g, ta, tb, s);
+    // ping-pong LDS images for the 64x64 tile (caphn_tune key 23: bit 0 NT, bit 1 NN, bit 2 TN layouts)
+    const int lay = (!ta && tb) ? 1 : (!ta && !tb) ? 2 : (ta && !tb) ? 4 : 0;
+    if (g_tune_gemm_db & lay) return launch_cfg<64, 64, 3>(g, ta, tb, s);
     return launch_cfg<64, 64, 0>(g, ta, tb, s);
 }
 

@@ -570,6 +570,7 @@ extern int g_tune_rec_cache;
 extern int g_tune_splitk_target;
 extern int g_tune_gemm_order;
 extern int g_tune_branch_mask;
+extern int g_tune_gemm_db;
 extern int g_tune_vocab_order;
 extern int g_det_vocab;
 int caphn_rec_pair_debug_skip(int v);
@@ -591,8 +592,9 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 20) { if (value < 0 || value > 7) return CAPHN_EINVAL; g_tune_branch_mask = value; return CAPHN_OK; }
     if (key == 18) { if (value < 0 || value > 2) return CAPHN_EINVAL; g_tune_gemm_order = value; return CAPHN_OK; }
     if (key == 17) { if (value < 1 || value > 65536) return CAPHN_EINVAL; g_tune_splitk_target = value; return CAPHN_OK; }
-    if (key == 16) { g_tune_rec_cache = value != 0; return CAPHN_OK; }
+    if (key == 16) { if (value < 0 || value > 2) return CAPHN_EINVAL; g_tune_rec_cache = value; return CAPHN_OK; }
     if (key == 15) { g_tune_chain_main = value != 0; return CAPHN_OK; }
+    if (key == 23) { if (value < 0 || value > 7) return CAPHN_EINVAL; g_tune_gemm_db = value; return CAPHN_OK; }
     if (key == 22) { if (value < 1) return CAPHN_EINVAL; g_tune_xch_timeout = 100ll * value; return CAPHN_OK; }
     if (key == 14) { if (value < 64 || value > 65535) return CAPHN_EINVAL; g_tune_adam_cap = value; return CAPHN_OK; }
     return CAPHN_EINVAL;

@@ -83,23 +83,30 @@ __device__ __forceinline__ float xrecv(u64* slot, unsigned tag, const XCtl& c) {
 // sums of EIGHT values over the 64 lanes in 10 shuffles instead of 48: three halving exchanges (after them lane l holds
 // the partial of value (l >> 3) & 7), then three plain stages over the 8 lanes that share a value.  Returns, in every
 // lane, the total of value index (lane >> 3).
+// The halving exchanges run on the lane-permute instructions of gfx950, not through ds_bpermute: v_permlane32_swap exchanges the
+// upper half of one register with the lower half of another -- give it (A = v[j], B = v[j + half]) and A' + B' is, in the lower
+// lanes, A(mine) + A(partner) and, in the upper lanes, B(partner) + B(mine): one instruction replaces two selects and a
+// shuffle; v_permlane16_swap does the same between the odd and even 16-lane rows; the last exchange (lanes l ^ 8, inside a
+// row) is a DPP row rotation.
 __device__ __forceinline__ float wave_sum8(float (&v)[8], int lane) {
 #pragma unroll
-    for (int st = 0; st < 3; ++st) {
-        const int mask = 32 >> st, half = 4 >> st;
-        const bool hi = (lane & mask) != 0;
-#pragma unroll
-        for (int j = 0; j < half; ++j) {
-            const float send = hi ? v[j] : v[j + half];
-            const float keep = hi ? v[j + half] : v[j];
-            v[j] = keep + __shfl_xor(send, mask, 64);
-        }
+    for (int j = 0; j < 4; ++j) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, v[j]), __builtin_bit_cast(int, v[j + 4]), false, false);
+        v[j] = __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
     }
-    float s = v[0];
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 1, 64);
-    return s;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, v[j]), __builtin_bit_cast(int, v[j + 2]), false, false);
+        v[j] = __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+    }
+    {
+        const bool hi = (lane & 8) != 0;
+        const float send = hi ? v[0] : v[1];
+        const float keep = hi ? v[1] : v[0];
+        const int got = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128 /* row_ror:8 */, 0xF, 0xF, true);
+        v[0] = keep + __builtin_bit_cast(float, got);
+    }
+    return group8_sum(v[0]);
 }
 
 struct HalfK { int k0, nk, k0p, nkp; };
@@ -128,29 +135,28 @@ __host__ __device__ __forceinline__ int xch_stride(int P, int H) { return ((half
 // cost the same 18 k cycles per time step for 400 rows as for 800.  Here a lane requests all its chunks of TWO rows
 // (2 x JM dwordx4, clamped addresses, no branches) before it uses any of them; x comes from LDS once per call.
 // Local row r = q' nk + kk: q' = 0 is U_a (-> uah_s[kk]), q' = 1 + q is gate block q of W_hh (-> gh_s[q nk + kk]).
+constexpr int FULL_RC = 5;     // register sweeps of the all-on-chip forward variant (5 x 64 rows x 28 VGPRs)
 constexpr int JM = 7;          // chunks per lane per column block: 8 lanes x 7 chunks x 4 floats = 224 columns per block
 // Rows come from the PACKED copy WP [(NG + 1) H][pitch] = [U_a; W_hh] with a row pitch of a multiple of 32 floats: a lane
 // group's eight 16-byte chunks of a row are then exactly one 128-byte line.  In the parameters' own layout a row is 800 bytes
 // (H = 200), every such 128-byte piece straddles two lines, and the mat-vec ran at half the L2 -> CU rate (31 B/clk).
-__device__ __forceinline__ const float* pair_row(const float* __restrict__ WP, int pitch, int H, int k0, int qp, int kk) {
-    return WP + (size_t)(qp * H + k0 + kk) * pitch;
+// ... and PER HALF, in the half's own row order: local row r = q' nk + kk of half hh sits at WP[hh][r] (pair_prep_kernel), so a
+// row address is base + r * pitch -- no (q', kk) bookkeeping in the inner loops of the mat-vec and of the transposed mat-vec.
+__device__ __forceinline__ const float* pair_row(const float* __restrict__ WPh, int pitch, int r) {
+    return WPh + (size_t)r * pitch;
 }
-__device__ __forceinline__ void pair_matvec(const float* __restrict__ WP, int pitch, const float* bias_s,
-                                            const float* x_s, float* uah_s, float* gh_s,
-                                            int H, int nk, int k0, int NR, int vec, int grp, int s) {
+__device__ __forceinline__ void pair_matvec(const float* __restrict__ WPh, int pitch, const float* bias_s,
+                                            const float* x_s, float* out_s,
+                                            int H, int NR, int vec, int grp, int s) {
     constexpr int RS = NT / 8;                  // rows per sweep
     if (vec) {
         const f32x4* x4 = reinterpret_cast<const f32x4*>(x_s);
         const int n4 = H >> 2;
-        int qa = 0, ka = grp;                   // (q', kk) of row r
-        while (ka >= nk) { ka -= nk; ++qa; }
 #pragma unroll 1
         for (int r = grp; r < NR; r += 2 * RS) {
-            int qb = qa, kb = ka + RS;          // the second row of the pair, r + RS
-            while (kb >= nk) { kb -= nk; ++qb; }
             const bool has_b = r + RS < NR;
-            const f32x4* ra = reinterpret_cast<const f32x4*>(pair_row(WP, pitch, H, k0, qa, ka));
-            const f32x4* rb = has_b ? reinterpret_cast<const f32x4*>(pair_row(WP, pitch, H, k0, qb, kb)) : ra;
+            const f32x4* ra = reinterpret_cast<const f32x4*>(pair_row(WPh, pitch, r));
+            const f32x4* rb = has_b ? reinterpret_cast<const f32x4*>(pair_row(WPh, pitch, r + RS)) : ra;
             float sa = 0.f, sb = 0.f;
             for (int c0 = 0; c0 < n4; c0 += 8 * JM) {
                 f32x4 va[JM], vb[JM], xv[JM];
@@ -166,26 +172,19 @@ __device__ __forceinline__ void pair_matvec(const float* __restrict__ WP, int pi
                     sb += vb[j][0] * xv[j][0] + vb[j][1] * xv[j][1] + vb[j][2] * xv[j][2] + vb[j][3] * xv[j][3];
                 }
             }
-            sa += __shfl_xor(sa, 4, 64); sb += __shfl_xor(sb, 4, 64);
-            sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
-            sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
+            sa = group8_sum(sa); sb = group8_sum(sb);
             if (s == 0) {       // (biases from LDS: a global load here makes the wave wait for every load issued before it)
-                if (qa == 0) uah_s[ka] = sa + bias_s[ka]; else gh_s[(qa - 1) * nk + ka] = sa + bias_s[qa * nk + ka];
-                if (has_b) { if (qb == 0) uah_s[kb] = sb + bias_s[kb]; else gh_s[(qb - 1) * nk + kb] = sb + bias_s[qb * nk + kb]; }
+                out_s[r] = sa + bias_s[r];
+                if (has_b) out_s[r + RS] = sb + bias_s[r + RS];
             }
-            qa = qb; ka = kb + RS;              // row r + 2 RS
-            while (ka >= nk) { ka -= nk; ++qa; }
         }
     } else {
         for (int r = grp; r < NR; r += RS) {
-            const int qp = r / nk, kk = r - qp * nk;
-            const float* row = pair_row(WP, pitch, H, k0, qp, kk);
+            const float* row = pair_row(WPh, pitch, r);
             float sum = 0.f;
             for (int c = s; c < H; c += 8) sum += row[c] * x_s[c];
-            sum += __shfl_xor(sum, 4, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            sum += __shfl_xor(sum, 1, 64);
-            if (s == 0) { if (qp == 0) uah_s[kk] = sum + bias_s[kk]; else gh_s[(qp - 1) * nk + kk] = sum + bias_s[qp * nk + kk]; }
+            sum = group8_sum(sum);
+            if (s == 0) out_s[r] = sum + bias_s[r];
         }
     }
 }
@@ -194,10 +193,11 @@ __device__ __forceinline__ void pair_matvec(const float* __restrict__ WP, int pi
 // ~26 B/clk per CU the 320 KB a half streams per step are 12 k of its 26 k cycles): the rows of the first RC sweeps live in the
 // lane group's own registers (RC x JM dwordx4 per lane), the next `NL` rows (slot = row order after those sweeps) in LDS, the
 // rest streams from L2 as above.  Needs H % 4 == 0 and H <= 32 JM (one column block).
-template <int RC>
-__device__ __forceinline__ void pair_matvec_cached(const float* __restrict__ WP, int pitch, const float* bias_s,
-                                                   const float* x_s, float* uah_s, float* gh_s,
-                                                   int H, int nk, int k0, int NR, int grp, int s, const f32x4 (&wc)[RC][JM],
+// STREAM = false: the launcher found room for ALL rows (RC register sweeps + NL rows of LDS >= NR): no global load in the time loop
+template <int RC, bool STREAM>
+__device__ __forceinline__ void pair_matvec_cached(const float* __restrict__ WPh, int pitch, const float* bias_s,
+                                                   const float* x_s, float* out_s,
+                                                   int H, int NR, int grp, int s, const f32x4 (&wc)[RC][JM],
                                                    const float* Wc_s, int NL) {
     constexpr int RS = NT / 8;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x_s);
@@ -209,32 +209,24 @@ __device__ __forceinline__ void pair_matvec_cached(const float* __restrict__ WP,
         float sa = 0.f;
 #pragma unroll
         for (int j = 0; j < JM; ++j) sa += v[j][0] * xv[j][0] + v[j][1] * xv[j][1] + v[j][2] * xv[j][2] + v[j][3] * xv[j][3];
-        sa += __shfl_xor(sa, 4, 64); sa += __shfl_xor(sa, 2, 64); sa += __shfl_xor(sa, 1, 64);
-        return sa;
+        return group8_sum(sa);
     };
-    auto emit = [&](int r, float sum) {
-        if (s == 0 && r < NR) {
-            int q = 0, kk = r;
-            while (kk >= nk) { kk -= nk; ++q; }
-            if (q == 0) uah_s[kk] = sum + bias_s[r]; else gh_s[(q - 1) * nk + kk] = sum + bias_s[r];
+    // (out_s = [uah ; gh] in local row order: a result goes to out_s[r].  The (q', kk) form of this -- a divergent subtract
+    //  loop and two address forms per row -- was ~100 of the ~150 instructions of a register sweep)
+    auto emit = [&](int r, float sum) { if (s == 0 && r < NR) out_s[r] = sum + bias_s[r]; };
+    // the first two streamed rows are requested BEFORE the on-chip rows are multiplied: their L2 round trip runs under that work
+    f32x4 va[STREAM ? JM : 1], vb[STREAM ? JM : 1];
+    auto request = [&](int i) {
+        if constexpr (STREAM) {
+            const f32x4* pa = reinterpret_cast<const f32x4*>(pair_row(WPh, pitch, min(RS * i + grp, NR - 1)));
+            const f32x4* pb = reinterpret_cast<const f32x4*>(pair_row(WPh, pitch, min(RS * (i + 1) + grp, NR - 1)));
+#pragma unroll
+            for (int j = 0; j < JM; ++j) { va[j] = pa[s + 8 * j]; vb[j] = pb[s + 8 * j]; }     // pad columns are zeros
         }
     };
-    // the first two streamed rows are requested BEFORE the on-chip rows are multiplied: their L2 round trip runs under that work
-    f32x4 va[JM], vb[JM];
-    auto request = [&](int i) {
-        int qa = 0, ka = min(RS * i + grp, NR - 1), qb = 0, kb = min(RS * (i + 1) + grp, NR - 1);
-        while (ka >= nk) { ka -= nk; ++qa; }
-        while (kb >= nk) { kb -= nk; ++qb; }
-        const f32x4* pa = reinterpret_cast<const f32x4*>(pair_row(WP, pitch, H, k0, qa, ka));
-        const f32x4* pb = reinterpret_cast<const f32x4*>(pair_row(WP, pitch, H, k0, qb, kb));
-#pragma unroll
-        for (int j = 0; j < JM; ++j) { va[j] = pa[s + 8 * j]; vb[j] = pb[s + 8 * j]; }     // pad columns are zeros
-    };
     int ig = RC + (NL > grp ? (NL - grp + RS - 1) / RS : 0);       // first streamed sweep of this lane group
-    {   // (one row only: a pair in flight on top of the resident rows does not fit the 256 registers)
-        int qa = 0, ka = min(RS * ig + grp, NR - 1);
-        while (ka >= nk) { ka -= nk; ++qa; }
-        const f32x4* pa = reinterpret_cast<const f32x4*>(pair_row(WP, pitch, H, k0, qa, ka));
+    if constexpr (STREAM) {   // (one row only: a pair in flight on top of the resident rows does not fit the 256 registers)
+        const f32x4* pa = reinterpret_cast<const f32x4*>(pair_row(WPh, pitch, min(RS * ig + grp, NR - 1)));
 #pragma unroll
         for (int j = 0; j < JM; ++j) va[j] = pa[s + 8 * j];
     }
@@ -251,31 +243,35 @@ __device__ __forceinline__ void pair_matvec_cached(const float* __restrict__ WP,
                 const f32x4 v = row[min(s + 8 * j, n4 - 1)];
                 sa += v[0] * xv[j][0] + v[1] * xv[j][1] + v[2] * xv[j][2] + v[3] * xv[j][3];
             }
-            sa += __shfl_xor(sa, 4, 64); sa += __shfl_xor(sa, 2, 64); sa += __shfl_xor(sa, 1, 64);
-            emit(RS * i + grp, sa);
+            emit(RS * i + grp, group8_sum(sa));
         }
     }
-    if (RS * ig + grp < NR) {
-        const float sa = dot(va);
-        const int ra = RS * ig + grp;
-        ig += 1;
-        if (RS * ig + grp < NR) request(ig);
-        emit(ra, sa);
-    }
+    if constexpr (STREAM) {
+        if (RS * ig + grp < NR) {
+            const float sa = dot(va);
+            const int ra = RS * ig + grp;
+            ig += 1;
+            if (RS * ig + grp < NR) request(ig);
+            emit(ra, sa);
+        }
 #pragma unroll 1
-    while (RS * ig + grp < NR) {
-        const float sa = dot(va), sb = dot(vb);
-        const int ra = RS * ig + grp;
-        ig += 2;
-        if (RS * ig + grp < NR) request(ig);
-        emit(ra, sa); emit(ra + RS, sb);
+        while (RS * ig + grp < NR) {
+            const float sa = dot(va), sb = dot(vb);
+            const int ra = RS * ig + grp;
+            ig += 2;
+            if (RS * ig + grp < NR) request(ig);
+            emit(ra, sa); emit(ra + RS, sb);
+        }
     }
 }
 
 // CACHED: part of the weight rows on chip (pair_matvec_cached); its own instantiation, because a kernel that carries both
 // mat-vec variants (and ten positions of D1 in flight) on top of the register-resident rows spills
-template <bool LSTM, bool CACHED>
+// CM: 0 all rows streamed, 1 two register sweeps + spare LDS + the rest streamed, 2 EVERYTHING on chip (five register sweeps = 320
+// rows, the other rows in LDS: the canonical GRU half has 400) -- the time loop then issues no weight load at all
+template <bool LSTM, int CM>
 __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
+    constexpr bool CACHED = CM != 0;
     constexpr int NG = LSTM ? 4 : 3;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -285,13 +281,15 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
     const int Ppad = (P + 63) & ~63;
     const HalfK hk = half_of(H, hh);
     const int k0 = hk.k0, nk = hk.nk, nkm = half_a(H);
+    const float* WPh = a.WP + (size_t)hh * (NG + 1) * nkm * a.wp_pitch;     // my half of the packed [U_a; W_hh], local row order
     float* G_s = lds;                           // [P][RG][nk]
     float* h_s = G_s + (size_t)P * RG * nkm;    // [H]  (16-byte aligned: every size below is a multiple of 4 floats)
-    float* uah_s = h_s + ((H + 3) & ~3);        // [nk]
-    float* va_s = uah_s + nkm;
+    float* va_s = h_s + ((H + 3) & ~3);         // [nk]
     float* c_s = va_s + nkm;
-    float* gh_s = c_s + nkm;                    // [NG][nk]
-    float* e_s = gh_s + NG * nkm;               // [Ppad]
+    float* out_s = c_s + nkm;                   // [(NG + 1) nk] the mat-vec's result in local row order: [uah (nk) ; gh (NG x nk)]
+    float* uah_s = out_s;
+    float* gh_s = out_s + nk;                   // [NG][nk]  (pitch nk)
+    float* e_s = out_s + (NG + 1) * nkm;        // [Ppad]
     float* part_s = e_s + Ppad;                 // [ng][NG][nk]
     float* bias_s = part_s + (size_t)kg_map(0, H - nkm > 0 ? H - nkm : 1).ng * NG * nkm;    // [(NG + 1) nkm] b_Ua | b_hh of my rows, row order
     float* Waf_s = bias_s + (size_t)(NG + 1) * nkm;                                          // [P][nkm] my columns of W_a f (waf_lds)
@@ -343,7 +341,7 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
     const int grp = tid >> 3, s8 = tid & 7;
     const int vecW = (H % 4) == 0;              // the packed weights are 128-byte aligned; half boundaries are multiples of 4
     // on-chip part of my rows (pair_matvec_cached): sweeps 0 .. WRC-1 in registers, the next wc_rows rows in LDS
-    constexpr int WRC = CACHED ? 2 : 1;
+    constexpr int WRC = CM == 2 ? FULL_RC : CACHED ? 2 : 1;
     constexpr bool cached = CACHED;             // the launcher checked H % 4 == 0 and H <= 32 JM
     const int NL = cached ? a.wc_rows : 0;
     f32x4 wc[WRC][JM];
@@ -351,17 +349,14 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
         const int n4 = H >> 2;
 #pragma unroll
         for (int i = 0; i < WRC; ++i) {
-            int q = 0, kk = min((NT / 8) * i + grp, NR - 1);
-            while (kk >= nk) { kk -= nk; ++q; }
-            const f32x4* row = reinterpret_cast<const f32x4*>(pair_row(a.WP, a.wp_pitch, H, k0, q, kk));
+            const f32x4* row = reinterpret_cast<const f32x4*>(pair_row(WPh, a.wp_pitch, min((NT / 8) * i + grp, NR - 1)));
 #pragma unroll
             for (int j = 0; j < JM; ++j) wc[i][j] = row[s8 + 8 * j];
         }
         for (int idx = tid; idx < NL * n4; idx += NT) {
             const int slot = idx / n4, c = idx - slot * n4;
-            int q = 0, kk = min((NT / 8) * (WRC + slot / (NT / 8)) + slot % (NT / 8), NR - 1);
-            while (kk >= nk) { kk -= nk; ++q; }
-            reinterpret_cast<f32x4*>(Wc_s)[idx] = reinterpret_cast<const f32x4*>(pair_row(a.WP, a.wp_pitch, H, k0, q, kk))[c];
+            const int r = min((NT / 8) * (WRC + slot / (NT / 8)) + slot % (NT / 8), NR - 1);
+            reinterpret_cast<f32x4*>(Wc_s)[idx] = reinterpret_cast<const f32x4*>(pair_row(WPh, a.wp_pitch, r))[c];
         }
     }
     __syncthreads();
@@ -379,8 +374,8 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
             __syncthreads();
         }
         PSTAMP(1);
-        if constexpr (cached) pair_matvec_cached<WRC>(a.WP, a.wp_pitch, bias_s, h_s, uah_s, gh_s, H, nk, k0, NR, grp, s8, wc, Wc_s, NL);
-        else pair_matvec(a.WP, a.wp_pitch, bias_s, h_s, uah_s, gh_s, H, nk, k0, NR, vecW, grp, s8);
+        if constexpr (cached) pair_matvec_cached<WRC, CM != 2>(WPh, a.wp_pitch, bias_s, h_s, out_s, H, NR, grp, s8, wc, Wc_s, NL);
+        else pair_matvec(WPh, a.wp_pitch, bias_s, h_s, out_s, H, NR, vecW, grp, s8);
         __syncthreads();
         PSTAMP(2);
         // B: my part of e_p = v_a . tanh(Waf_p + uah) (+ b_va)
@@ -536,6 +531,7 @@ template <bool LSTM>
 __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
     constexpr int NG = LSTM ? 4 : 3;
     constexpr int PGM = 10;
+    constexpr int TU = 8;                       // streamed rows in flight per thread in the transposed mat-vec
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = (w & 7) + 8 * (w >> 4), hh = (w >> 3) & 1;
@@ -545,6 +541,7 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
     const HalfK hk = half_of(H, hh);
     const int k0 = hk.k0, nk = hk.nk, nkm = half_a(H);
     const int H4 = (H + 3) & ~3;
+    const float* WPh = a.WP + (size_t)hh * (NG + 1) * nkm * a.wp_pitch;     // my half of the packed [U_a; W_hh], local row order
     float* G_s = lds;                           // [P][RG][nk]
     float* dh_s = G_s + (size_t)P * RG * nkm;   // [nk] carried dh of my k
     float* dc_s = dh_s + nkm;
@@ -612,9 +609,8 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
         if (slice < nsl) {
             for (int c = chunk; c < nch; c += nch_eff) {
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                int r = slice, qp = 0, kk = slice;
-                while (kk >= nk) { kk -= nk; ++qp; }
-                const float* col = a.WP + cb + c * CH;
+                int r = slice;
+                const float* col = WPh + cb + c * CH;        // row r of my half: col + r * pitch (per-half packed copy)
                 // rows [0, NLb) come from LDS (NLb is a multiple of 4 nsl: a batch of four is on one side or the other)
                 const int NLb = (CH == 4 && cb == 0) ? a.wc_rows : 0;
                 while (r < NLb) {               // (NLb <= NR: all four rows exist)
@@ -623,31 +619,31 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
                     for (int u = 0; u < 4; ++u) {
                         wv[u] = *reinterpret_cast<const f32x4*>(Wc_s + (size_t)r * H + c * 4);
                         dj[u] = dvec_s[r];
-                        r += nsl; kk += nsl;
-                        while (kk >= nk) { kk -= nk; ++qp; }
+                        r += nsl;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { acc[0] += wv[u][0] * dj[u]; acc[1] += wv[u][1] * dj[u]; acc[2] += wv[u][2] * dj[u]; acc[3] += wv[u][3] * dj[u]; }
                 }
+                // streamed rows, TU at a time: TU independent 16-byte loads in flight per thread (linear addresses: nothing but
+                // the row counter lives across the batch -- with the (q', kk) form this loop held 245 VGPRs at four loads)
                 while (r < NR) {
-                    const float* rp[4]; float dj[4];
+                    const float* rp[TU]; float dj[TU];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < TU; ++u) {
                         const bool ok = r < NR;
-                        rp[u] = col + (size_t)((ok ? qp : 0) * H + k0 + (ok ? kk : 0)) * a.wp_pitch;
+                        rp[u] = col + (size_t)(ok ? r : 0) * a.wp_pitch;
                         dj[u] = ok ? dvec_s[r] : 0.f;
-                        r += nsl; kk += nsl;
-                        while (kk >= nk) { kk -= nk; ++qp; }
+                        r += nsl;
                     }
                     if (CH == 4) {
-                        f32x4 wv[4];
+                        f32x4 wv[TU];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) wv[u] = *reinterpret_cast<const f32x4*>(rp[u]);
+                        for (int u = 0; u < TU; ++u) wv[u] = *reinterpret_cast<const f32x4*>(rp[u]);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { acc[0] += wv[u][0] * dj[u]; acc[1] += wv[u][1] * dj[u]; acc[2] += wv[u][2] * dj[u]; acc[3] += wv[u][3] * dj[u]; }
+                        for (int u = 0; u < TU; ++u) { acc[0] += wv[u][0] * dj[u]; acc[1] += wv[u][1] * dj[u]; acc[2] += wv[u][2] * dj[u]; acc[3] += wv[u][3] * dj[u]; }
                     } else {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) acc[0] += rp[u][0] * dj[u];
+                        for (int u = 0; u < TU; ++u) acc[0] += rp[u][0] * dj[u];
                     }
                 }
                 if (CH == 4) *reinterpret_cast<f32x4*>(part_s + (size_t)slice * H4 + c * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
@@ -669,8 +665,7 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
         const int n4 = H >> 2;
         for (int idx = tid; idx < a.wc_rows * n4; idx += NT) {
             const int r = idx / n4, c = idx - r * n4;
-            const int qp = r / nk, kk = r - qp * nk;
-            reinterpret_cast<f32x4*>(Wc_s)[idx] = reinterpret_cast<const f32x4*>(a.WP + (size_t)(qp * H + k0 + kk) * a.wp_pitch)[c];
+            reinterpret_cast<f32x4*>(Wc_s)[idx] = reinterpret_cast<const f32x4*>(WPh + (size_t)r * a.wp_pitch)[c];
         }
         __syncthreads();
     }
@@ -900,23 +895,29 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(u64* __restrict__ xch, s
     // (a buffer the backward wants zero-filled -- d Hs, accumulated by split-K atomics -- rides along: its own launch sat on the
     //  chain between the loss and the first backward GEMM)
     for (size_t j = i0; j < nz; j += stride) zbuf[j] = 0.f;
+    // packed layout: WP[half][local row r = q' nk_half + kk][pitch], q' = 0 the rows of U_a, 1 + q gate block q of W_hh, restricted
+    // to the half's k range [k0, k0 + nk); each half has room for (NG + 1) nkm rows (nkm = the wider half)
+    const int HA = half_a(H), NGp1 = rows / H, hrows = NGp1 * HA;
+    auto src_row = [&](int hh, int r) -> const float* {
+        const int k0 = hh ? HA : 0, nk = hh ? H - HA : HA;
+        if (r >= NGp1 * nk) return nullptr;
+        const int q = r / nk, kk = r - q * nk;
+        return q == 0 ? U_a + (size_t)(k0 + kk) * H : W_hh + (size_t)((q - 1) * H + k0 + kk) * H;
+    };
     if ((H & 3) == 0 && caphn_aligned16_dev(U_a) && caphn_aligned16_dev(W_hh)) {
         // whole pitch written: the pad columns hold zeros, so a lane may read its chunk without a bounds clamp (one base address
         // and immediate offsets instead of an address pair per chunk)
         const int n4 = H >> 2, p4 = pitch >> 2;
-        for (size_t j = i0; j < (size_t)rows * p4; j += stride) {
-            const int r = (int)(j / p4), c = (int)(j % p4);
-            const float* src = r < H ? U_a + (size_t)r * H : W_hh + (size_t)(r - H) * H;
-            reinterpret_cast<f32x4*>(WP + (size_t)r * pitch)[c] = c < n4 ? reinterpret_cast<const f32x4*>(src)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (size_t j = i0; j < (size_t)2 * hrows * p4; j += stride) {
+            const int rr = (int)(j / p4), c = (int)(j % p4);
+            const float* src = src_row(rr / hrows, rr % hrows);
+            reinterpret_cast<f32x4*>(WP + (size_t)rr * pitch)[c] = (src && c < n4) ? reinterpret_cast<const f32x4*>(src)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     } else {
-        for (size_t j = i0; j < (size_t)rows * H; j += stride) {
-            const int r = (int)(j / H), c = (int)(j % H);
-            WP[(size_t)r * pitch + c] = r < H ? U_a[(size_t)r * H + c] : W_hh[(size_t)(r - H) * H + c];
-        }
-        for (size_t j = i0; j < (size_t)rows * (pitch - H); j += stride) {
-            const int r = (int)(j / (pitch - H)), c = H + (int)(j % (pitch - H));
-            WP[(size_t)r * pitch + c] = 0.f;
+        for (size_t j = i0; j < (size_t)2 * hrows * pitch; j += stride) {
+            const int rr = (int)(j / pitch), c = (int)(j % pitch);
+            const float* src = src_row(rr / hrows, rr % hrows);
+            WP[(size_t)rr * pitch + c] = (src && c < H) ? src[c] : 0.f;
         }
     }
 }
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(u64* __restrict__ xch, s
 }  // namespace
 // (at least one full column block of the mat-vec, 32 JM floats: see the pad note in pair_prep_kernel)
 int caphn_rec_pair_pitch(int H) { const int p = (H + 31) & ~31; return p < 32 * JM ? 32 * JM : p; }
-size_t caphn_rec_pair_wp_floats(int H, int NG) { return (size_t)(NG + 1) * H * caphn_rec_pair_pitch(H); }
+size_t caphn_rec_pair_wp_floats(int H, int NG) { return (size_t)2 * (NG + 1) * half_a(H) * caphn_rec_pair_pitch(H); }
 int caphn_launch_rec_pair_prep(unsigned long long* xch, size_t nxch, const float* U_a, const float* W_hh, int H, int NG, float* WP,
                                float* zbuf, size_t nz, hipStream_t s) {
     hipLaunchKernelGGL(pair_prep_kernel, dim3(256), dim3(256), 0, s, xch, nxch, U_a, W_hh, H, (NG + 1) * H, caphn_rec_pair_pitch(H), WP,
@@ -934,7 +935,8 @@ int caphn_launch_rec_pair_prep(unsigned long long* xch, size_t nxch, const float
 int caphn_rec_pair_debug_skip(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(d_skip_xrecv), &v, sizeof(int)) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH; }
 
 static int kgn(int n) { return n >= NT ? 1 : NT / n; }
-int g_tune_rec_cache = 1;   // 1 (default): part of the recurrent weights on chip for the whole kernel (registers + spare LDS); 0: all streamed
+int g_tune_rec_cache = 2;   // 2 (default): the forward keeps ALL of a half's [U_a; W_hh] on chip when it fits (GRU, H = 200), else as 1;
+                            // 1: part of the recurrent weights on chip for the whole kernel (registers + spare LDS); 0: all streamed
 size_t caphn_rec_pair_xch_bytes(int B, int P, int H) {
     const size_t nwg = 16 * (size_t)((B + 7) / 8);
     return nwg * xch_stride(P, H) * sizeof(u64);
@@ -982,8 +984,9 @@ static int set_attrs_here() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CAPHN_ELAUNCH;
     if (done[dev]) return CAPHN_OK;
-    if (set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, false>)) ||
-        set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, true>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, true>)) ||
+    if (set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, 0>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, 0>)) ||
+        set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, 1>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, 1>)) ||
+        set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, 2>)) ||
         set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<true>)))
         return CAPHN_ELAUNCH;
     done[dev] = true;
@@ -1002,12 +1005,12 @@ static int prepare_xch(int T, unsigned* epoch, int** err, long long* limit) {
 }
 // rows of the half's [U_a; W_hh] the forward kernel keeps in the LDS left over (a multiple of 8: wave-uniform; at most what
 // the two register-resident sweeps leave)
-int caphn_rec_pair_fwd_cache_rows(int P, int H, int NG, int RG) {
+int caphn_rec_pair_fwd_cache_rows(int P, int H, int NG, int RG, int rc = 2) {
     size_t base = caphn_rec_pair_fwd_lds_bytes(P, H, NG, RG);
     if (base > LDS_LIMIT || g_tune_rec_cache == 0) return g_tune_rec_cache == 0 ? -1 : 0;
     if (base + sizeof(float) * (size_t)P * half_a(H) <= LDS_LIMIT) base += sizeof(float) * (size_t)P * half_a(H);      // W_a f columns
     long rows = (long)((LDS_LIMIT - base) / (sizeof(float) * (size_t)H)) & ~7L;
-    const long nr = (long)(NG + 1) * half_a(H), left = nr - 2 * (NT / 8);
+    const long nr = (long)(NG + 1) * half_a(H), left = nr - rc * (NT / 8);
     if (rows > left) rows = left > 0 ? (left + 7) & ~7L : 0;
     if ((size_t)rows * H * sizeof(float) + base > LDS_LIMIT) rows -= 8;
     return rows > 0 ? (int)rows : 0;
@@ -1020,17 +1023,27 @@ int caphn_launch_rec_pair_fwd(const RecFwdArgs& a_, bool lstm, hipStream_t s) {
     a.waf_lds = lds + waf_bytes <= LDS_LIMIT ? 1 : 0;
     if (a.waf_lds) lds += waf_bytes;
     a.wc_rows = ((a.H % 4) == 0 && a.H <= 32 * JM) ? caphn_rec_pair_fwd_cache_rows(a.P, a.H, lstm ? 4 : 3, a.RG) : -1;
+    // everything on chip?  FULL_RC register sweeps + the LDS rows must cover the wider half's rows (GRU cell only: the LSTM's fourth
+    // gate block does not fit).  caphn_tune(16, 1) keeps the partial cache for A/B runs; 2 (default) takes this when it fits
+    bool full = false;
+    if (!lstm && a.wc_rows >= 0 && g_tune_rec_cache >= 2) {
+        const int nr = 4 * half_a(a.H);
+        const int rows5 = caphn_rec_pair_fwd_cache_rows(a.P, a.H, 3, a.RG, FULL_RC);
+        if (rows5 >= 0 && FULL_RC * (NT / 8) + rows5 >= nr) { full = true; a.wc_rows = rows5; }
+    }
     if (a.wc_rows > 0) lds += sizeof(float) * (size_t)a.wc_rows * a.H;
     RUN_ATTR();
     if (prepare_xch(a.T, &a.epoch, &a.err, &a.xlimit) != CAPHN_OK) return CAPHN_ELIMIT;
     const unsigned nwg = 16u * (unsigned)((a.B + 7) / 8);
     const bool cached = a.wc_rows >= 0 && (a.H % 4) == 0 && a.H <= 32 * JM;
-    if (cached) {
-        if (lstm) hipLaunchKernelGGL((rec_pair_fwd_kernel<true, true>), dim3(nwg), dim3(NT), lds, s, a);
-        else hipLaunchKernelGGL((rec_pair_fwd_kernel<false, true>), dim3(nwg), dim3(NT), lds, s, a);
+    if (cached && full) {
+        hipLaunchKernelGGL((rec_pair_fwd_kernel<false, 2>), dim3(nwg), dim3(NT), lds, s, a);
+    } else if (cached) {
+        if (lstm) hipLaunchKernelGGL((rec_pair_fwd_kernel<true, 1>), dim3(nwg), dim3(NT), lds, s, a);
+        else hipLaunchKernelGGL((rec_pair_fwd_kernel<false, 1>), dim3(nwg), dim3(NT), lds, s, a);
     } else {
-        if (lstm) hipLaunchKernelGGL((rec_pair_fwd_kernel<true, false>), dim3(nwg), dim3(NT), lds, s, a);
-        else hipLaunchKernelGGL((rec_pair_fwd_kernel<false, false>), dim3(nwg), dim3(NT), lds, s, a);
+        if (lstm) hipLaunchKernelGGL((rec_pair_fwd_kernel<true, 0>), dim3(nwg), dim3(NT), lds, s, a);
+        else hipLaunchKernelGGL((rec_pair_fwd_kernel<false, 0>), dim3(nwg), dim3(NT), lds, s, a);
     }
     return caphn_launch_status();
 }

@@ -13,8 +13,11 @@ p = {n: (torch.rand(s, device=dev) - 0.5) * 0.14 for n, s in dims.param_shapes()
 feats = torch.relu(torch.randn(B, P, 2048, device=dev)) * 0.45
 caps = torch.randint(1, 9684, (B, T), device=dev)
 ws = ops.decoder_workspace(dims, dev)
-for pair in (1, 0):
+# (pair, forward cache mode of caphn_tune key 16): 2 = everything on chip when it fits, 1 = partial, single-workgroup kernels last
+for pair, cache in ((1, 2), (1, 1), (0, 1)):
     _lib.load().caphn_tune(9, pair)
+    _lib.load().caphn_tune(16, cache)
+    print(f"---- pair={pair} cache={cache}")
     for _ in range(3):
         logits, _ = ops.decoder_forward(dims, p, feats, caps, ws)
         lo, dl = ops.cross_entropy_fwd_bwd(logits, caps, 0)
