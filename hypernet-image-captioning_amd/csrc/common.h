@@ -69,14 +69,39 @@ __device__ __forceinline__ float group8_sum(float v) {
 }
 
 // ---- wave reductions (64 lanes) ----
+// On the DPP / lane-permute path (no ds_bpermute: six dependent LDS round trips per reduction were ~700 cycles): pairs and quads
+// by quad_perm, the two quads of a half row by row_half_mirror, the two halves of a 16-lane row by row_mirror, odd/even rows by
+// v_permlane16_swap, the wave halves by v_permlane32_swap (given the same register twice, the two results are "mine" and
+// "the other side's" in every lane).  Every lane ends with the total.
+__device__ __forceinline__ float caphn_dpp_row_mirror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    v = group8_sum(v);
+    v += caphn_dpp_row_mirror(v);
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), false, false);
+        v = __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), false, false);
+        v = __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+    }
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    v = fmaxf(v, caphn_dpp(v, 0xB1));
+    v = fmaxf(v, caphn_dpp(v, 0x4E));
+    v = fmaxf(v, caphn_dpp(v, 0x141));
+    v = fmaxf(v, caphn_dpp_row_mirror(v));
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), false, false);
+        v = fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), false, false);
+        v = fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+    }
     return v;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {

@@ -46,10 +46,21 @@ constexpr int NT = 512;
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ void xsend(u64* slot, float v, unsigned tag) {
+// near = the partner runs on the SAME XCD (both read HW_REG_XCC_ID at kernel start and told each other through the safe form):
+// the granule is then stored with workgroup scope (sc0: the line STAYS in the XCD's L2) and the partner's sc1 poll is served by
+// that L2 in ~200 cycles.  An agent-scope (sc1) store writes through and DROPS the line, so the poll that finds the granule is a
+// trip past the L2 (545-900 cycles idle, 2-3 k under load) -- that read, not waiting for the partner, was the ~3 k cycles of a
+// hand-off (work placed between send and receive did not hide any of it).  Partners on different XCDs keep the sc1 form: an
+// L2 is only coherent for its own XCD's CUs.  Placement decides speed, never correctness.
+__device__ int d_pair_opts = 0;       // caphn_tune key 24 (A/B): bit 0 no same-XCD form; bit 1 forward mat-vec split around the score exchange, bit 2 backward
+                                      // transposed mat-vec split around the d alpha exchange (both measured SLOWER: off by default)
+__device__ __forceinline__ void xsend(u64* slot, float v, unsigned tag, bool near = false) {
     const u64 bits = ((u64)tag << 32) | (u64)__float_as_uint(v);
-    __hip_atomic_store(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (near) __hip_atomic_store(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// one safe hand-off at kernel start: do my partner and I share an XCD?  (thread 0 asks, the answer goes through LDS)
+__device__ __forceinline__ bool partner_is_near(u64* ctl_mine, u64* ctl_part, unsigned tag, int* err, long long limit, int tid, int* flag_s);
 // tag of exchange x (1: h / dh, 2: scores / d alpha) of time step t in the launch with epoch `ep` (already shifted)
 __device__ __forceinline__ unsigned xtag(unsigned ep, int t, int x) { return ep | (2u * (unsigned)t + (unsigned)x); }
 // caphn_tune key 10 -- experiments and tests only: 1 = do not wait for the partner (timing; WRONG results), 2 = half 1 never
@@ -78,6 +89,18 @@ __device__ __forceinline__ float xrecv(u64* slot, unsigned tag, const XCtl& c) {
     const u64 bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((unsigned)(bits >> 32) == tag) return __uint_as_float((unsigned)bits);
     return xrecv_wait(slot, tag, c.err, c.limit);
+}
+
+__device__ __forceinline__ bool partner_is_near(u64* ctl_mine, u64* ctl_part, unsigned tag, int* err, long long limit, int tid, int* flag_s) {
+    if (tid == 0) {
+        const unsigned mine = __builtin_amdgcn_s_getreg(6164);      // hwreg(HW_REG_XCC_ID, 0, 4)
+        xsend(ctl_mine, __uint_as_float(mine + 1u), tag);
+        const XCtl c{err, limit};
+        const unsigned theirs = __float_as_uint(xrecv(ctl_part, tag, c));
+        *flag_s = (theirs == mine + 1u && !(d_pair_opts & 1) && d_skip_xrecv == 0) ? 1 : 0;
+    }
+    __syncthreads();
+    return *flag_s != 0;
 }
 
 // sums of EIGHT values over the 64 lanes in 10 shuffles instead of 48: three halving exchanges (after them lane l holds
@@ -128,7 +151,9 @@ __device__ __forceinline__ KG kg_map(int tid, int n) {
     if (m.g >= m.ng) m.g = -1;
     return m;
 }
-__host__ __device__ __forceinline__ int xch_stride(int P, int H) { return ((half_a(H) + P + 7) & ~7); }     // granules per workgroup
+// granules per workgroup: [h / dh half | scores / d alpha | 8 control granules (0: XCC id)]
+__host__ __device__ __forceinline__ int xch_stride(int P, int H) { return ((half_a(H) + P + 7) & ~7) + 8; }
+__host__ __device__ __forceinline__ int xch_ctl(int P, int H) { return ((half_a(H) + P + 7) & ~7); }
 
 // y[r] = row_r . x + bias_r for the rows r = grp, grp + NT/8, ... < NR of this half's [U_a; W_hh] (8 lanes per row).
 // Everything in this kernel is bound by dependent latencies, not by bytes: a load-wait-multiply loop per 16-byte chunk
@@ -194,7 +219,11 @@ __device__ __forceinline__ void pair_matvec(const float* __restrict__ WPh, int p
 // lane group's own registers (RC x JM dwordx4 per lane), the next `NL` rows (slot = row order after those sweeps) in LDS, the
 // rest streams from L2 as above.  Needs H % 4 == 0 and H <= 32 JM (one column block).
 // STREAM = false: the launcher found room for ALL rows (RC register sweeps + NL rows of LDS >= NR): no global load in the time loop
-template <int RC, bool STREAM>
+// PART (all-on-chip variant only): 0 the whole product; 1 only the register sweeps [0, SPLIT_RC) -- they hold every row of U_a, which
+// is all the attention scores need; 2 the rest (W_hh rows, needed only by the gates) -- issued between the send and the receive of
+// the score exchange, whose ~3 k cycles of L2 round trip it hides (with the weights on chip a split product has no second ramp-up)
+constexpr int SPLIT_RC = 2;
+template <int RC, bool STREAM, int PART = 0>
 __device__ __forceinline__ void pair_matvec_cached(const float* __restrict__ WPh, int pitch, const float* bias_s,
                                                    const float* x_s, float* out_s,
                                                    int H, int NR, int grp, int s, const f32x4 (&wc)[RC][JM],
@@ -231,8 +260,8 @@ __device__ __forceinline__ void pair_matvec_cached(const float* __restrict__ WPh
         for (int j = 0; j < JM; ++j) va[j] = pa[s + 8 * j];
     }
 #pragma unroll
-    for (int i = 0; i < RC; ++i) emit(RS * i + grp, dot(wc[i]));
-    {
+    for (int i = (PART == 2 ? SPLIT_RC : 0); i < (PART == 1 ? SPLIT_RC : RC); ++i) emit(RS * i + grp, dot(wc[i]));
+    if constexpr (PART != 1) {
         int i = RC;
 #pragma unroll 1
         for (int slot = grp; slot < NL; slot += RS, ++i) {
@@ -302,6 +331,8 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
     const unsigned ep = a.epoch << 16;
     const XCtl xc{a.err, a.xlimit};
     const bool mute = d_skip_xrecv == 2 && hh == 1;
+    // (the flag word borrows the first word of the score vector: free until the first time step, a barrier lies between)
+    const bool near = partner_is_near(xmine + xch_ctl(P, H), xpart + xch_ctl(P, H), ep | 0xFFFFu, a.err, a.xlimit, tid, reinterpret_cast<int*>(e_s));
 
     const float* Gb = a.G + (size_t)b * P * GH;
     const int vecS = a.vecS && (nk % 4 == 0) && (k0 % 4 == 0);
@@ -374,7 +405,13 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
             __syncthreads();
         }
         PSTAMP(1);
-        if constexpr (cached) pair_matvec_cached<WRC, CM != 2>(WPh, a.wp_pitch, bias_s, h_s, out_s, H, NR, grp, s8, wc, Wc_s, NL);
+        // (CM == 2 with P <= 64: only the sweeps that hold U_a's rows now, the W_hh rows between the send and the receive below)
+        constexpr bool SPLIT = CM == 2;
+        const bool split = SPLIT && P <= 64 && (d_pair_opts & 2);
+        if constexpr (cached) {
+            if (split) pair_matvec_cached<WRC, CM != 2, SPLIT ? 1 : 0>(WPh, a.wp_pitch, bias_s, h_s, out_s, H, NR, grp, s8, wc, Wc_s, NL);
+            else pair_matvec_cached<WRC, CM != 2>(WPh, a.wp_pitch, bias_s, h_s, out_s, H, NR, grp, s8, wc, Wc_s, NL);
+        }
         else pair_matvec(WPh, a.wp_pitch, bias_s, h_s, out_s, H, NR, vecW, grp, s8);
         __syncthreads();
         PSTAMP(2);
@@ -407,11 +444,17 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
         // exchange 1: e = e(half 0) + e(half 1), the same sum in the same order on both sides
         if (P <= 64) {
             // ... and the softmax right there, in the registers of wave 0 (both halves compute the same values)
+            float mine = 0.f;
+            if (wave == 0 && lane < P) {
+                mine = e_s[lane];
+                if (!mute) xsend(xe_mine + lane, mine, xtag(ep, t, 2), near);
+            }
+            if constexpr (SPLIT) {      // the W_hh rows of the mat-vec run while the partner's partial scores travel
+                if (split) pair_matvec_cached<WRC, false, 2>(WPh, a.wp_pitch, bias_s, h_s, out_s, H, NR, grp, s8, wc, Wc_s, NL);
+            }
             if (wave == 0) {
                 float e = -INFINITY;
                 if (lane < P) {
-                    const float mine = e_s[lane];
-                    if (!mute) xsend(xe_mine + lane, mine, xtag(ep, t, 2));
                     const float theirs = xrecv(xe_part + lane, xtag(ep, t, 2), xc);
                     e = hh == 0 ? mine + theirs : theirs + mine;
                 }
@@ -424,7 +467,7 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
         } else {
         for (int p = tid; p < P; p += NT) {
             const float mine = e_s[p];
-            if (!mute) xsend(xe_mine + p, mine, xtag(ep, t, 2));
+            if (!mute) xsend(xe_mine + p, mine, xtag(ep, t, 2), near);
             const float theirs = xrecv(xe_part + p, xtag(ep, t, 2), xc);
             e_s[p] = hh == 0 ? mine + theirs : theirs + mine;
         }
@@ -514,11 +557,12 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
                 a.hn[bt * H + k] = hnv;
             }
             if (a.drop_p > 0.f) hnew *= caphn_keep_scale(a.drop_seed, (unsigned long long)bt * H + k, a.drop_p, 1.0f / (1.0f - a.drop_p));
+            // (the hand-off first: the saved activations below are seven more stores in this lane's memory queue)
+            if (t + 1 < t1 && !mute) xsend(xh_mine + kk, hnew, xtag(ep, t, 1), near);
             a.Hprev[bt * H + k] = hp;
             a.Hs[bt * H + k] = hnew;
             a.uah[bt * H + k] = uah_s[kk];
             h_s[k] = hnew;
-            if (t + 1 < t1 && !mute) xsend(xh_mine + kk, hnew, xtag(ep, t, 1));
         }
         __syncthreads();
         PSTAMP(7);
@@ -563,6 +607,7 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
     const unsigned ep = a.epoch << 16;
     const XCtl xc{a.err, a.xlimit};
     const bool mute = d_skip_xrecv == 2 && hh == 1;
+    const bool near = partner_is_near(xmine + xch_ctl(P, H), xpart + xch_ctl(P, H), ep | 0xFFFFu, a.err, a.xlimit, tid, reinterpret_cast<int*>(dal_s));
 
     const float* Gb = a.G + (size_t)b * P * GH;
     const int vecS = a.vecS && (nk % 4 == 0) && (k0 % 4 == 0);
@@ -658,6 +703,58 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
         }
         __syncthreads();
     };
+    // The same product in TWO parts (the common shape: float4 column chunks, one chunk per thread): rows [nk, NR) -- W_hh^T dgh,
+    // known as soon as the cell backward is done -- are accumulated in registers between the send and the receive of the d alpha
+    // exchange (its ~3 k cycles of L2 round trip run under ~6 k cycles of mat-vec); rows [0, nk) -- U_a^T duah, the end of the
+    // attention backward -- are added at the old place.  Same thread map, same per-thread row order, one reduction.
+    const int ts_nch = (H + 3) / 4;
+    const bool tsplit = CH == 4 && ts_nch <= NT && P <= 64 && (d_pair_opts & 4);
+    const int ts_nsl = tsplit ? NT / ts_nch : 1;
+    const int ts_chunk = tid % ts_nch, ts_slice = tid / ts_nch;
+    auto tm_rows = [&](int rlo, int rhi, float (&acc)[4]) {
+        if (ts_slice >= ts_nsl) return;
+        int r = ts_slice;
+        if (r < rlo) r += ((rlo - r + ts_nsl - 1) / ts_nsl) * ts_nsl;
+        const float* col = WPh + ts_chunk * 4;
+        const int lhi = min(rhi, a.wc_rows);
+        while (r < lhi) {               // rows resident in LDS
+            f32x4 wv[4]; float dj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = r < lhi;
+                wv[u] = *reinterpret_cast<const f32x4*>(Wc_s + (size_t)(ok ? r : 0) * H + ts_chunk * 4);
+                dj[u] = ok ? dvec_s[r] : 0.f;
+                r += ts_nsl;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc[0] += wv[u][0] * dj[u]; acc[1] += wv[u][1] * dj[u]; acc[2] += wv[u][2] * dj[u]; acc[3] += wv[u][3] * dj[u]; }
+        }
+        while (r < rhi) {               // streamed rows, TU loads in flight
+            const float* rp[TU]; float dj[TU];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const bool ok = r < rhi;
+                rp[u] = col + (size_t)(ok ? r : 0) * a.wp_pitch;
+                dj[u] = ok ? dvec_s[r] : 0.f;
+                r += ts_nsl;
+            }
+            f32x4 wv[TU];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) wv[u] = *reinterpret_cast<const f32x4*>(rp[u]);
+#pragma unroll
+            for (int u = 0; u < TU; ++u) { acc[0] += wv[u][0] * dj[u]; acc[1] += wv[u][1] * dj[u]; acc[2] += wv[u][2] * dj[u]; acc[3] += wv[u][3] * dj[u]; }
+        }
+    };
+    auto tm_finish = [&](const float (&acc)[4]) {
+        if (ts_slice < ts_nsl) *reinterpret_cast<f32x4*>(part_s + (size_t)ts_slice * H4 + ts_chunk * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        __syncthreads();
+        for (int j = tid; j < H; j += NT) {
+            float sum = 0.f;
+            for (int sl = 0; sl < ts_nsl; ++sl) sum += part_s[(size_t)sl * H4 + j];
+            dhp_s[j] = sum;
+        }
+        __syncthreads();
+    };
 
     // the saved activations of a step are requested one step ahead (seven or eight global loads per k; waited for at the
     // top of a step they cost ~2 k cycles): thread kk < nk holds its k's values, thread p < P alpha_p
@@ -686,6 +783,7 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
 
     for (int t = bt1 - 1; t >= bt0; --t) {
         const size_t bt = (size_t)b * T + t;
+        float accw[4] = {0.f, 0.f, 0.f, 0.f};       // this thread's part of the transposed mat-vec (tm_rows)
         if (pfk) { if (tid < P) al_s[tid] = pfa; }
         else for (int p = tid; p < P; p += NT) al_s[p] = a.alphas[bt * P + p];
         // cell backward (pointwise) for my k
@@ -768,11 +866,15 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
         if (P <= 64) {
             // ... and the softmax backward right there, in the registers of wave 0 (both halves, same values):
             // de_p = alpha_p (dalpha_p - sum_q alpha_q dalpha_q)
+            float mine = 0.f;
+            if (wave == 0 && lane < P) {
+                mine = dal_s[lane];
+                if (!mute) xsend(xe_mine + lane, mine, xtag(ep, t, 2), near);
+            }
+            if (tsplit) tm_rows(nk, NR, accw);      // W_hh^T dgh while the partner's partial d alpha travels
             if (wave == 0) {
                 float da = 0.f, al = 0.f;
                 if (lane < P) {
-                    const float mine = dal_s[lane];
-                    if (!mute) xsend(xe_mine + lane, mine, xtag(ep, t, 2));
                     al = al_s[lane];
                     const float theirs = xrecv(xe_part + lane, xtag(ep, t, 2), xc);
                     da = hh == 0 ? mine + theirs : theirs + mine;
@@ -783,7 +885,7 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
         } else {
         for (int p = tid; p < P; p += NT) {
             const float mine = dal_s[p];
-            if (!mute) xsend(xe_mine + p, mine, xtag(ep, t, 2));
+            if (!mute) xsend(xe_mine + p, mine, xtag(ep, t, 2), near);
             const float theirs = xrecv(xe_part + p, xtag(ep, t, 2), xc);
             dal_s[p] = hh == 0 ? mine + theirs : theirs + mine;
         }
@@ -845,9 +947,10 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
         // first (sent at once), then my own while its contribution to them travels
         // (one sweep over whole rows: 800 contiguous bytes per row and one reduction, instead of a sweep per column half --
         //  the hand-off it would have hidden costs ~1 k cycles, the second sweep cost 8 k)
-        tmatvec(0, H);
+        if (tsplit) { tm_rows(0, nk, accw); tm_finish(accw); }
+        else tmatvec(0, H);
         PSTAMP(5);
-        if (!mute) for (int j = tid; j < hk.nkp; j += NT) xsend(xh_mine + j, dhp_s[hk.k0p + j], xtag(ep, t, 1));
+        if (!mute) for (int j = tid; j < hk.nkp; j += NT) xsend(xh_mine + j, dhp_s[hk.k0p + j], xtag(ep, t, 1), near);
         PSTAMP(6);
         for (int kk = tid; kk < nk; kk += NT) {
             const float mine = dhp_s[k0 + kk];
@@ -932,6 +1035,7 @@ int caphn_launch_rec_pair_prep(unsigned long long* xch, size_t nxch, const float
                        zbuf, zbuf ? nz : 0);
     return caphn_launch_status();
 }
+int caphn_rec_pair_debug_opts(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(d_pair_opts), &v, sizeof(int)) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH; }
 int caphn_rec_pair_debug_skip(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(d_skip_xrecv), &v, sizeof(int)) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH; }
 
 static int kgn(int n) { return n >= NT ? 1 : NT / n; }
@@ -1029,7 +1133,7 @@ int caphn_launch_rec_pair_fwd(const RecFwdArgs& a_, bool lstm, hipStream_t s) {
     if (!lstm && a.wc_rows >= 0 && g_tune_rec_cache >= 2) {
         const int nr = 4 * half_a(a.H);
         const int rows5 = caphn_rec_pair_fwd_cache_rows(a.P, a.H, 3, a.RG, FULL_RC);
-        if (rows5 >= 0 && FULL_RC * (NT / 8) + rows5 >= nr) { full = true; a.wc_rows = rows5; }
+        if (rows5 >= 0 && FULL_RC * (NT / 8) + rows5 >= nr && half_a(a.H) <= SPLIT_RC * (NT / 8)) { full = true; a.wc_rows = rows5; }
     }
     if (a.wc_rows > 0) lds += sizeof(float) * (size_t)a.wc_rows * a.H;
     RUN_ATTR();
