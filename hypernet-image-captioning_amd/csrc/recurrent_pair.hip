@@ -52,8 +52,7 @@ typedef unsigned long long u64;
 // trip past the L2 (545-900 cycles idle, 2-3 k under load) -- that read, not waiting for the partner, was the ~3 k cycles of a
 // hand-off (work placed between send and receive did not hide any of it).  Partners on different XCDs keep the sc1 form: an
 // L2 is only coherent for its own XCD's CUs.  Placement decides speed, never correctness.
-__device__ int d_pair_opts = 0;       // caphn_tune key 24 (A/B): bit 0 no same-XCD form; bit 1 forward mat-vec split around the score exchange, bit 2 backward
-                                      // transposed mat-vec split around the d alpha exchange (both measured SLOWER: off by default)
+__device__ int d_pair_opts = 0;       // caphn_tune key 24 (A/B): bit 0 no same-XCD hand-off form
 __device__ __forceinline__ void xsend(u64* slot, float v, unsigned tag, bool near = false) {
     const u64 bits = ((u64)tag << 32) | (u64)__float_as_uint(v);
     if (near) __hip_atomic_store(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -160,6 +159,9 @@ __host__ __device__ __forceinline__ int xch_ctl(int P, int H) { return ((half_a(
 // cost the same 18 k cycles per time step for 400 rows as for 800.  Here a lane requests all its chunks of TWO rows
 // (2 x JM dwordx4, clamped addresses, no branches) before it uses any of them; x comes from LDS once per call.
 // Local row r = q' nk + kk: q' = 0 is U_a (-> uah_s[kk]), q' = 1 + q is gate block q of W_hh (-> gh_s[q nk + kk]).
+constexpr int BWD_TCR = 0;     // (register-resident rows of the BPTT transposed mat-vec: at 16 / 24 / 32 rows the kernel spills 52 / 104 / 144
+                               //  registers -- its other phases already hold ~240; the variant is compiled out)
+constexpr int BWD_TCR_UNUSED = 32;    // register-resident rows per thread of the all-on-chip backward variant (128 VGPRs)
 constexpr int FULL_RC = 5;     // register sweeps of the all-on-chip forward variant (5 x 64 rows x 28 VGPRs)
 constexpr int JM = 7;          // chunks per lane per column block: 8 lanes x 7 chunks x 4 floats = 224 columns per block
 // Rows come from the PACKED copy WP [(NG + 1) H][pitch] = [U_a; W_hh] with a row pitch of a multiple of 32 floats: a lane
@@ -219,11 +221,7 @@ __device__ __forceinline__ void pair_matvec(const float* __restrict__ WPh, int p
 // lane group's own registers (RC x JM dwordx4 per lane), the next `NL` rows (slot = row order after those sweeps) in LDS, the
 // rest streams from L2 as above.  Needs H % 4 == 0 and H <= 32 JM (one column block).
 // STREAM = false: the launcher found room for ALL rows (RC register sweeps + NL rows of LDS >= NR): no global load in the time loop
-// PART (all-on-chip variant only): 0 the whole product; 1 only the register sweeps [0, SPLIT_RC) -- they hold every row of U_a, which
-// is all the attention scores need; 2 the rest (W_hh rows, needed only by the gates) -- issued between the send and the receive of
-// the score exchange, whose ~3 k cycles of L2 round trip it hides (with the weights on chip a split product has no second ramp-up)
-constexpr int SPLIT_RC = 2;
-template <int RC, bool STREAM, int PART = 0>
+template <int RC, bool STREAM>
 __device__ __forceinline__ void pair_matvec_cached(const float* __restrict__ WPh, int pitch, const float* bias_s,
                                                    const float* x_s, float* out_s,
                                                    int H, int NR, int grp, int s, const f32x4 (&wc)[RC][JM],
@@ -260,8 +258,8 @@ __device__ __forceinline__ void pair_matvec_cached(const float* __restrict__ WPh
         for (int j = 0; j < JM; ++j) va[j] = pa[s + 8 * j];
     }
 #pragma unroll
-    for (int i = (PART == 2 ? SPLIT_RC : 0); i < (PART == 1 ? SPLIT_RC : RC); ++i) emit(RS * i + grp, dot(wc[i]));
-    if constexpr (PART != 1) {
+    for (int i = 0; i < RC; ++i) emit(RS * i + grp, dot(wc[i]));
+    {
         int i = RC;
 #pragma unroll 1
         for (int slot = grp; slot < NL; slot += RS, ++i) {
@@ -405,13 +403,7 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
             __syncthreads();
         }
         PSTAMP(1);
-        // (CM == 2 with P <= 64: only the sweeps that hold U_a's rows now, the W_hh rows between the send and the receive below)
-        constexpr bool SPLIT = CM == 2;
-        const bool split = SPLIT && P <= 64 && (d_pair_opts & 2);
-        if constexpr (cached) {
-            if (split) pair_matvec_cached<WRC, CM != 2, SPLIT ? 1 : 0>(WPh, a.wp_pitch, bias_s, h_s, out_s, H, NR, grp, s8, wc, Wc_s, NL);
-            else pair_matvec_cached<WRC, CM != 2>(WPh, a.wp_pitch, bias_s, h_s, out_s, H, NR, grp, s8, wc, Wc_s, NL);
-        }
+        if constexpr (cached) pair_matvec_cached<WRC, CM != 2>(WPh, a.wp_pitch, bias_s, h_s, out_s, H, NR, grp, s8, wc, Wc_s, NL);
         else pair_matvec(WPh, a.wp_pitch, bias_s, h_s, out_s, H, NR, vecW, grp, s8);
         __syncthreads();
         PSTAMP(2);
@@ -448,9 +440,6 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
             if (wave == 0 && lane < P) {
                 mine = e_s[lane];
                 if (!mute) xsend(xe_mine + lane, mine, xtag(ep, t, 2), near);
-            }
-            if constexpr (SPLIT) {      // the W_hh rows of the mat-vec run while the partner's partial scores travel
-                if (split) pair_matvec_cached<WRC, false, 2>(WPh, a.wp_pitch, bias_s, h_s, out_s, H, NR, grp, s8, wc, Wc_s, NL);
             }
             if (wave == 0) {
                 float e = -INFINITY;
@@ -571,7 +560,10 @@ __global__ __launch_bounds__(NT) void rec_pair_fwd_kernel(RecFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ BPTT, two workgroups per caption
-template <bool LSTM>
+// TCR > 0 (the launcher's choice when the shape allows: float4 column chunks, one chunk per thread, and every row a thread walks is
+// either among the LDS-resident ones or among the next TCR): those TCR rows of the transposed mat-vec live in the thread's
+// registers for the whole kernel -- the time loop then streams no weight at all (it was 320 rows x 800 B from L2 per step)
+template <bool LSTM, int TCR>
 __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
     constexpr int NG = LSTM ? 4 : 3;
     constexpr int PGM = 10;
@@ -638,13 +630,64 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
     float dw[PGM];
 #pragma unroll
     for (int i = 0; i < PGM; ++i) dw[i] = 0.f;
+    // my (k, position group) entries of W_a f: t-invariant, ten values a thread for the whole kernel (they were ten global loads
+    // per thread and time step in the d(U_a h) phase: this kernel's LDS is taken by the G slab and the weight rows)
+    float wafr[PGM];
+#pragma unroll
+    for (int i = 0; i < PGM; ++i) { const int p = m.g + i * m.ng; wafr[i] = (fuse && p < P) ? Waf_b[p * H + k0 + m.k] : 0.f; }
     float dva = 0.f, dbva = 0.f;
     PDECL;
 
     // partial of dh_{t-1}[cb .. ce) over my rows -> dhp_s[cb .. ce).  Threads = (column chunk, row slice); a thread walks its
     // slice's rows four at a time (four independent 16-byte loads in flight, no division in the loop)
+    // register-resident rows of the transposed mat-vec: row a.wc_rows + slice + u nsl, my column chunk
+    f32x4 wreg[TCR > 0 ? TCR : 1];
+    const int tc_nch = (H + 3) / 4, tc_nsl = NT / (tc_nch < NT ? tc_nch : NT);
+    const int tc_chunk = tid % tc_nch, tc_slice = tid / tc_nch;
+    if constexpr (TCR > 0) {
+#pragma unroll
+        for (int u = 0; u < TCR; ++u) {
+            const int r = a.wc_rows + tc_slice + u * tc_nsl;
+            wreg[u] = (tc_slice < tc_nsl && r < NR) ? *reinterpret_cast<const f32x4*>(WPh + (size_t)r * a.wp_pitch + tc_chunk * 4)
+                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     const float* dvec_s = duah_s;
     auto tmatvec = [&](int cb, int ce) {
+        if constexpr (TCR > 0) {        // (whole rows only: cb == 0, ce == H)
+            if (tc_slice < tc_nsl) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int r = tc_slice; r < a.wc_rows;) {        // LDS-resident rows, four at a time (wc_rows is a multiple of 4 nsl)
+                    f32x4 wv[4]; float dj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        wv[u] = *reinterpret_cast<const f32x4*>(Wc_s + (size_t)r * H + tc_chunk * 4);
+                        dj[u] = dvec_s[r];
+                        r += tc_nsl;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { acc[0] += wv[u][0] * dj[u]; acc[1] += wv[u][1] * dj[u]; acc[2] += wv[u][2] * dj[u]; acc[3] += wv[u][3] * dj[u]; }
+                }
+#pragma unroll
+                for (int u0 = 0; u0 < TCR; u0 += 8) {           // register-resident rows: eight LDS reads of d in flight
+                    float dj[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int r = a.wc_rows + tc_slice + (u0 + u) * tc_nsl; dj[u] = (u0 + u < TCR && r < NR) ? dvec_s[r] : 0.f; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u0 + u < TCR) { const f32x4 w = wreg[u0 + u]; acc[0] += w[0] * dj[u]; acc[1] += w[1] * dj[u]; acc[2] += w[2] * dj[u]; acc[3] += w[3] * dj[u]; }
+                }
+                *reinterpret_cast<f32x4*>(part_s + (size_t)tc_slice * H4 + tc_chunk * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            }
+            __syncthreads();
+            for (int j = tid; j < H; j += NT) {
+                float sum = 0.f;
+                for (int sl = 0; sl < tc_nsl; ++sl) sum += part_s[(size_t)sl * H4 + j];
+                dhp_s[j] = sum;
+            }
+            __syncthreads();
+            return;
+        }
         const int ncol = ce - cb;
         if (ncol <= 0) return;
         const int nch = (ncol + CH - 1) / CH;
@@ -703,59 +746,6 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
         }
         __syncthreads();
     };
-    // The same product in TWO parts (the common shape: float4 column chunks, one chunk per thread): rows [nk, NR) -- W_hh^T dgh,
-    // known as soon as the cell backward is done -- are accumulated in registers between the send and the receive of the d alpha
-    // exchange (its ~3 k cycles of L2 round trip run under ~6 k cycles of mat-vec); rows [0, nk) -- U_a^T duah, the end of the
-    // attention backward -- are added at the old place.  Same thread map, same per-thread row order, one reduction.
-    const int ts_nch = (H + 3) / 4;
-    const bool tsplit = CH == 4 && ts_nch <= NT && P <= 64 && (d_pair_opts & 4);
-    const int ts_nsl = tsplit ? NT / ts_nch : 1;
-    const int ts_chunk = tid % ts_nch, ts_slice = tid / ts_nch;
-    auto tm_rows = [&](int rlo, int rhi, float (&acc)[4]) {
-        if (ts_slice >= ts_nsl) return;
-        int r = ts_slice;
-        if (r < rlo) r += ((rlo - r + ts_nsl - 1) / ts_nsl) * ts_nsl;
-        const float* col = WPh + ts_chunk * 4;
-        const int lhi = min(rhi, a.wc_rows);
-        while (r < lhi) {               // rows resident in LDS
-            f32x4 wv[4]; float dj[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool ok = r < lhi;
-                wv[u] = *reinterpret_cast<const f32x4*>(Wc_s + (size_t)(ok ? r : 0) * H + ts_chunk * 4);
-                dj[u] = ok ? dvec_s[r] : 0.f;
-                r += ts_nsl;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { acc[0] += wv[u][0] * dj[u]; acc[1] += wv[u][1] * dj[u]; acc[2] += wv[u][2] * dj[u]; acc[3] += wv[u][3] * dj[u]; }
-        }
-        while (r < rhi) {               // streamed rows, TU loads in flight
-            const float* rp[TU]; float dj[TU];
-#pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                const bool ok = r < rhi;
-                rp[u] = col + (size_t)(ok ? r : 0) * a.wp_pitch;
-                dj[u] = ok ? dvec_s[r] : 0.f;
-                r += ts_nsl;
-            }
-            f32x4 wv[TU];
-#pragma unroll
-            for (int u = 0; u < TU; ++u) wv[u] = *reinterpret_cast<const f32x4*>(rp[u]);
-#pragma unroll
-            for (int u = 0; u < TU; ++u) { acc[0] += wv[u][0] * dj[u]; acc[1] += wv[u][1] * dj[u]; acc[2] += wv[u][2] * dj[u]; acc[3] += wv[u][3] * dj[u]; }
-        }
-    };
-    auto tm_finish = [&](const float (&acc)[4]) {
-        if (ts_slice < ts_nsl) *reinterpret_cast<f32x4*>(part_s + (size_t)ts_slice * H4 + ts_chunk * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-        __syncthreads();
-        for (int j = tid; j < H; j += NT) {
-            float sum = 0.f;
-            for (int sl = 0; sl < ts_nsl; ++sl) sum += part_s[(size_t)sl * H4 + j];
-            dhp_s[j] = sum;
-        }
-        __syncthreads();
-    };
-
     // the saved activations of a step are requested one step ahead (seven or eight global loads per k; waited for at the
     // top of a step they cost ~2 k cycles): thread kk < nk holds its k's values, thread p < P alpha_p
     if (a.wc_rows > 0) {            // (CH == 4 guaranteed by the launcher: H % 4 == 0)
@@ -783,7 +773,6 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
 
     for (int t = bt1 - 1; t >= bt0; --t) {
         const size_t bt = (size_t)b * T + t;
-        float accw[4] = {0.f, 0.f, 0.f, 0.f};       // this thread's part of the transposed mat-vec (tm_rows)
         if (pfk) { if (tid < P) al_s[tid] = pfa; }
         else for (int p = tid; p < P; p += NT) al_s[p] = a.alphas[bt * P + p];
         // cell backward (pointwise) for my k
@@ -871,7 +860,6 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
                 mine = dal_s[lane];
                 if (!mute) xsend(xe_mine + lane, mine, xtag(ep, t, 2), near);
             }
-            if (tsplit) tm_rows(nk, NR, accw);      // W_hh^T dgh while the partner's partial d alpha travels
             if (wave == 0) {
                 float da = 0.f, al = 0.f;
                 if (lane < P) {
@@ -914,7 +902,7 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
                 const int p = m.g + i * m.ng;
                 if (p < P) {
                     const float de = dal_s[p];
-                    const float tv = caphn_tanh(Waf_b[p * H + k0 + kk] + u);
+                    const float tv = caphn_tanh(wafr[i] + u);
                     const float wv = de * (1.0f - tv * tv);
                     sd += wv; dw[i] += wv; dva += de * tv;
                     if (hh == 0 && kk == 0) dbva += de;
@@ -947,8 +935,7 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
         // first (sent at once), then my own while its contribution to them travels
         // (one sweep over whole rows: 800 contiguous bytes per row and one reduction, instead of a sweep per column half --
         //  the hand-off it would have hidden costs ~1 k cycles, the second sweep cost 8 k)
-        if (tsplit) { tm_rows(0, nk, accw); tm_finish(accw); }
-        else tmatvec(0, H);
+        tmatvec(0, H);
         PSTAMP(5);
         if (!mute) for (int j = tid; j < hk.nkp; j += NT) xsend(xh_mine + j, dhp_s[hk.k0p + j], xtag(ep, t, 1), near);
         PSTAMP(6);
@@ -1091,7 +1078,8 @@ static int set_attrs_here() {
     if (set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, 0>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, 0>)) ||
         set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, 1>)) || set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<true, 1>)) ||
         set_attr(reinterpret_cast<const void*>(rec_pair_fwd_kernel<false, 2>)) ||
-        set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<false>)) || set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<true>)))
+        set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<false, 0>)) || set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<true, 0>)) ||
+        set_attr(reinterpret_cast<const void*>(rec_pair_bwd_kernel<false, BWD_TCR>)))
         return CAPHN_ELAUNCH;
     done[dev] = true;
     return CAPHN_OK;
@@ -1133,7 +1121,7 @@ int caphn_launch_rec_pair_fwd(const RecFwdArgs& a_, bool lstm, hipStream_t s) {
     if (!lstm && a.wc_rows >= 0 && g_tune_rec_cache >= 2) {
         const int nr = 4 * half_a(a.H);
         const int rows5 = caphn_rec_pair_fwd_cache_rows(a.P, a.H, 3, a.RG, FULL_RC);
-        if (rows5 >= 0 && FULL_RC * (NT / 8) + rows5 >= nr && half_a(a.H) <= SPLIT_RC * (NT / 8)) { full = true; a.wc_rows = rows5; }
+        if (rows5 >= 0 && FULL_RC * (NT / 8) + rows5 >= nr) { full = true; a.wc_rows = rows5; }
     }
     if (a.wc_rows > 0) lds += sizeof(float) * (size_t)a.wc_rows * a.H;
     RUN_ATTR();
@@ -1181,7 +1169,14 @@ int caphn_launch_rec_pair_bwd(const RecBwdArgs& a_, bool lstm, hipStream_t s) {
     RUN_ATTR();
     if (prepare_xch(a.T, &a.epoch, &a.err, &a.xlimit) != CAPHN_OK) return CAPHN_ELIMIT;
     const unsigned nwg = 16u * (unsigned)((a.B + 7) / 8);
-    if (lstm) hipLaunchKernelGGL(rec_pair_bwd_kernel<true>, dim3(nwg), dim3(NT), lds, s, a);
-    else hipLaunchKernelGGL(rec_pair_bwd_kernel<false>, dim3(nwg), dim3(NT), lds, s, a);
+    // everything on chip?  float4 chunks, one per thread, and LDS rows + BWD_TCR register rows per slice cover the half's rows
+    bool full = false;
+    if (BWD_TCR > 0 && !lstm && g_tune_rec_cache >= 2 && (a.H % 4) == 0 && a.H / 4 <= NT && a.wc_rows > 0) {
+        const int nsl = NT / (a.H / 4), nr = 4 * half_a(a.H);
+        full = a.wc_rows + BWD_TCR * nsl >= nr;
+    }
+    if (full) hipLaunchKernelGGL((rec_pair_bwd_kernel<false, BWD_TCR>), dim3(nwg), dim3(NT), lds, s, a);
+    else if (lstm) hipLaunchKernelGGL((rec_pair_bwd_kernel<true, 0>), dim3(nwg), dim3(NT), lds, s, a);
+    else hipLaunchKernelGGL((rec_pair_bwd_kernel<false, 0>), dim3(nwg), dim3(NT), lds, s, a);
     return caphn_launch_status();
 }
