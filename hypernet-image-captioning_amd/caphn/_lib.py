@@ -166,6 +166,9 @@ SIGNATURES = {
                                        C.POINTER(C.c_size_t), C.c_double, C.c_double, c_fp, c_fp, c_fp]),
     "caphn_clip_coef": (C.c_int, [C.c_int, c_fp, c_fp, C.c_double, C.c_double, c_fp, c_fp]),
     "caphn_adam_dense_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp, c_fp, c_fp, C.POINTER(AdamHParams), c_fp]),
+    "caphn_grad_norm_adam_dense": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                             C.c_double, C.c_double, c_fp, c_fp, C.POINTER(AdamHParams), C.c_int, c_fp, c_fp, c_fp, c_fp]),
     "caphn_grad_norm_multi_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(C.c_size_t), C.c_int, C.c_int]),
     "caphn_grad_norm_multi": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
                                         C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),

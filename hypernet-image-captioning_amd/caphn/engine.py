@@ -346,7 +346,7 @@ class FusedTrainer:
         return ("emb", int(inp)) if self.fe_mode == "embedding" else ("fe", inp.data_ptr(), inp._version)
 
     def forward_backward(self, features, captions, x_style=None, style_token: Optional[int] = None,
-                         validate: bool = False, domain_input=None):
+                         validate: bool = False, domain_input=None, defer_loss: bool = False):
         """Fills the gradient arena (and the rank-1 factors) for one minibatch; returns the device
         tensor [loss, n_valid_targets] (a per-shape buffer the next call overwrites: .clone() or .item() it to keep a
         step's value).  Exactly one of x_style ([he] or [1,he]) / style_token (Flickr
@@ -440,7 +440,11 @@ class FusedTrainer:
         dlogits = buf["logits"]
         # (the reduction of the per-row losses used to run on the side stream; the two events that took -- a record on
         #  this stream, a wait at the end of the backward -- cost the chain more than the 6 us kernel does in line)
-        ops.cross_entropy_finish(B * T, buf["ce_ws"], buf["loss"], cnt)
+        # (step(): the reduction rides in the optimiser's first launch instead -- nothing on the device needs the scalar)
+        if defer_loss:
+            self._ce_pending = (B * T, buf["ce_ws"], cnt, buf["loss"])
+        else:
+            ops.cross_entropy_finish(B * T, buf["ce_ws"], buf["loss"], cnt)
         dtheta = self.flat_g[:self.theta_size]
         grads = self._dec_tensors(dtheta, grads=True)
         hg = self._hg_cache
@@ -577,10 +581,12 @@ class FusedTrainer:
         gn = self._gradnorm.get(R)
         if gn is None:
             gn = self._gradnorm[R] = ops.GradNorm(self.n_dense, R, len(segs), self.dev)
-        gn(self.flat_g, [(s[0], s[1]) for s in segs], self.max_norm, 1.0 / R, self._coef)
         step = max(self.step_count, 1)
-        ops.adam_dense(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self._coef, self.lr, step,
-                       self.betas, self.eps, dev_scalars=self._adam_dev if self._graph_scalars else None)
+        ce, self._ce_pending = getattr(self, "_ce_pending", None), None
+        # norm partials, then ONE launch that finishes the clip coefficient, runs Adam over the dense arena and reduces the loss
+        ops.grad_norm_adam_dense(gn, self.flat_p, self.flat_m, self.flat_v, self.flat_g, [(s[0], s[1]) for s in segs], self.max_norm,
+                                 1.0 / R, self._coef, self.lr, step, self.betas, self.eps,
+                                 dev_scalars=self._adam_dev if self._graph_scalars else None, ce=ce)
         prefetch = (next_x_style is not None) or (next_style_token is not None) or (next_domain_input is not None)
         if prefetch:
             # the small layers (and the style row of the embedding / the front-end) are already updated: compute the next
@@ -676,7 +682,7 @@ class FusedTrainer:
         minibatch when the loader is one batch ahead -- the front of its forward then overlaps this step's optimiser
         (the next call must pass those same tensors; captions as int64)."""
         self._begin_step()          # the Adam scalars' H2D copy goes in front of the forward, off the optimiser's tail
-        loss = self.forward_backward(features, captions, x_style, style_token, domain_input=domain_input)
+        loss = self.forward_backward(features, captions, x_style, style_token, domain_input=domain_input, defer_loss=True)
         if next_captions is not None:
             next_T = next_captions.shape[1]
         nb = None if next_features is None else (next_features, next_captions, captions.shape[1] if next_T is None else next_T)
@@ -711,7 +717,7 @@ class FusedTrainer:
                 torch.cuda.current_stream().wait_stream(self._pre_stream)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    loss = self.forward_backward(features, captions, x_style, style_token)
+                    loss = self.forward_backward(features, captions, x_style, style_token, defer_loss=True)
                     self._optimizer_impl()
                 self._graphs[key] = (g, loss)
             g, loss = self._graphs[key]

@@ -740,6 +740,35 @@ def adam_multi(ps, ms, vs, gs, coef, lr, step, betas=(0.9, 0.999), eps=1e-8) -> 
                                      L.ptr(coef), C.byref(hp), L.stream_ptr()), "caphn_adam_multi_f32")
 
 
+def grad_norm_adam_dense(gn: "GradNorm", p, m, v, flat_g: torch.Tensor, pairs, max_norm: float, scale: float, out: torch.Tensor,
+                         lr, step, betas, eps, dev_scalars=None, ce=None) -> torch.Tensor:
+    """gn(flat_g, pairs, ...) followed by adam_dense(p, m, v, flat_g, out, ...) in two launches (caphn_grad_norm_adam_dense): the
+    clip coefficient is finished inside the Adam kernel.  ce = (rows, ce_ws, n_valid_ptr or None, loss_out): the launch also reduces the
+    cross entropy's per-row losses (cross_entropy_rows) to loss_out -- cross_entropy_finish without a launch of its own."""
+    lib = L.load()
+    n = len(pairs)
+    assert flat_g.numel() == gn.n and n == gn.njobs and (n == 0 or pairs[0][0].shape[0] == gn.R)
+    key = (flat_g.data_ptr(),) + tuple((g.data_ptr(), g.stride(0), g.shape[1], a.data_ptr(), a.stride(0), a.shape[1]) for g, a in pairs)
+    if key != gn._key:
+        gn._args = ((C.c_int * n)(*[g.shape[1] for g, _ in pairs]), (C.c_int * n)(*[a.shape[1] for _, a in pairs]),
+                    (C.c_void_p * n)(*[g.data_ptr() for g, _ in pairs]), (C.c_size_t * n)(*[g.stride(0) for g, _ in pairs]),
+                    (C.c_void_p * n)(*[a.data_ptr() for _, a in pairs]), (C.c_size_t * n)(*[a.stride(0) for _, a in pairs]))
+        for g, a in pairs:
+            assert g.stride(1) == 1 and a.stride(1) == 1 and g.dtype == torch.float32 and a.dtype == torch.float32
+        L.ptr(flat_g); L.ptr(p); L.ptr(m); L.ptr(v)
+        gn._key = key
+    rows, ks, gp, ldg, ap, lda = gn._args
+    hp = _hp(lr, betas, eps, step, dev_scalars)
+    ce_rows, ce_ws, ce_cnt, ce_out = (0, None, None, None) if ce is None else ce
+    L.check(lib.caphn_grad_norm_adam_dense(gn.n, C.c_void_p(p.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()),
+                                           C.c_void_p(flat_g.data_ptr()), gn.R, n, rows, ks, gp, ldg, ap, lda, float(max_norm),
+                                           float(scale), L.ptr(out), C.c_void_p(gn.ws.data_ptr()), C.byref(hp), int(ce_rows),
+                                           None if ce_ws is None else C.c_void_p(ce_ws.data_ptr()), ce_cnt,
+                                           None if ce_out is None else C.c_void_p(ce_out.data_ptr()), L.stream_ptr()),
+            "caphn_grad_norm_adam_dense")
+    return out
+
+
 def decoder_hyper_backward(dims: DecDims, params, features, captions, dlogits, grads, ws,
                            shape: HyperShape, hyper_params, acts, hyper_grads, hyper_ws, want_x: bool = False):
     """decoder_backward + hyper_backward in one call; the hypernet VJP overlaps the decoder's tail.

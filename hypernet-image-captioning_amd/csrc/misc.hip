@@ -383,9 +383,10 @@ __global__ __launch_bounds__(256) void grad_norm_partials_kernel(size_t n, const
     __syncthreads();
     if (tid == 0) part[bid] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ __launch_bounds__(256) void grad_norm_finish_kernel(int nb_s, int R, int njobs, const double* __restrict__ part,
-                                                               double max_norm, double scale, float* __restrict__ coef_out) {
-    __shared__ double red[4];
+// the reduction of grad_norm_partials_kernel's slots to clip_grad_norm_'s coefficient, by one workgroup of 256 threads (fixed order).
+// Returns (in every thread) scale * min(1, max_norm / (norm + 1e-6)); *norm_out = the total norm.
+__device__ __forceinline__ float norm_finish(int nb_s, int R, int njobs, const double* __restrict__ part, double max_norm, double scale,
+                                             double* red /* [5] LDS */, float* norm_out) {
     const int tid = threadIdx.x;
     const double* gram = part + nb_s;            // [job][which][pair][chunk]
     double tot = 0.0;
@@ -402,14 +403,19 @@ __global__ __launch_bounds__(256) void grad_norm_finish_kernel(int nb_s, int R, 
     tot = wave_sum_d(tot);
     if ((tid & 63) == 0) red[tid >> 6] = tot;
     __syncthreads();
-    if (tid == 0) {
-        const double t = red[0] + red[1] + red[2] + red[3];
-        const double norm = scale * sqrt(t);
-        double c = max_norm / (norm + 1e-6);          // torch.nn.utils.clip_grad_norm_
-        if (c > 1.0) c = 1.0;
-        coef_out[0] = (float)(scale * c);
-        coef_out[1] = (float)norm;
-    }
+    const double t = red[0] + red[1] + red[2] + red[3];
+    const double norm = scale * sqrt(t);
+    double c = max_norm / (norm + 1e-6);          // torch.nn.utils.clip_grad_norm_
+    if (c > 1.0) c = 1.0;
+    *norm_out = (float)norm;
+    return (float)(scale * c);
+}
+__global__ __launch_bounds__(256) void grad_norm_finish_kernel(int nb_s, int R, int njobs, const double* __restrict__ part,
+                                                               double max_norm, double scale, float* __restrict__ coef_out) {
+    __shared__ double red[5];
+    float norm;
+    const float c = norm_finish(nb_s, R, njobs, part, max_norm, scale, red, &norm);
+    if (threadIdx.x == 0) { coef_out[0] = c; coef_out[1] = norm; }
 }
 
 // ------------------------------------------------------------------ Adam (torch.optim.Adam, single-tensor form)
@@ -423,6 +429,54 @@ __device__ __forceinline__ float adam_elem(float p, float g, float& m, float& v,
 __global__ __launch_bounds__(256) void adam_dense_kernel(size_t n, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                          const float* __restrict__ g, const float* __restrict__ coef, AdamK k, int vec) {
     const float c = coef[0];
+    if (k.dev) { k.lr_bc1 = k.dev[0]; k.sqrt_bc2 = k.dev[1]; }
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (vec) {
+        f32x4* p4 = reinterpret_cast<f32x4*>(p); f32x4* m4 = reinterpret_cast<f32x4*>(m); f32x4* v4 = reinterpret_cast<f32x4*>(v);
+        const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+        const size_t n4 = n >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            f32x4 pp = p4[i], mm = m4[i], vv = v4[i], gg = g4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float me = mm[e], ve = vv[e]; pp[e] = adam_elem(pp[e], gg[e] * c, me, ve, k); mm[e] = me; vv[e] = ve; }
+            p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        }
+        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            float me = m[i], ve = v[i]; p[i] = adam_elem(p[i], g[i] * c, me, ve, k); m[i] = me; v[i] = ve;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            float me = m[i], ve = v[i]; p[i] = adam_elem(p[i], g[i] * c, me, ve, k); m[i] = me; v[i] = ve;
+        }
+    }
+}
+
+// adam_dense_kernel that finishes the clip coefficient itself: every workgroup reduces grad_norm_partials_kernel's slots (a few KB
+// from L2, the same fixed order in each), workgroup 0 also publishes coef / norm for the kernels behind it and -- when asked --
+// reduces the cross entropy's per-row losses to the reported scalar (that one-workgroup kernel used to sit on the chain between
+// the loss and the first backward GEMM; nothing on the device needs its result).  One launch instead of three.
+struct NormFin { const double* part; int nb_s, R, njobs; double max_norm, scale; float* coef_out;
+                 int ce_rows; const float* ce_rowloss; const float* ce_nvalid; const int* ce_nvi; float* loss_out; };
+__global__ __launch_bounds__(256) void adam_dense_clip_kernel(size_t n, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                              const float* __restrict__ g, NormFin nf, AdamK k, int vec) {
+    __shared__ double red[5];
+    float norm;
+    const float c = norm_finish(nf.nb_s, nf.R, nf.njobs, nf.part, nf.max_norm, nf.scale, red, &norm);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) { nf.coef_out[0] = c; nf.coef_out[1] = norm; }
+        if (nf.ce_rows > 0) {
+            __syncthreads();
+            double s = 0.0;
+            for (int i = threadIdx.x; i < nf.ce_rows; i += 256) s += (double)nf.ce_rowloss[i];
+            s = wave_sum_d(s);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const float nn = nf.ce_nvi ? (float)nf.ce_nvi[0] : nf.ce_nvalid[0];
+                nf.loss_out[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)nn); nf.loss_out[1] = nn;
+            }
+        }
+    }
     if (k.dev) { k.lr_bc1 = k.dev[0]; k.sqrt_bc2 = k.dev[1]; }
     const size_t stride = (size_t)gridDim.x * 256;
     if (vec) {
@@ -1106,5 +1160,33 @@ extern "C" int caphn_stream_copy_f32(size_t n, const float* src, float* dst, cap
     if (n == 0 || (n & 3) || !src || !dst || !caphn_aligned16(src) || !caphn_aligned16(dst)) return CAPHN_EINVAL;
     hipLaunchKernelGGL(stream_copy_kernel, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(stream), n >> 2,
                        reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst));
+    return caphn_launch_status();
+}
+// grad_norm_partials + (finish fused into) adam_dense: the front of the fused optimiser in TWO launches (was four, five with the
+// cross entropy's loss reduction, which rides along when ce_ws / loss_out are given: ce_rows rows as caphn_cross_entropy_rows left them)
+extern "C" int caphn_grad_norm_adam_dense(size_t n, float* p, float* m, float* v, const float* g, int R, int njobs, const int* rows,
+                                          const int* k, const float* const* gfac, const size_t* ldg, const float* const* afac,
+                                          const size_t* lda, double max_norm, double scale, float* coef_out, void* ws,
+                                          const caphn_adam_hparams* hp, int ce_rows, const void* ce_ws, const int* ce_n_valid_dev,
+                                          float* loss_out, caphn_stream_t stream) {
+    if (n == 0 || !p || !m || !v || !g || R <= 0 || R > RMAX || njobs < 0 || njobs > CAPHN_MAX_HEADS || !coef_out || !ws || !hp ||
+        hp->step < 1 || (ce_rows > 0 && (!ce_ws || !loss_out))) return CAPHN_EINVAL;
+    GramJobs jobs; jobs.n = njobs;
+    for (int i = 0; i < njobs; ++i) {
+        if (!rows || !k || !gfac || !ldg || !afac || !lda || rows[i] <= 0 || k[i] <= 0 || !gfac[i] || !afac[i]) return CAPHN_EINVAL;
+        jobs.j[i] = GramJob{gfac[i], ldg[i], afac[i], lda[i], rows[i], k[i]};
+    }
+    const int nb_s = caphn_sumsq_blocks(n);
+    const unsigned nb = (unsigned)nb_s + (unsigned)(njobs * 2 * R * R * NORM_CHUNKS);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(grad_norm_partials_kernel, dim3(nb), dim3(256), 0, s, n, g, (int)caphn_aligned16(g), nb_s, R, jobs,
+                       static_cast<double*>(ws));
+    NormFin nf{static_cast<const double*>(ws), nb_s, R, njobs, max_norm, scale, coef_out, ce_rows,
+               ce_rows > 0 ? static_cast<const float*>(ce_ws) + 4 : nullptr, static_cast<const float*>(ce_ws), ce_n_valid_dev, loss_out};
+    const int vec = caphn_aligned16(p) && caphn_aligned16(m) && caphn_aligned16(v) && caphn_aligned16(g);
+    size_t nbk = (n / 4 + 255) / 256;
+    if (nbk > 2048) nbk = 2048;
+    if (nbk < 1) nbk = 1;
+    hipLaunchKernelGGL(adam_dense_clip_kernel, dim3((unsigned)nbk), dim3(256), 0, s, n, p, m, v, g, nf, make_adam(hp), vec);
     return caphn_launch_status();
 }

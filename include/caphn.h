@@ -486,6 +486,15 @@ typedef struct caphn_adam_hparams {
 /* p,m,v,g flat [n]; g is multiplied by coef[0] (device) first. */
 int caphn_adam_dense_f32(size_t n, float* p, float* m, float* v, const float* g, const float* coef,
                          const caphn_adam_hparams* hp, caphn_stream_t stream);
+/* caphn_grad_norm_coef followed by caphn_adam_dense_f32 on the same flat gradient x = g, with the coefficient finished INSIDE the
+ * Adam kernel (two launches instead of three; coef_out is still written for the rank-1 passes behind it).  When ce_rows > 0 the
+ * launch also reduces the per-row losses caphn_cross_entropy_rows left in ce_ws to loss_out = {mean loss, n_valid}
+ * (= caphn_cross_entropy_finish, which then need not sit between the loss and the backward). */
+int caphn_grad_norm_adam_dense(size_t n, float* p, float* m, float* v, const float* g, int R, int njobs, const int* rows,
+                               const int* k, const float* const* gfac, const size_t* ldg, const float* const* afac,
+                               const size_t* lda, double max_norm, double scale, float* coef_out, void* ws,
+                               const caphn_adam_hparams* hp, int ce_rows, const void* ce_ws, const int* ce_n_valid_dev,
+                               float* loss_out, caphn_stream_t stream);
 /* The same two operations for parameters that live in SEPARATE allocations (a torch.optim.Optimizer over a module's
  * parameter list: cc_train_hypernet.py:110-120 builds Adam over ~30 tensors, Lightning clips their global norm to 5.0, :405).
  * All arrays are HOST arrays of ntensors entries holding device pointers / element counts (they travel as kernel arguments;
