@@ -181,6 +181,37 @@ def module_api_loop(dev, dims, batches, steps=10, warmup=3):
     return out
 
 
+def bind_to_gpu_numa(local_rank):
+    """Pin this rank's host threads to the CPUs of its GPU's NUMA node -- by sched_setaffinity in THIS process, before anything
+    touches the GPU (no re-exec, no numactl wrapper: a process that has initialised the GPU must not exec).  The GPU of local rank
+    r is the r-th GPU node of the KFD topology; its CPU list is the PCI device's local_cpulist.  Best effort: any surprise leaves
+    the affinity as it was.  CAPHN_BIND_NUMA=0 switches it off.  Returns a short description for the bench line."""
+    if os.environ.get("CAPHN_BIND_NUMA", "1") != "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = []
+        for n in sorted(os.listdir(base), key=int):
+            props = dict(l.split() for l in open(os.path.join(base, n, "properties")) if len(l.split()) == 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(int(props["drm_render_minor"]))
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if vis:
+            gpus = [gpus[int(i)] for i in vis.split(",") if i.strip().isdigit() and int(i) < len(gpus)]
+        minor = gpus[local_rank]
+        cpus = set()
+        for part in open(f"/sys/class/drm/renderD{minor}/device/local_cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = cpus & os.sched_getaffinity(0)
+        if not allowed or allowed == os.sched_getaffinity(0):
+            return None
+        os.sched_setaffinity(0, allowed)
+        return f"renderD{minor}: {len(allowed)} cpus"
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: this process -- which has made NO GPU call (counting devices does not
     initialise the GPU) and makes none -- starts N ranks through torch.distributed.run as a child process, passes their
@@ -288,6 +319,7 @@ def main():
     rehearsal = os.environ.get("CAPHN_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
+    numa = bind_to_gpu_numa(local) if world > 1 and not rehearsal else None      # before the first GPU call of this process
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -475,6 +507,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
 
+    final_loss = float(loss[0])
+    if dist.is_initialized() and (world > 1 or forced):
+        # per-collective device time: four extra steps OUTSIDE the timed region (every rank takes them) with every collective
+        # waited for at once between two events on the communication stream
+        tr.time_collectives = True
+        for i in range(4):
+            run_step(off + args.steps + i)
+        tr.time_collectives = False
+        barrier()
+    coll = tr.collective_report()
+
     if args.phases and rank == 0:
         phase_report(tr, batches, style)
 
@@ -511,8 +554,8 @@ def main():
                                       (" (one-rank RCCL group, collectives forced)" if forced else ""), "launch": "hipGraph" if use_graph else "eager",
                        "next_theta_in_adam_pass": not (use_graph or args.no_prefetch),
                        "next_precompute_beside_adam": not (use_graph or args.no_prefetch or args.no_overlap),
-                       "spinup_steps": spin["steps"],
-                       "final_loss": float(loss[0])},
+                       "spinup_steps": spin["steps"], "cpu_affinity": numa,
+                       "final_loss": final_loss},
             "roofline": {"bound": "hbm", "kernel": "adam_rank_kernel(hn_heads.0.2.weight)",
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": (achieved / (HBM_PEAK / 1e9)) if achieved else None, "traffic": traffic,
@@ -521,7 +564,7 @@ def main():
                          "copy_ceiling_gbps": ceiling, "frac_of_copy_ceiling": (achieved / ceiling) if (achieved and ceiling) else None,
                          "step_frac": STEP_ALGO_BYTES / (ms_step * 1e-3) / HBM_PEAK if B == 128 else None},
         }
-        line["collectives"] = tr.collective_report()
+        line["collectives"] = coll
         if world == 1 and not forced and not args.no_module_api and args.cell == "gru" and args.dtype == "f32":
             line["module_api"] = module_api_loop(dev, (B, T, P, D, F, E, H, V), batches)
         if world == 1 and not args.no_cpu_baseline:

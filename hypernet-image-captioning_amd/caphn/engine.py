@@ -62,8 +62,10 @@ class FusedTrainer:
         self._cell_names = d0.cell_names()
         # arena order of the decoder's parameters = the order their gradients are finished by the backward, so that
         # the data-parallel all-reduce can go bucket by bucket: vocabulary projection, embedding table, the rest
-        front = ["fc.weight", "fc.bias", "embed.weight"]
-        self._dec_names = front + [n for n in d0.names() if n not in self._cell_names and n not in front]
+        # ... and what the backward finishes LAST (feature_fc, attention, init_h: the end of the attention / feature_fc chain) sits
+        # right behind the hypernet's small layers, whose VJP ends at about the same time: ONE all-reduce covers both
+        back = ["fc.weight", "fc.bias", "embed.weight"]
+        self._dec_names = [n for n in d0.names() if n not in self._cell_names and n not in back] + back
         self._vcache = {}
         self._versions = {}
         self._invalidate_caches()
@@ -150,11 +152,15 @@ class FusedTrainer:
             o = _up4(o + prm.numel())
         self.n_dense = o
         self.offs = offs
-        # all-reduce buckets (float ranges of the arena), in the order the backward completes them
+        # all-reduce buckets (float ranges of the arena): vocabulary projection and embedding table as soon as the backward has
+        # them, then ONE bucket for everything that is complete only when the backward ends -- the hypernet's small layers and
+        # second-layer biases (= d theta), feature_fc, attention, init_h and the domain front-end
+        s_fc = offs["captioner.fc.weight"][0]
         e_fc = offs["captioner.embed.weight"][0]
         e_emb = _up4(e_fc + offs["captioner.embed.weight"][1])
-        self._buckets = {"hyper": (0, self._hyper_small_end), "fc": (self._hyper_small_end, e_fc),
-                         "embed": (e_fc, e_emb), "rest": (e_emb, o)}
+        fe_lo = min([offs[n][0] for n in fe], default=o)
+        assert e_emb == fe_lo or not fe
+        self._buckets = {"tail": (0, s_fc), "fc": (s_fc, e_fc), "embed": (e_fc, e_emb), "frontend": (e_emb, o)}
         dev = self.dev
         self.flat_p = torch.zeros(o, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(o, dtype=torch.float32, device=dev)
@@ -486,35 +492,55 @@ class FusedTrainer:
         backward reaches them; RCCL runs them on its own stream beside the attention / feature_fc chain and the hypernet's
         576 MB transposed GEMV.  Nothing is allocated or packed per step: dtheta is gathered straight out of the gradient
         arena, the activation factors out of the acts buffer, into two preallocated [R, .] buffers.
-          after dL/dtheta          all-gather of the rank-1 row factors (dtheta) and column factors (acts)
+          after dL/dtheta          all-gather of the rank-1 row factors (a SNAPSHOT of dtheta: the arena range itself is
+                                   all-reduced later) and of the column factors (acts)
           after the vocab wgrad    all-reduce of fc.weight / fc.bias                       (7.8 MB)
-          after the hypernet VJP   all-reduce of [second-layer biases | hn_base | first layers]  (1.9 MB)
           after the scatter-add    all-reduce of embed.weight (+ the style row's VJP, Flickr path)   (7.7 MB)
-          after the whole call     all-reduce of the rest (feature_fc, attention, init_h)  (2 MB)"""
+          after the whole call     ONE all-reduce of [second-layer biases | hn_base | first layers | feature_fc, attention,
+                                   init_h] (3.9 MB; + the domain front-end when there is one): these are what the two chains
+                                   behind BPTT finish last, within ~20 us of each other -- no collective is issued after that"""
         R = dp.world(self.group)
         g, th = self.flat_g, self.theta_size
         if self._gfac_all is None or self._gfac_all.shape[0] != R:
             self._gfac_all = torch.empty(R, th, dtype=torch.float32, device=self.dev)
             self._acts_all = torch.empty(R, self._acts.numel(), dtype=torch.float32, device=self.dev)
+            self._gfac_snap = torch.empty(th, dtype=torch.float32, device=self.dev)
         main = torch.cuda.current_stream()
         cs = self._comm_stream
         bk = self._buckets
         w = self._works
+        if getattr(self, "time_collectives", False):
+            # measurement mode (bench.py, a few steps OUTSIDE the timed region): every collective is waited for at once between
+            # two events on the communication stream, so each one's own device time is seen; nothing overlaps in this mode
+            class _Timed(list):
+                def append(inner, work):
+                    if work is not None:
+                        work.wait()
+                    e = torch.cuda.Event(enable_timing=True); e.record(cs)
+                    self._xstat.setdefault("marks", []).append(e)
+            w = _Timed()
+            with torch.cuda.stream(cs):
+                cs.wait_stream(main)
+                e = torch.cuda.Event(enable_timing=True); e.record(cs)
+                self._xstat.setdefault("marks", []).append(e)
         with torch.cuda.stream(cs):
             ops.backward_milestone_wait(ops.MS_DTHETA)
-            w.append(dp.all_gather_factors(g[:th], self._gfac_all, self.group, async_op=True)[1])
+            # the all-gather reads a snapshot: dtheta's arena range is part of the "tail" bucket, all-reduced in place below, and a
+            # backend that runs asynchronous works out of issue order (gloo's thread pool) must not see the two overlap
+            ops.stream_copy(g[:th], self._gfac_snap)
+            w.append(dp.all_gather_factors(self._gfac_snap, self._gfac_all, self.group, async_op=True)[1])
             w.append(dp.all_gather_factors(self._acts, self._acts_all, self.group, async_op=True)[1])
             ops.backward_milestone_wait(ops.MS_VOCAB)
             w.append(dp.all_reduce_dense(g[bk["fc"][0]:bk["fc"][1]], self.group, async_op=True))
-            ops.backward_milestone_wait(ops.MS_HYPER)
-            w.append(dp.all_reduce_dense(g[bk["hyper"][0]:bk["hyper"][1]], self.group, async_op=True))
             ops.backward_milestone_wait(ops.MS_EMBED)
             if tok is not None:
                 gx.record_stream(cs)        # allocated on the main stream, consumed here
                 ops.embedding_scatter_add(gx.view(1, -1), tok, self._view(g, "captioner.embed.weight"))
             w.append(dp.all_reduce_dense(g[bk["embed"][0]:bk["embed"][1]], self.group, async_op=True))
             cs.wait_stream(main)
-            w.append(dp.all_reduce_dense(g[bk["rest"][0]:bk["rest"][1]], self.group, async_op=True))
+            w.append(dp.all_reduce_dense(g[bk["tail"][0]:bk["tail"][1]], self.group, async_op=True))
+            if bk["frontend"][1] > bk["frontend"][0]:
+                w.append(dp.all_reduce_dense(g[bk["frontend"][0]:bk["frontend"][1]], self.group, async_op=True))
 
     def _exchange(self):
         """Joins the exchange _issue_exchange started.  Returns (gfac [R,theta], acts_all [R,L])."""
@@ -545,8 +571,15 @@ class FusedTrainer:
         xs = self._xstat
         torch.cuda.synchronize()
         ts = [a.elapsed_time(b) * 1e3 for a, b in xs["timed"]]
+        per = None
+        marks = xs.get("marks")
+        if marks:
+            names = ["all_gather d theta", "all_gather acts", "all_reduce fc", "all_reduce embed", "all_reduce tail", "all_reduce frontend"]
+            nper = 6 if self._buckets["frontend"][1] > self._buckets["frontend"][0] else 5
+            steps = [marks[i:i + nper + 1] for i in range(0, len(marks) - nper, nper + 1)]
+            per = {names[j]: float(sum(st[j].elapsed_time(st[j + 1]) for st in steps) / len(steps) * 1e3) for j in range(nper)}
         return {"backend": dist.get_backend(self.group), "world": dp.world(self.group),
-                "per_step": xs["collectives"] / max(1, xs["steps"]),
+                "per_step": xs["collectives"] / max(1, xs["steps"]), "per_collective_us_serialised": per,
                 "exposed_us": (sum(ts) / len(ts)) if ts else None, "exposed_us_max": max(ts) if ts else None,
                 "steps_observed": xs["steps"], "steps_timed": len(ts)}
 

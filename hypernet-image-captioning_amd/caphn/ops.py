@@ -390,6 +390,18 @@ def _dec_struct(cls, dims: DecDims, t: Dict[str, torch.Tensor]):
     return s
 
 
+def stream_copy(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst = src (contiguous fp32, same size) on libcaphn's streaming copy kernel; small tails go through the 4-element path."""
+    lib = L.load()
+    n = src.numel()
+    assert dst.numel() == n
+    if n % 4 == 0 and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0:
+        L.check(lib.caphn_stream_copy_f32(n, L.ptr(src), L.ptr(dst), L.stream_ptr()), "caphn_stream_copy_f32")
+    else:
+        dst.copy_(src)
+    return dst
+
+
 def device_error(clear: bool = False) -> int:
     """The current device's sticky failure word (include/caphn.h caphn_device_error): 0 or CAPHN_ETIMEOUT (-4).  Kernels write it
     asynchronously: synchronise first if the question is about work already enqueued."""

@@ -704,11 +704,13 @@ int launch_one(const GemmArgs& g, hipStream_t s) {
     constexpr size_t lds_tiles = sizeof(__bf16) * (TileA::ELEMS + TileB::ELEMS) * (PL == 3 ? 2 : 1);
     size_t lds = lds_tiles;
     if (g.kmap_lds > 0) lds += sizeof(int) * (size_t)g.kmap_lds;
-    static bool attr_set = false;          // one flag per instantiation; one host thread drives one device
-    if (lds_tiles + 16384 > 48 * 1024 && !attr_set) {
+    static bool attr_set[64];              // one flag per instantiation AND device (the attribute is per device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CAPHN_ELAUNCH;
+    if (lds_tiles + 16384 > 48 * 1024 && !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<BM, BN, TA, TB, PL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_tiles + 16384)) != hipSuccess) return CAPHN_ELAUNCH;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk > 1 ? g.splitk : 1);
     hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, PL>), grid, dim3(256), lds, s, g);

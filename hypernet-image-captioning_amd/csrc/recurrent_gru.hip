@@ -621,14 +621,16 @@ __global__ void mean_p_kernel(int P, int F, const float* __restrict__ f, float* 
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
-bool g_attr_set = false;
+bool g_attr_set[64];              // per device: the 160 KB dynamic-LDS opt-in is a per-device function attribute
 int ensure_lds_attr() {
-    if (g_attr_set) return CAPHN_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CAPHN_ELAUNCH;
+    if (g_attr_set[dev]) return CAPHN_OK;
     const void* fns[4] = {reinterpret_cast<const void*>(rec_attn_fwd_kernel<false>), reinterpret_cast<const void*>(rec_attn_fwd_kernel<true>),
                           reinterpret_cast<const void*>(rec_attn_bwd_kernel<false>), reinterpret_cast<const void*>(rec_attn_bwd_kernel<true>)};
     for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess) return CAPHN_ELAUNCH;
-    g_attr_set = true;
+    g_attr_set[dev] = true;
     return CAPHN_OK;
 }
 

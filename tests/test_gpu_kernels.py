@@ -62,7 +62,7 @@ def test_gemm_large_tile_config(ops, gemm_backend, K):
     bias = torch.randn(4000, generator=g)
     out = ops.gemm(A.to(DEV), B.to(DEV), False, True, bias=bias.to(DEV))
     ref = (A.to(DEV).double() @ B.to(DEV).double().t() + bias.to(DEV).double())
-    assert float((out.double() - ref).abs().max()) < 2e-6 * math.sqrt(K) * 4
+    assert float((out.double() - ref).abs().max()) < 1e-6 * math.sqrt(K) * 4
 
 
 def test_gemm_split_bf16_is_fp32_accurate(ops):
@@ -116,15 +116,15 @@ def test_hyper_forward_backward_tiny(ops, name):
     shape = hyper_shape(dims)
     hp = hyper_params_from_oracle(p, DEV)
     theta, acts = ops.hyper_forward(shape, hp, xs.to(DEV))
-    assert maxdiff(theta.cpu(), g["theta"]) < 2e-6
+    assert maxdiff(theta.cpu(), g["theta"]) < 1e-6
     grads = {n: torch.empty(s, device=DEV) for n, s in shape.param_shapes().items()}
     gx = ops.hyper_backward(shape, hp, g["dtheta"].to(DEV), acts, grads, want_x=True)
     for n in grads:
-        assert maxdiff(grads[n].cpu(), g["gint/" + n]) < 2e-6, n
+        assert maxdiff(grads[n].cpu(), g["gint/" + n]) < 1e-6, n
     # dx against autograd on the oracle
     xr = xs.clone().reshape(-1).requires_grad_(True)
     O.hyper_forward(p, xr).backward(g["dtheta"])
-    assert maxdiff(gx.cpu(), xr.grad) < 2e-6
+    assert maxdiff(gx.cpu(), xr.grad) < 1e-6
 
 
 def test_hyper_forward_backward_canonical_shape(ops):
@@ -161,23 +161,23 @@ def test_decoder_forward_backward_tiny(ops, name):
     ws = ops.decoder_workspace(dd, DEV)
     feats, caps = g["features"].to(DEV), g["captions"].to(DEV)
     logits, alphas = ops.decoder_forward(dd, params, feats, caps, ws)
-    assert maxdiff(logits.cpu(), g["logits"]) < 2e-6
+    assert maxdiff(logits.cpu(), g["logits"]) < 1e-6
     assert maxdiff(alphas.cpu(), g["alphas"]) < 1e-6
     lo, dlogits = ops.cross_entropy_fwd_bwd(logits, caps, 0)
-    assert abs(float(lo[0]) - float(g["loss"])) < 2e-6
+    assert abs(float(lo[0]) - float(g["loss"])) < 1e-6
     grads = {n: torch.full(s, float("nan"), device=DEV) for n, s in dd.param_shapes().items()}
     ops.decoder_backward(dd, params, feats, caps, dlogits, grads, ws)
     for n, gt in grads.items():
         if n.startswith("gru."):
             continue
-        assert maxdiff(gt.cpu(), g["glit/captioner." + n]) < 2e-6, n
+        assert maxdiff(gt.cpu(), g["glit/captioner." + n]) < 1e-6, n
     dth = torch.cat([grads["gru." + n].flatten() for n, _ in dims.cell_param_shapes()])
-    assert maxdiff(dth.cpu(), g["dtheta"]) < 2e-6
+    assert maxdiff(dth.cpu(), g["dtheta"]) < 1e-6
     # quirk: caps[:,0] / caps[:,T-1] do not influence logits
     l2, _ = ops.decoder_forward(dd, params, feats, g["captions_q0"].to(DEV), ws)
     assert torch.equal(l2, logits)
     l3, _ = ops.decoder_forward(dd, params, feats, g["captions_q1"].to(DEV), ws)
-    assert maxdiff(l3.cpu(), g["logits_q1"]) < 2e-6
+    assert maxdiff(l3.cpu(), g["logits_q1"]) < 1e-6
 
 
 @pytest.mark.parametrize("name", ["gru_tiny_flickr", "gru_tiny_cc", "gru_odd_cc", "lstm_tiny"])
@@ -195,14 +195,14 @@ def test_decoder_free_running_and_scheduled_sampling(ops, name):
     ws = ops.decoder_workspace(dd, DEV)
     feats, caps = g["features"].to(DEV), g["captions"].to(DEV)
     lf, af = ops.decoder_forward_sampled(dd, params, feats, caps, [True] * T, ws)
-    assert maxdiff(lf.cpu(), g["logits_free"]) < 2e-6 and maxdiff(af.cpu(), g["alphas_free"]) < 1e-6
+    assert maxdiff(lf.cpu(), g["logits_free"]) < 1e-6 and maxdiff(af.cpu(), g["alphas_free"]) < 1e-6
     assert torch.equal(lf.argmax(-1).cpu(), g["tokens_free"])
     pattern = [bool(v) for v in g["mixed_pattern"]]
     lm, am = ops.decoder_forward_sampled(dd, params, feats, caps, pattern, ws)
-    assert maxdiff(lm.cpu(), g["logits_mixed"]) < 2e-6 and maxdiff(am.cpu(), g["alphas_mixed"]) < 1e-6
+    assert maxdiff(lm.cpu(), g["logits_mixed"]) < 1e-6 and maxdiff(am.cpu(), g["alphas_mixed"]) < 1e-6
     # all-False flags == teacher forcing
     l0, _ = ops.decoder_forward_sampled(dd, params, feats, caps, [False] * T, ws)
-    assert maxdiff(l0.cpu(), g["logits"]) < 2e-6
+    assert maxdiff(l0.cpu(), g["logits"]) < 1e-6
 
 
 @pytest.mark.parametrize("name", ["gru_tiny_cc", "gru_odd_cc"])
@@ -243,7 +243,7 @@ def test_decoder_row_subset_equals_full(ops, name):
                                           style_token=int(g["style_token"]) if int(g["style_token"]) >= 0 else None)
     for n in out["rows"][2]:
         if not n.startswith("gru."):
-            assert maxdiff(out["rows"][2][n].cpu(), gref["captioner." + n]) < 2e-6, n
+            assert maxdiff(out["rows"][2][n].cpu(), gref["captioner." + n]) < 1e-6, n
 
 
 def test_decoder_lstm_raw_features_tiny(ops):
@@ -259,18 +259,18 @@ def test_decoder_lstm_raw_features_tiny(ops):
     ws = ops.decoder_workspace(dd, DEV)
     feats, caps = g["features"].to(DEV), g["captions"].to(DEV)
     logits, alphas = ops.decoder_forward(dd, params, feats, caps, ws)
-    assert maxdiff(logits.cpu(), g["logits"]) < 2e-6
+    assert maxdiff(logits.cpu(), g["logits"]) < 1e-6
     assert maxdiff(alphas.cpu(), g["alphas"]) < 1e-6
     lo, dlogits = ops.cross_entropy_fwd_bwd(logits, caps, 0)
-    assert abs(float(lo[0]) - float(g["loss"])) < 2e-6
+    assert abs(float(lo[0]) - float(g["loss"])) < 1e-6
     grads = {n: torch.full(s, float("nan"), device=DEV) for n, s in dd.param_shapes().items()}
     ops.decoder_backward(dd, params, feats, caps, dlogits, grads, ws)
     for n, gt in grads.items():
         if n.startswith("lstm."):
             continue
-        assert maxdiff(gt.cpu(), g["glit/captioner." + n]) < 2e-6, n
+        assert maxdiff(gt.cpu(), g["glit/captioner." + n]) < 1e-6, n
     dth = torch.cat([grads["lstm." + n].flatten() for n, _ in dims.cell_param_shapes()])
-    assert maxdiff(dth.cpu(), g["dtheta"]) < 2e-6
+    assert maxdiff(dth.cpu(), g["dtheta"]) < 1e-6
 
 
 @pytest.mark.parametrize("H,P", [(12, 6), (200, 49)])
@@ -310,7 +310,7 @@ def test_cross_entropy_matches_torch(ops):
     ref = torch.nn.functional.cross_entropy(lr, tgt, ignore_index=0)
     ref.backward()
     out, dl = ops.cross_entropy_fwd_bwd(logits.to(DEV), tgt.to(DEV), 0)
-    assert abs(float(out[0]) - float(ref)) < 2e-6
+    assert abs(float(out[0]) - float(ref)) < 1e-6
     assert int(out[1]) == int((tgt != 0).sum())
     assert maxdiff(dl.cpu(), lr.grad) < 1e-7      # values ~1e-2: fp32 rounding
     # in place
@@ -368,7 +368,7 @@ def test_adam_rank_equals_dense(ops, R, rows, k):
     for step in (1, 2):
         O.adam_step(W, (dense * 0.37).float(), m, v, step, 1e-3)
         ops.adam_rank(Wd, md, vd, gf.to(DEV), af.to(DEV), coef, 1e-3, step)
-    assert maxdiff(Wd.cpu(), W) < 2e-6
+    assert maxdiff(Wd.cpu(), W) < 1e-6
     assert maxdiff(ops.outer(gf[0].to(DEV), af[0].to(DEV)).cpu(), torch.outer(gf[0], af[0])) < 1e-7
 
 
@@ -387,7 +387,7 @@ def test_adam_rank_eight_ranks_matches_dense(ops):
     assert maxdiff(m.cpu(), 0.1 * grad) < 1e-7                          # m after one step = (1 - beta1) * grad
     assert maxdiff(v.cpu(), 0.001 * grad * grad) < 1e-9
     ref = W.double().cpu() - 1e-3 * grad / (grad.abs() + 1e-8)           # first Adam step: lr * g / (|g| + eps)
-    assert maxdiff(Wc.cpu(), ref) < 2e-6
+    assert maxdiff(Wc.cpu(), ref) < 1e-6
 
 
 @pytest.mark.parametrize("R,rows,k,fused", [(1, 77, 1031, True), (1, 50, 2050, False), (3, 41, 2501, True), (1, 9, 8437, True)])
@@ -408,7 +408,7 @@ def test_adam_rank_long_odd_rows(ops, R, rows, k, fused):
         O.adam_step(W, dense, m, v, step, 1e-3)
         kw = dict(next_a=na.to(DEV), next_bias=nb.to(DEV), next_theta=th) if fused else {}
         ops.adam_rank(Wd, md, vd, gfac.to(DEV), a.to(DEV), coef, 1e-3, step, **kw)
-    assert maxdiff(Wd.cpu(), W) < 2e-6 and maxdiff(md.cpu(), m) < 1e-7 and maxdiff(vd.cpu(), v) < 1e-9
+    assert maxdiff(Wd.cpu(), W) < 1e-6 and maxdiff(md.cpu(), m) < 1e-7 and maxdiff(vd.cpu(), v) < 1e-9
     if fused:
         assert maxdiff(th.cpu(), (Wd.cpu().double() @ na.double() + nb.double()).float()) < 2e-5 * (k / 1000) ** 0.5 + 1e-5
 
@@ -491,7 +491,7 @@ def test_gemm_on_presplit_operands_equals_split_on_use(ta, tb, M, N, K):
     base = cops.gemm(A, B, ta, tb, bias=bias)
     scale = float(ref.abs().max())
     assert float((got.double() - ref).abs().max()) < 3e-6 * scale
-    assert float((got - base).abs().max()) < 2e-6 * scale
+    assert float((got - base).abs().max()) < 1e-6 * scale
     if ta:                                   # split-K with atomics into a zeroed C
         got2 = cops.gemm_planes(pa, pb, ta, tb, splitk=4, kp=kp if K % 8 else 0)
         assert float((got2.double() - (ref - bias.double())).abs().max()) < 3e-6 * scale
