@@ -275,10 +275,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cell", choices=["gru", "lstm"], default="gru",
                     help="gru: the metric's workload; lstm: BASELINE config 3 (hypernet-generated LSTMCell, side measurement)")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x2"], default="f32",
                     help="f32: the metric's arithmetic (the reference trains with precision=32).  bf16: SIDE measurement, never the "
                          "headline -- every dense contraction as one bf16 MFMA product on operands rounded to bf16, fp32 accumulate; "
-                         "recurrent kernels, softmax, loss, Adam and master weights stay fp32 (caphn_tune key 11)")
+                         "recurrent kernels, softmax, loss, Adam and master weights stay fp32 (caphn_tune key 11).  bf16x2: SIDE measurement too -- "
+                         "operands as two bf16 planes (16 significand bits), three products: logits within 1e-4 of the fp32 vectors")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not tell the optimiser pass the next minibatch's style (disables the fused next-theta GEMV)")
@@ -342,8 +343,8 @@ def main():
     for kv in args.tune:
         k, v = kv.split("=")
         assert _lib.load().caphn_tune(int(k), int(v)) == 0
-    if args.dtype == "bf16":
-        assert _lib.load().caphn_tune(11, 1) == 0
+    if args.dtype != "f32":
+        assert _lib.load().caphn_tune(11, {"bf16": 1, "bf16x2": 2}[args.dtype]) == 0
 
     B, T, P, D, F, E, H, V = args.batch, 20, 49, 2048, 200, 200, 200, 9684
     torch.manual_seed(1234)                       # identical replicas on every rank
@@ -546,7 +547,8 @@ def main():
             "data": "synthetic" + (" (each minibatch copied from pinned host memory inside the timed region)" if args.from_host else ""),
             "config": {"workload": f"Flickr30k-shaped {args.cell.upper()}+additive-attention decoder + hypernet (3 style domains), "
                                    "full training step (fwd, CE, bwd, clip 5.0, Adam)" +
-                                   (" -- SIDE MEASUREMENT: single-product bf16 contractions, not the metric's fp32 arithmetic" if args.dtype == "bf16" else ""),
+                                   (" -- SIDE MEASUREMENT: single-product bf16 contractions, not the metric's fp32 arithmetic" if args.dtype == "bf16" else
+                                    " -- SIDE MEASUREMENT: two-plane bf16 contractions (3 products), not the metric's fp32 arithmetic" if args.dtype == "bf16x2" else ""),
                        "per_gpu_batch": B, "global_batch": B * world, "T": T, "P": P, "D": D, "F": F, "E": E, "H": H,
                        "V": V, "hypernet_params": int(sum(q.numel() for q in net.hn_base.parameters()) +
                                                       sum(q.numel() for q in net.hn_heads.parameters())),

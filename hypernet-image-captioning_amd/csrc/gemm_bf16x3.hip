@@ -170,6 +170,26 @@ struct TileS {
             *reinterpret_cast<bf16x4*>(p) = v;
         }
     }
+    // two-plane side mode (MODE 4): hi by truncation (exact), mid = the remainder ROUNDED to bf16 -- hi + mid carries 16 significand
+    // bits, the best two-plane representation; the lo plane is not written
+    __device__ static __forceinline__ void store2(const f32x4 (&r)[NV], __bf16* __restrict__ S, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            union { f32x4 f; unsigned u[4]; } x, h;
+            x.f = r[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h.u[e] = x.u[e] & 0xffff0000u;
+            const f32x4 rem = x.f - h.f;
+            union { unsigned u[2]; bf16x4 b; } hi;
+            hi.u[0] = pack_hi16(x.u[0], x.u[1]); hi.u[1] = pack_hi16(x.u[2], x.u[3]);
+            const bf16x4 mid = {(__bf16)rem[0], (__bf16)rem[1], (__bf16)rem[2], (__bf16)rem[3]};
+            __bf16* p = KC ? S + kc_off(idx >> 3, (idx & 7) * 4)
+                           : S + (idx / (BMN / 4)) * PITCHM + (idx % (BMN / 4)) * 4;
+            *reinterpret_cast<bf16x4*>(p) = hi.b;
+            *reinterpret_cast<bf16x4*>(p + PLANE) = mid;
+        }
+    }
     __device__ static __forceinline__ void store(const f32x4 (&r)[NV], __bf16* __restrict__ S, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -269,6 +289,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     constexpr bool PL = MODE == 1;
     constexpr bool SINGLE = MODE == 2;
     constexpr bool DB = MODE == 3;          // MODE 0 with TWO LDS images of a slab (ping-pong): see mainloop_db
+    constexpr bool TWO = MODE == 4;         // two planes (hi + mid, 16 significand bits), three products: the bf16x2 side mode
     using TileA = TileS<BM, !TA>;
     using TileB = TileS<BN, TB>;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -370,7 +391,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (ks < nks) {
-                constexpr int NPL = SINGLE ? 1 : 3;
+                constexpr int NPL = SINGLE ? 1 : TWO ? 2 : 3;
                 bf16x8 fa[TM][3], fb[TN][3];
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
@@ -386,6 +407,17 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
                         for (int b = 0; b < TN; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+                } else if constexpr (TWO) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            f32x16 c = acc[a][b];            // small terms first; dropped: mid.mid and everything with lo (<= 2^-16 relative)
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], c, 0, 0, 0);   // mid . hi
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], c, 0, 0, 0);   // hi  . mid
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], c, 0, 0, 0);   // hi  . hi
+                            acc[a][b] = c;
+                        }
                 } else
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
@@ -433,6 +465,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             }
         }
         if constexpr (SINGLE) { TileA::store_single(ra, As, tid); TileB::store_single(rb, Bs, tid); }
+        else if constexpr (TWO) { TileA::store2(ra, As, tid); TileB::store2(rb, Bs, tid); }
         else { TileA::store(ra, As, tid); TileB::store(rb, Bs, tid); }
     };
     auto mainloop = [&](auto fc) {
@@ -729,7 +762,8 @@ int launch_cfg(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 
 extern int g_tune_gemm_planes;
 int g_tune_gemm_tile = 0;     // 0: automatic tile choice; 64 / 128: forced (experiments)
-int g_tune_gemm_single = 0;   // 1: reduced-precision side mode -- one bf16 product per contraction instead of six (caphn_tune key 11)
+int g_tune_gemm_single = 0;   // reduced-precision side modes (caphn_tune key 11): 1 one bf16 product per contraction instead of six; 2 "bf16x2" -- operands
+                              // as two bf16 planes (16 significand bits), three products: ~2e-5 relative, inside the north star's 1e-4 on logits
 int g_tune_gemm_order = 1;    // tile walk inside an XCD: 0 n fastest always, 1 (default) m fastest when B outgrows L2 and A is the smaller, 2 m fastest always
 int g_tune_gemm_xcd = 1;      // 1 (default): XCD-aware tile order
 int g_tune_gemm_db = 0;       // layouts that run the 64x64 tile with ping-pong LDS images (MODE 3): bit 0 NT, bit 1 NN, bit 2 TN
@@ -796,9 +830,13 @@ int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
         if (tiles128 >= 512) return launch_cfg<128, 128, 1>(g, ta, tb, s);
         return launch_cfg<64, 64, 1>(g, ta, tb, s);
     }
-    if (g_tune_gemm_single && !(ta && tb)) {
+    if (g_tune_gemm_single == 1 && !(ta && tb)) {
         if (tiles128 >= 512) return launch_cfg<128, 128, 2>(g, ta, tb, s);
         return launch_cfg<64, 64, 2>(g, ta, tb, s);
+    }
+    if (g_tune_gemm_single == 2 && !(ta && tb)) {       // bf16x2: two planes, three products
+        if (tiles128 >= 512) return launch_cfg<128, 128, 4>(g, ta, tb, s);
+        return launch_cfg<64, 64, 4>(g, ta, tb, s);
     }
     if (tiles128 >= 512) return launch_cfg<128, 128, 0>(g, ta, tb, s);
     // ping-pong LDS images for the 64x64 tile (caphn_tune key 23: bit 0 NT, bit 1 NN, bit 2 TN layouts)

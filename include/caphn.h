@@ -531,7 +531,8 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * GEMM tile order, key 7: branch-free GEMM loads, key 8: pre-split GEMM operands -- 0 off (every tile split on use), 1 on, key 9: recurrent kernels with two workgroups
  * per caption -- 0 off, 1 on, key 10: timing experiments only, key 11: REDUCED-PRECISION side mode -- 1 = every dense
  * contraction as ONE bf16 product (operands rounded to bf16 at staging, fp32 accumulate; recurrent kernels, softmax, loss,
- * Adam and the master weights stay fp32), 0 = the fp32-class six-product default, key 12: forced GEMM tile (experiments), key 13: DETERMINISTIC gradients -- value V > 0 (the
+ * Adam and the master weights stay fp32), 2 = "bf16x2": operands as TWO bf16 planes (hi + mid = 16 significand bits), three products
+ * (logits within 1e-4 of the fp32 path at the canonical size), 0 = the fp32-class six-product default, key 12: forced GEMM tile (experiments), key 13: DETERMINISTIC gradients -- value V > 0 (the
  * vocabulary size) turns split-K off in the decoder composites (its partial products are summed with fp32 atomics) and computes
  * the embedding gradient by a destination-major scan of the V table rows instead of atomic scatter-adds: gradients are then
  * bit-identical from run to run, at a cost in speed; 0 = off), key 14: workgroup cap of one rank-1 Adam launch (64..65535, default
@@ -544,6 +545,10 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * B outgrows the L2 and A is the smaller operand, 2 m fastest always); key 20: bit mask of the composites' side branches in
  * use (default 7 = all three; a cleared branch runs on the caller's stream -- every smaller set measured 10-70 us slower); key 21:
  * with the vocabulary weight gradient beside BPTT (key 4 = 2), 1 (default) starts it after the dHs GEMM, 0 beside it.
+ * key 16 also takes 2 (default): the pair FORWARD kernel keeps ALL of a half's [U_a; W_hh] on chip when it fits; key 22: hand-off time
+ * bound of the pair kernels in microseconds (default 1 000 000); key 23: bit mask of GEMM layouts (1 NT, 2 NN, 4 TN) that run the
+ * 64x64 tile with ping-pong LDS images (default 0: measured slower or equal on every shape of the step); key 24: bit 0 switches
+ * the same-XCD hand-off form of the pair kernels off (A/B).
  * Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
