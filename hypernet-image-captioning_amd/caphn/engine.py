@@ -492,8 +492,8 @@ class FusedTrainer:
         backward reaches them; RCCL runs them on its own stream beside the attention / feature_fc chain and the hypernet's
         576 MB transposed GEMV.  Nothing is allocated or packed per step: dtheta is gathered straight out of the gradient
         arena, the activation factors out of the acts buffer, into two preallocated [R, .] buffers.
-          after dL/dtheta          all-gather of the rank-1 row factors (a SNAPSHOT of dtheta: the arena range itself is
-                                   all-reduced later) and of the column factors (acts)
+          after dL/dtheta          ONE all-gather of the packed rank-1 factors [d theta | acts] (a SNAPSHOT of dtheta: the arena
+                                   range itself is all-reduced later)
           after the vocab wgrad    all-reduce of fc.weight / fc.bias                       (7.8 MB)
           after the scatter-add    all-reduce of embed.weight (+ the style row's VJP, Flickr path)   (7.7 MB)
           after the whole call     ONE all-reduce of [second-layer biases | hn_base | first layers | feature_fc, attention,
@@ -502,9 +502,14 @@ class FusedTrainer:
         R = dp.world(self.group)
         g, th = self.flat_g, self.theta_size
         if self._gfac_all is None or self._gfac_all.shape[0] != R:
-            self._gfac_all = torch.empty(R, th, dtype=torch.float32, device=self.dev)
-            self._acts_all = torch.empty(R, self._acts.numel(), dtype=torch.float32, device=self.dev)
-            self._gfac_snap = torch.empty(th, dtype=torch.float32, device=self.dev)
+            # ONE packed factor buffer per rank: [d theta (theta_size, padded to 4) | acts]; the gathered [R, .] buffer is viewed as
+            # the row factors and the column factors (row pitch = the packed length: the rank-R kernels take leading dimensions)
+            L = self._acts.numel()
+            tp = _up4(th)
+            self._fac_snap = torch.zeros(_up4(tp + L), dtype=torch.float32, device=self.dev)
+            self._fac_all = torch.empty(R, _up4(tp + L), dtype=torch.float32, device=self.dev)
+            self._gfac_all = self._fac_all[:, :th]
+            self._acts_all = self._fac_all[:, tp:tp + L]
         main = torch.cuda.current_stream()
         cs = self._comm_stream
         bk = self._buckets
@@ -527,9 +532,9 @@ class FusedTrainer:
             ops.backward_milestone_wait(ops.MS_DTHETA)
             # the all-gather reads a snapshot: dtheta's arena range is part of the "tail" bucket, all-reduced in place below, and a
             # backend that runs asynchronous works out of issue order (gloo's thread pool) must not see the two overlap
-            ops.stream_copy(g[:th], self._gfac_snap)
-            w.append(dp.all_gather_factors(self._gfac_snap, self._gfac_all, self.group, async_op=True)[1])
-            w.append(dp.all_gather_factors(self._acts, self._acts_all, self.group, async_op=True)[1])
+            ops.stream_copy(g[:th], self._fac_snap[:th])
+            ops.stream_copy(self._acts, self._fac_snap[_up4(th):_up4(th) + self._acts.numel()])
+            w.append(dp.all_gather_factors(self._fac_snap, self._fac_all, self.group, async_op=True)[1])
             ops.backward_milestone_wait(ops.MS_VOCAB)
             w.append(dp.all_reduce_dense(g[bk["fc"][0]:bk["fc"][1]], self.group, async_op=True))
             ops.backward_milestone_wait(ops.MS_EMBED)
@@ -574,8 +579,8 @@ class FusedTrainer:
         per = None
         marks = xs.get("marks")
         if marks:
-            names = ["all_gather d theta", "all_gather acts", "all_reduce fc", "all_reduce embed", "all_reduce tail", "all_reduce frontend"]
-            nper = 6 if self._buckets["frontend"][1] > self._buckets["frontend"][0] else 5
+            names = ["all_gather factors", "all_reduce fc", "all_reduce embed", "all_reduce tail", "all_reduce frontend"]
+            nper = 5 if self._buckets["frontend"][1] > self._buckets["frontend"][0] else 4
             steps = [marks[i:i + nper + 1] for i in range(0, len(marks) - nper, nper + 1)]
             per = {names[j]: float(sum(st[j].elapsed_time(st[j + 1]) for st in steps) / len(steps) * 1e3) for j in range(nper)}
         return {"backend": dist.get_backend(self.group), "world": dp.world(self.group),
