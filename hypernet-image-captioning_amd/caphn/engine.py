@@ -56,8 +56,9 @@ class FusedTrainer:
         if dev.type != "cuda":
             raise CaphnError("FusedTrainer needs the model on a CUDA(HIP) device")
         self.dev = dev
-        if getattr(self.cap, "layers", None):
-            raise NotImplementedError("fused step supports num_layers=1")
+        # AttentionGru(num_layers > 1) (models/decoderlstm.py:34-36, :101-103; train_gru.py's default is 2): the extra cells'
+        # parameters are ordinary trainable tensors -- they join the arena, the clip norm and the dense Adam pass; the composites
+        # run the time loop in per-step windows for them (csrc/decoder_layers.hip)
         d0 = self.cap.dec_dims(1, 1, 1)
         self._cell_names = d0.cell_names()
         # arena order of the decoder's parameters = the order their gradients are finished by the backward, so that
@@ -778,7 +779,8 @@ class FusedTrainer:
                "attention.U_a.bias", "attention.v_a.weight", "attention.v_a.bias", "init_h.weight", "init_h.bias",
                "init_c.weight", "init_c.bias"]
         names += ["captioner." + n for n in dec if n in self._dec_names]
-        return names
+        names += ["captioner." + n for n in self._dec_names if n.startswith("layers.")]      # (not in the reference's HyperNet list:
+        return names                                                                          #  its captioner has one layer)
 
     def _moments(self, name):
         if name.startswith("hn_heads.") and name.endswith(".2.weight"):

@@ -147,12 +147,16 @@ class FusedPlainTrainer:
 
     # ------------------------------------------------------------------ one step
     def step(self, imgs, captions, style_token: int, h0: Optional[torch.Tensor] = None, c0: Optional[torch.Tensor] = None,
-             next_style_token: Optional[int] = None):
+             next_style_token: Optional[int] = None, teacher_forcing: bool = True, seed: Optional[int] = None):
         """imgs: [B, 2048] pooled ResNet features (through image_encoder.fc) or ready [B, E] embeddings; captions
         [B, T] int64; style_token: vocab id of the style word (x = captioner.embed.weight[token], hypernet.py:128-131).
         h0 / c0: initial states; default as the module draws them (DecoderGRU: torch.rand on the CPU generator).
         next_style_token: the next minibatch's style when the loader is one batch ahead -- the optimiser pass then
-        emits that step's theta.  Returns the device tensor [loss, n_targets] (reused by the next call)."""
+        emits that step's theta.  teacher_forcing=False: hypernet.py:135-140's other branch (later.py:418-431) -- from step 1 on
+        the cell is fed a word drawn from the previous step's softmax (caphn_plain_forward_sampled: counter-based draws from
+        `seed`, default a fresh one per step; the ids are kept in self.last_chosen [B, T], -1 at step 0); the loss is still
+        taken against the caption and nothing flows through the draw.  Returns the device tensor [loss, n_targets] (reused by
+        the next call)."""
         cap, dev = self.cap, self.dev
         B, T = captions.shape
         buf = self._buffers(B, T)
@@ -179,7 +183,15 @@ class FusedPlainTrainer:
                              bias=self._view(self.flat_p, "image_encoder.fc.bias"), out=buf["feats"])
         else:
             feats = imgs
-        logits = ops.plain_forward(dims, params, feats, captions, h0, c0, buf["ws"], check_ids=False, logits=buf["logits"])
+        if teacher_forcing:
+            logits = ops.plain_forward(dims, params, feats, captions, h0, c0, buf["ws"], check_ids=False, logits=buf["logits"])
+            self.last_chosen = None
+        else:
+            if seed is None:
+                from .functional import next_seed
+                seed = next_seed()
+            # (the workspace keeps the drawn ids: caphn_plain_backward scatters d x_t into THEIR embedding rows)
+            logits, self.last_chosen = ops.plain_forward_sampled(dims, params, feats, h0, c0, buf["ws"], seed)
         loss, dlogits = ops.cross_entropy_fwd_bwd(logits, captions, ignore_index=-100, dlogits=logits)
         # ---- decoder backward: the first cell's gradients land in dtheta directly, the extra layers' (views of the
         # same range) in scratch and are then added

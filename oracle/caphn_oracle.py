@@ -523,12 +523,15 @@ PLAIN_OPTIMISED_PREFIXES = ("hn_heads.", "hn_base.", "captioner.embed.", "image_
 
 def plain_train_step(d: PlainDims, p: Dict[str, Tensor], state: Dict[str, Tensor], step: int, imgs: Tensor,
                      captions: Tensor, h0: Tensor, c0: Optional[Tensor] = None, style_token: int = 4,
-                     lr: float = 1e-6) -> Tensor:
+                     lr: float = 1e-6, input_captions: Optional[Tensor] = None) -> Tensor:
     """One optimiser step of hypernet.py: training_step (:126-152, teacher forcing, loss without ignore_index),
     Adam(lr) over hn_heads, hn_base, captioner.embed and image_encoder.fc only (configure_optimizers :116-123 --
     fc_out has no optimiser entry) and no gradient clipping (the Trainer of :218 sets none).  The generated weights
     stay attached ("intended" gradients).  imgs: [B, 2048] pooled features through image_encoder.fc (:47, when
-    p holds it) or ready [B, E] embeddings.  In place on p / state ('m.'+name, 'v.'+name); returns the loss."""
+    p holds it) or ready [B, E] embeddings.  In place on p / state ('m.'+name, 'v.'+name); returns the loss.
+    input_captions: the teacher_forcing=False branch (hypernet.py:135-140, later.py:418-431) GIVEN the words that were drawn --
+    the ids fed to the cell come from input_captions (column t - 1 feeds step t), the loss is still taken against `captions`;
+    nothing flows through the draw, so this is that branch's autograd graph."""
     names = [n for n, _ in plain_param_shapes(d)] + [n for n in ("image_encoder.fc.weight", "image_encoder.fc.bias") if n in p]
     q = {n: p[n].clone().requires_grad_(True) for n in names}
     feats = imgs
@@ -536,7 +539,7 @@ def plain_train_step(d: PlainDims, p: Dict[str, Tensor], state: Dict[str, Tensor
         feats = F_.linear(imgs, q["image_encoder.fc.weight"], q["image_encoder.fc.bias"])
     x = q["captioner.embed.weight"][torch.tensor([style_token])]
     theta = hyper_forward(q, x, n_heads=len(plain_head_layout(d)))
-    logits = plain_decoder_forward(d, q, plain_inject(d, theta), feats, captions, h0, c0)
+    logits = plain_decoder_forward(d, q, plain_inject(d, theta), feats, captions if input_captions is None else input_captions, h0, c0)
     loss = F_.cross_entropy(logits.reshape(-1, d.V), captions.reshape(-1))
     loss.backward()
     for n in names:

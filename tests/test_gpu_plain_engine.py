@@ -79,3 +79,40 @@ def test_needs_cuda_model():
     from hypernet import HyperNet
     with pytest.raises(CaphnError):
         FusedPlainTrainer(HyperNet(8, 6, 20, _Vocab(), num_layers=1, type="gru"))
+
+
+@pytest.mark.parametrize("cell,L", [("gru", 2), ("lstm", 1)])
+def test_sampled_branch_in_the_fused_trainer_given_the_ids_drawn(cell, L):
+    """hypernet.py:135-140: np.random.binomial picks teacher forcing or the sampled branch per step.  FusedPlainTrainer.step(
+    teacher_forcing=False) runs later.py:418-431's branch on libcaphn; the reference's draws (torch.multinomial) cannot be
+    reproduced, so parity is: GIVEN the ids the kernel drew, loss and every parameter after each Adam step equal the oracle's
+    step whose cell inputs are those ids and whose loss is taken against the caption."""
+    from caphn.engine_plain import FusedPlainTrainer
+    d = O.PlainDims(E=12, H=10, V=41, L=L, cell=cell)
+    p = O.init_plain_params(d, seed=11)
+    net = _net(d, {k: v.clone() for k, v in p.items()})
+    tr = FusedPlainTrainer(net, lr=LR)
+    rng = np.random.default_rng(5)
+    B, T = 6, 7
+    state = {}
+    for s, tf in enumerate([False, True, False]):
+        imgs = torch.from_numpy(rng.standard_normal((B, d.E)).astype(np.float32))
+        caps = torch.from_numpy(rng.integers(0, d.V, size=(B, T)))
+        h0 = torch.from_numpy(rng.random((B, d.H), dtype=np.float32))
+        c0 = torch.zeros(B, d.H) if cell == "lstm" else None
+        out = tr.step(imgs.to(DEV), caps.to(DEV), 4, h0.to(DEV), c0.to(DEV) if c0 is not None else None,
+                      teacher_forcing=tf, seed=1000 + s)
+        eff = None
+        if not tf:
+            ids = tr.last_chosen.cpu()
+            assert bool((ids[:, 0] == -1).all()) and bool((ids[:, 1:] >= 0).all())
+            eff = caps.clone()
+            eff[:, :T - 1] = ids[:, 1:]
+        else:
+            assert tr.last_chosen is None
+        ref = O.plain_train_step(d, p, state, s + 1, imgs, caps, h0, c0, style_token=4, lr=LR, input_captions=eff)
+        assert abs(float(out[0]) - float(ref)) < 2e-5, (s, float(out[0]), float(ref))
+    got = dict(net.named_parameters())
+    for n in p:
+        if n.startswith(O.PLAIN_OPTIMISED_PREFIXES):
+            assert maxdiff(got[n].detach().cpu(), p[n]) < 2e-2 * LR + 1e-6, n
