@@ -153,6 +153,7 @@ SIGNATURES = {
     "caphn_cross_entropy_fwd_bwd": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, C.c_int64, c_fp, c_fp, C.c_int, c_fp, c_fp]),
     "caphn_embedding_gather": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
     "caphn_embedding_scatter_add": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
+    "caphn_embedding_scatter_add_v": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
     "caphn_sumsq_blocks": (C.c_int, [C.c_size_t]),
     "caphn_sumsq_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp]),
     "caphn_rank_sumsq_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, C.c_size_t, c_fp, C.c_size_t,

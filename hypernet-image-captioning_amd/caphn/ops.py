@@ -640,8 +640,8 @@ def embedding_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 def embedding_scatter_add(g: torch.Tensor, idx: torch.Tensor, table_grad: torch.Tensor) -> None:
     lib = L.load()
     rows, E = g.shape
-    L.check(lib.caphn_embedding_scatter_add(rows, E, L.ptr(g), L.ptr(idx.reshape(-1), torch.int64),
-                                            L.ptr(table_grad), L.stream_ptr()), "caphn_embedding_scatter_add")
+    L.check(lib.caphn_embedding_scatter_add_v(rows, E, int(table_grad.shape[0]), L.ptr(g), L.ptr(idx.reshape(-1), torch.int64),
+                                              L.ptr(table_grad), L.stream_ptr()), "caphn_embedding_scatter_add_v")
 
 
 # ------------------------------------------------------------------ optimiser

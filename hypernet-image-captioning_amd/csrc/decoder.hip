@@ -716,7 +716,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     hipStream_t se = late ? b2 : b0;
     RUN(caphn_gemm_f32(0, 0, BT, E, GH, dgi, GH, p->w_ih, EF, ws + w.dXe, E, nullptr, nullptr, 0, 0, 1, se));
     if (!gz) RUN(caphn_zero_f32(g->embed_w, (size_t)V * E, se));
-    RUN(caphn_embedding_scatter_add(BT, E, ws + w.dXe, idx, g->embed_w, se));
+    RUN(caphn_embedding_scatter_add_v(BT, E, V, ws + w.dXe, idx, g->embed_w, se));
     RUN(sd.milestone(CAPHN_MS_EMBED, se));
     // dL/dtheta = [dW_ih | dW_hh | db_ih | db_hh] is complete once E3 has fired on top of sT's own work so far: a
     // data-parallel caller starts its all-gather of the rank-1 row factors here (CAPHN_MS_DTHETA)

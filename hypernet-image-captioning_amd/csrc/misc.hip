@@ -920,14 +920,24 @@ int caphn_embedding_gather_strided(int rows, int E, const float* table, const in
 }
 extern int g_tune_deterministic;
 int g_det_vocab = 0;      // rows of the embedding table the deterministic scatter scans (set with the mode: caphn_tune(13, V))
-extern "C" int caphn_embedding_scatter_add(int rows, int E, const float* g, const int64_t* idx, float* table_grad, caphn_stream_t stream) {
-    if (rows <= 0 || E <= 0 || !g || !idx || !table_grad) return CAPHN_EINVAL;
-    if (g_tune_deterministic && g_det_vocab > 0 && rows > 1) {
+// V: rows of THIS table (the deterministic mode scans every one of them; with the table's own row count a process may hold several
+// tables -- the captioner's vocabulary, a front-end's domain table, another model's -- without one global deciding for all)
+extern "C" int caphn_embedding_scatter_add_v(int rows, int E, int V, const float* g, const int64_t* idx, float* table_grad,
+                                             caphn_stream_t stream) {
+    if (rows <= 0 || E <= 0 || V <= 0 || !g || !idx || !table_grad) return CAPHN_EINVAL;
+    if (g_tune_deterministic && rows > 1) {
         // destination-major: one wave per table row scans the indices in order and adds its matches in that order (no atomics)
-        hipLaunchKernelGGL(embed_scatter_det_kernel, dim3((g_det_vocab + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), rows, E,
-                           g_det_vocab, g, idx, table_grad);
+        hipLaunchKernelGGL(embed_scatter_det_kernel, dim3((V + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), rows, E,
+                           V, g, idx, table_grad);
         return caphn_launch_status();
     }
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), rows, E, g, idx, table_grad);
+    return caphn_launch_status();
+}
+// (without a row count: the deterministic mode falls back to the value given with caphn_tune(13, V); prefer the _v form)
+extern "C" int caphn_embedding_scatter_add(int rows, int E, const float* g, const int64_t* idx, float* table_grad, caphn_stream_t stream) {
+    if (rows <= 0 || E <= 0 || !g || !idx || !table_grad) return CAPHN_EINVAL;
+    if (g_tune_deterministic && g_det_vocab > 0 && rows > 1) return caphn_embedding_scatter_add_v(rows, E, g_det_vocab, g, idx, table_grad, stream);
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), rows, E, g, idx, table_grad);
     return caphn_launch_status();
 }

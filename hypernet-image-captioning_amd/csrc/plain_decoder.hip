@@ -387,6 +387,6 @@ extern "C" int caphn_plain_backward(const caphn_plain_dims* d, const caphn_plain
     if (g->features)
         if (hipMemcpyAsync(g->features, ws + w.dX, sizeof(float) * (size_t)B * E, hipMemcpyDeviceToDevice, s) != hipSuccess) return CAPHN_ELAUNCH;
     if (hipMemsetAsync(g->embed_w, 0, sizeof(float) * (size_t)V * E, s) != hipSuccess) return CAPHN_ELAUNCH;
-    RUN(caphn_embedding_scatter_add(TB, E, ws + w.dX, reinterpret_cast<const int64_t*>(ws + w.idx), g->embed_w, s));
+    RUN(caphn_embedding_scatter_add_v(TB, E, d->V, ws + w.dX, reinterpret_cast<const int64_t*>(ws + w.idx), g->embed_w, s));
     return caphn_launch_status();
 }

@@ -448,6 +448,10 @@ int caphn_embedding_gather(int rows, int E, const float* table, const int64_t* i
                            caphn_stream_t stream);
 int caphn_embedding_scatter_add(int rows, int E, const float* g, const int64_t* idx, float* table_grad,
                                 caphn_stream_t stream);
+/* The same with the table's row count V: what the DETERMINISTIC mode (caphn_tune key 13) scans.  The form without V falls back to
+ * the single value given with caphn_tune(13, V), which cannot fit two tables of different sizes in one process. */
+int caphn_embedding_scatter_add_v(int rows, int E, int V, const float* g, const int64_t* idx, float* table_grad,
+                                  caphn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Optimiser: clip_grad_norm_(5.0) + torch.optim.Adam            [cc_train_hypernet.py:120,405]
