@@ -290,6 +290,8 @@ def main():
                          "the dominant kernel sit inside the timed region")
     ap.add_argument("--eager", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-spinup", action="store_true", help="skip the untimed spin-up windows after --warmup")
+    ap.add_argument("--pretouch", type=int, default=0, help="issue this many trivial kernel launches (and a synchronise) after "
+                    "--warmup: experiment on the one-time host stall of the first process on a fresh box (DESIGN.md section 6)")
     ap.add_argument("--from-host", action="store_true", help="side measurement (DESIGN.md): every minibatch starts in pinned HOST "
                     "memory and crosses PCIe on a copy stream, two batches ahead, into one of three device slots")
     ap.add_argument("--no-module-api", action="store_true", help="skip the side measurement of the unchanged-driver loop "
@@ -340,6 +342,7 @@ def main():
     from hypernet_attention import HyperNet
     from caphn.engine import FusedTrainer
     from caphn import _lib
+    from caphn import ops as ops_mod
     for kv in args.tune:
         k, v = kv.split("=")
         assert _lib.load().caphn_tune(int(k), int(v)) == 0
@@ -448,6 +451,17 @@ def main():
     # Keep stepping in windows of 20 until two consecutive windows agree within 2 % and the last one is within 3 % of
     # the fastest seen, or 4 s have passed.
     spin = {"steps": 0}
+    if args.pretouch > 0:
+        tiny = torch.zeros(4, dtype=torch.float32, device=dev)
+        t_pt = time.perf_counter()
+        worst = 0.0
+        for j in range(args.pretouch):
+            t1 = time.perf_counter()
+            ops_mod.zero_(tiny)
+            worst = max(worst, time.perf_counter() - t1)
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f"[pretouch] {args.pretouch} launches in {(time.perf_counter() - t_pt) * 1e3:.1f} ms, slowest single call {worst * 1e3:.2f} ms", file=sys.stderr)
     if not args.no_spinup:
         def window(n=20):
             torch.cuda.synchronize()

@@ -29,7 +29,7 @@ class HyperGrads(C.Structure):
     _fields_ = [("g_base_w0", c_fp), ("g_base_b0", c_fp), ("g_base_w2", c_fp), ("g_base_b2", c_fp),
                 ("g_w1", c_fp * MAX_HEADS), ("g_b1", c_fp * MAX_HEADS),
                 ("g_w2", c_fp * MAX_HEADS), ("g_b2", c_fp * MAX_HEADS),
-                ("g_x", c_fp)]
+                ("g_x", c_fp), ("x_accumulate", C.c_int)]
 
 
 class DecoderDims(C.Structure):

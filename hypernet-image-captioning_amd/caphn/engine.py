@@ -431,7 +431,8 @@ class FusedTrainer:
         dv = buf.get("dims_variants") if dims is buf["dims"] else None
         if dv is None:
             import dataclasses
-            dv = {p: dataclasses.replace(dims, pre=p | 8) for p in (0, 1, 5, 7, 21)}
+            # bits 8 and 32 on both sides of the step: d Hs zero-filled by the forward's prep kernel, ctx left by the forward
+            dv = {p: dataclasses.replace(dims, pre=p | 8 | 32) for p in (0, 1, 5, 7, 21)}
             if dims is buf["dims"]:          # (with decoder dropout the dims carry a fresh seed every step: not cached)
                 buf["dims_variants"] = dv
         fdims = dv[pre]
@@ -466,9 +467,13 @@ class FusedTrainer:
                                          dtype=torch.uint8, device=self.dev)
         # decoder backward with the hypernet VJP hooked in: it starts on a side stream as soon as dtheta is
         # complete and streams the 576 MB of second-layer weights beside the attention / feature_fc chain
+        # Flickr path on one rank: the style row's VJP is added to its row of the embedding gradient by the VJP's last kernel
+        # (data parallel: the row goes to the communication stream, in front of the embedding bucket's all-reduce)
+        direct = style_token is not None and not dp.active(self.group)
         gx = ops.decoder_hyper_backward(dv[0], params, features, captions, dlogits, grads, buf["ws"],
                                         self.shape, hp, self._acts, hg, self._hyper_ws,
-                                        want_x=style_token is not None or domain_input is not None)
+                                        want_x=(style_token is not None or domain_input is not None) and not direct,
+                                        x_accum_into=self._view(self.flat_g, "captioner.embed.weight")[int(style_token)] if direct else None)
         if domain_input is not None:    # the input row's gradient goes on through the front-end, before the exchange is issued
             self._fe_backward(gx, self._fe_slot)
         tok = None
@@ -480,8 +485,6 @@ class FusedTrainer:
                 tok = self._toks[int(style_token)] = torch.full((1,), int(style_token), dtype=torch.int64, device=self.dev)
         if dp.active(self.group):
             self._issue_exchange(gx, tok)
-        elif tok is not None:
-            ops.embedding_scatter_add(gx.view(1, -1), tok, self._view(self.flat_g, "captioner.embed.weight"))
         if self._loss_pending:       # whoever reads the returned loss on the current stream sees the finished value
             torch.cuda.current_stream().wait_event(self._loss_done)
             self._loss_pending = False
@@ -540,6 +543,7 @@ class FusedTrainer:
             w.append(dp.all_reduce_dense(g[bk["fc"][0]:bk["fc"][1]], self.group, async_op=True))
             ops.backward_milestone_wait(ops.MS_EMBED)
             if tok is not None:
+                ops.backward_milestone_wait(ops.MS_HYPER)      # gx is the last output of the hypernet VJP
                 gx.record_stream(cs)        # allocated on the main stream, consumed here
                 ops.embedding_scatter_add(gx.view(1, -1), tok, self._view(g, "captioner.embed.weight"))
             w.append(dp.all_reduce_dense(g[bk["embed"][0]:bk["embed"][1]], self.group, async_op=True))

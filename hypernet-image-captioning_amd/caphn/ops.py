@@ -782,7 +782,8 @@ def grad_norm_adam_dense(gn: "GradNorm", p, m, v, flat_g: torch.Tensor, pairs, m
 
 
 def decoder_hyper_backward(dims: DecDims, params, features, captions, dlogits, grads, ws,
-                           shape: HyperShape, hyper_params, acts, hyper_grads, hyper_ws, want_x: bool = False):
+                           shape: HyperShape, hyper_params, acts, hyper_grads, hyper_ws, want_x: bool = False,
+                           x_accum_into: Optional[torch.Tensor] = None):
     """decoder_backward + hyper_backward in one call; the hypernet VJP overlaps the decoder's tail.
     The cell gradients in `grads` must be consecutive views of one dtheta buffer (theta order)."""
     lib = L.load()
@@ -802,8 +803,16 @@ def decoder_hyper_backward(dims: DecDims, params, features, captions, dlogits, g
             g.g_w2[i] = gp(f"hn_heads.{i}.2.weight"); g.g_b2[i] = gp(f"hn_heads.{i}.2.bias")
         if hyper_grads.get("__frozen__"):
             hyper_grads["__hgrads__"] = g
-    gx = _f32(shape.he, device=dlogits.device) if want_x else None
-    g.g_x = gx.data_ptr() if gx is not None else None
+    # x_accum_into: the row's gradient is ADDED there by the VJP's last kernel (the style token's row of the embedding gradient:
+    # no separate scatter-add); else want_x returns it as a fresh tensor
+    if x_accum_into is not None:
+        gx = None
+        g.g_x = L.ptr(x_accum_into).value
+        g.x_accumulate = 1
+    else:
+        gx = _f32(shape.he, device=dlogits.device) if want_x else None
+        g.g_x = gx.data_ptr() if gx is not None else None
+        g.x_accumulate = 0
     L.check(lib.caphn_decoder_hyper_backward(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64),
                                              L.ptr(dlogits), None, C.byref(gs), C.c_void_p(ws.data_ptr()),
                                              C.byref(hd), L.ptr(acts), C.byref(g), C.c_void_p(hyper_ws.data_ptr()),

@@ -172,7 +172,7 @@ inline Ws layout(const caphn_decoder_dims* d) {
     w.dHs = take(B * T * H); w.dgi = take(B * T * NG * H); w.dgh = take(lstm ? 0 : B * T * NG * H); w.duah = take(B * T * H);
     w.de = take(B * T * P); w.dh0 = take(B * H); w.dc0 = take(lstm ? B * H : 0);
     w.ctx = w.Xe + E; w.dctx = take(raw ? 0 : B * T * F);
-    w.dXe = take(B * T * E); w.dWaf = take(B * P * H); w.dmeanf = take(raw ? 0 : B * F); w.df = take(raw ? 0 : B * P * F);
+    w.dXe = take(B * T * E); w.dWaf = take(B * P * H); w.dmeanf = take(raw ? 0 : 2 * B * F); w.df = take(raw ? 0 : B * P * F);      // dmeanf: two partials (pair BPTT epilogue)
     w.dY1 = take(raw ? 0 : B * P * F);
     w.pchunk = 1; w.npc = (int)((P + w.pchunk - 1) / w.pchunk);     // one workgroup per (caption, position)
     // per caption: positions, or thread groups when the BPTT kernel fuses the attention parameter gradients
@@ -563,6 +563,10 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
                               reinterpret_cast<const int*>(ws + w.rowmap) + 4, reinterpret_cast<const int*>(ws + w.rowmap), 1, s));
     else
         RUN(caphn_gemm_f32(0, 1, BT, V, H, ws + w.Hs, H, p->out_w, H, logits, V, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+    // bit 32 (given to the forward AND the backward of a training step): the context vectors ctx_t = sum_p alpha_tp f_p -- the
+    // second operand of dW_ih, which the forward never forms (it uses G) -- are left beside the embeddings now, behind the logits
+    // GEMM, instead of in front of the dW_ih GEMM on the backward's chain to d theta
+    if (pc & 32) RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, EF, s));
     if (alphas)
         if (hipMemcpyAsync(alphas, ws + w.alphas, sizeof(float) * (size_t)BT * P, hipMemcpyDeviceToDevice, s) != hipSuccess)
             return CAPHN_ELAUNCH;
@@ -683,6 +687,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
         a.xch = reinterpret_cast<unsigned long long*>(ws + w.xch) + w.xch_floats * sizeof(float) / sizeof(unsigned long long);
         a.apart_rows = ang;
         a.WP = ws + w.wp; a.wp_pitch = caphn_rec_pair_pitch(H);
+        if (!raw) { a.inith_w = p->inith_w; a.initc_w = lstm ? p->initc_w : nullptr; a.dmean_part = ws + w.dmeanf; a.F = F; }
         RUN(caphn_launch_rec_pair_bwd(a, lstm, s));
     } else
     RUN(caphn_launch_rec_bwd(a, lstm, s));
@@ -704,7 +709,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     }
     // sT -- input weights dW_ih = dgi^T [Xe | ctx] (ctx lands beside the embeddings, so this is ONE GEMM: two back to back on the
     // chain to d theta cost 72 + 57 us)
-    RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, EF, sT));
+    if (!(d->precomputed & 32)) RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, EF, sT));      // (else: left by the forward)
     if (lstm) RUN(gemm_auto(1, 0, GH, EF, BT, dgi, GH, ws + w.Xe, EF, g->w_ih, EF, nullptr, 0, sT, nullptr, 0, gz));
     else RUN(wgrad_bias(GH, EF, BT, dgi, GH, ws + w.Xe, EF, g->w_ih, EF, g->b_ih, nullptr, cw1, sT, gz));      // + db_ih
     // b2 -- recurrent weights dW_hh = dgh^T Hprev (+ db_hh), then the embedding gradient
@@ -731,8 +736,9 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     // ~275 us in the kernel trace although the producers had long finished
     if (!raw) {
         RUN(caphn_gemm_f32(0, 0, BT, F, GH, dgi, GH, p->w_ih + E, EF, ws + w.dctx, F, nullptr, nullptr, 0, 0, 1, sF));
-        RUN(caphn_launch_dmean(B, H, F, ws + w.dh0, p->inith_w, lstm ? ws + w.dc0 : nullptr, lstm ? p->initc_w : nullptr,
-                               ws + w.dmeanf, sF));
+        if (!pair)      // (the pair BPTT kernel leaves d mean_f as two partials in its epilogue)
+            RUN(caphn_launch_dmean(B, H, F, ws + w.dh0, p->inith_w, lstm ? ws + w.dc0 : nullptr, lstm ? p->initc_w : nullptr,
+                                   ws + w.dmeanf, sF));
     }
     // attention parameter gradients (dWaf, partial d v_a) when the BPTT kernel did not fuse them
     AttnGradArgs ag;
@@ -752,7 +758,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     if (lstm) RUN(wgrad_bias(H, F, B, ws + w.dc0, H, ws + w.meanf, F, g->initc_w, F, g->initc_b, nullptr, cws, b0, gz));
     // sF -- df = alpha^T dctx + dmean/P + dWaf W_a, then feature_fc backward
     if (!raw) {
-        RUN(caphn_launch_df(B, T, P, F, ws + w.alphas, ws + w.dctx, ws + w.dmeanf, ws + w.df, sF));
+        RUN(caphn_launch_df(B, T, P, F, ws + w.alphas, ws + w.dctx, ws + w.dmeanf, ws + w.df, sF, pair ? ws + w.dmeanf + (size_t)B * F : nullptr));
         RUN(caphn_gemm_f32(0, 0, BP, F, H, ws + w.dWaf, H, p->Wa_w, F, ws + w.df, F, nullptr, nullptr, 0, CAPHN_GEMM_ACCUM, 1, sF));
         RUN(sd.record(4, sF));
         if (hold_big) {

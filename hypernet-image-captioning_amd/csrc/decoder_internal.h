@@ -59,6 +59,9 @@ struct RecBwdArgs {
     int apart_rows = 0;                  // pair kernels: rows of `apart` per caption
     float drop_p = 0.f; unsigned long long drop_seed = 0;
     unsigned epoch = 0; int* err = nullptr; long long xlimit = 0;   // pair kernels (set by the launcher), as in RecFwdArgs
+    // pair kernels: init_hidden's backward in the kernel's epilogue -- each half leaves its part of d mean_f = dh0 W_inith (+ dc0
+    // W_initc) over ITS k in dmean_part[half][B][F] (the two are added, half 0 first, by the df kernel); null = not wanted
+    const float* inith_w = nullptr; const float* initc_w = nullptr; float* dmean_part = nullptr; int F = 0;
     int part_rows = 0, wc_rows = 0;      // pair backward kernel (set by the launcher): rows of its slice-partials array, weight rows kept in LDS
     int t0 = 0, t1 = 0;                  // time-step window [t0, t1), walked backwards (t1 == 0: T).  A window starts from dh = 0 (dc
                                          // from dc0 when t1 < T) and leaves dh_{t0-1} in dh0 (dc in dc0): the caller adds it to what
@@ -110,7 +113,8 @@ int caphn_launch_rec_pair_bwd(const RecBwdArgs& a, bool lstm, hipStream_t s);
 int caphn_rec_bwd_groups(int P, int H);     // > 0: the backward kernel can fuse the attention parameter gradients (rows of `apart` per caption)
 int caphn_launch_attn_param_grads(const AttnGradArgs& a, int B, int npc, hipStream_t s);
 int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const float* f, float* ctx, int ldc, hipStream_t s);   // ctx rows at pitch ldc
-int caphn_launch_df(int B, int T, int P, int F, const float* alphas, const float* dctx, const float* dmean, float* df, hipStream_t s);
+int caphn_launch_df(int B, int T, int P, int F, const float* alphas, const float* dctx, const float* dmean, float* df, hipStream_t s,
+                    const float* dmean2 = nullptr);      // dmean2: second partial of d mean_f (pair BPTT epilogue), added to the first
 int caphn_launch_dmean(int B, int H, int F, const float* dh0, const float* Wh, const float* dc0, const float* Wc, float* out, hipStream_t s);
 int caphn_launch_init_state(int B, int P, int F, int H, const float* f, const float* Wh, const float* bh, const float* Wc,
                             const float* bc, float* meanf, float* h0, float* c0, hipStream_t s);

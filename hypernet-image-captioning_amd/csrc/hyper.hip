@@ -306,7 +306,7 @@ __global__ __launch_bounds__(1024) void gemv_t_reduce_kernel(ReduceJobs jobs) {
 
 // small matrices: y[c] = (sum_jobs sum_r W_j[r][c] d_j[r]) * lrelu'(post[c])
 struct SmallTJob { const float* W; const float* d; int rows; };
-struct SmallTArgs { SmallTJob j[CAPHN_MAX_HEADS]; int n; int k; const float* post; float* out0; float* out1; };
+struct SmallTArgs { SmallTJob j[CAPHN_MAX_HEADS]; int n; int k; const float* post; float* out0; float* out1; int acc0 = 0; };
 // 1024 threads = 8 columns x 128 row lanes (was 64 x 16: with k = 200 that is four workgroups, each thread walking 70
 // rows one dependent load at a time -- 17-43 us for 0.9 MB, on the tail of the hypernet VJP branch)
 constexpr int STC = 8, STR = 128;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(1024) void gemv_t_small_kernel(SmallTArgs a) {
         const int cc = blockIdx.x * STC + col;
         if (lane == 0 && cc < a.k) {
             if (a.post) s *= lrelu_grad(a.post[cc]);
-            if (a.out0) a.out0[cc] = s;
+            if (a.out0) { if (a.acc0) atomicAdd(a.out0 + cc, s); else a.out0[cc] = s; }
             if (a.out1) a.out1[cc] = s;
         }
     }
@@ -511,7 +511,7 @@ extern "C" int caphn_hyper_backward(const caphn_hyper_desc* d, const float* dthe
         hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d_mid(d) + STC - 1) / STC), dim3(1024), 0, s, a);
     }
     if (g->g_x) {   // dx = Wb0^T dzb0
-        SmallTArgs a; a.n = 1; a.k = d_in(d); a.post = nullptr; a.out0 = g->g_x; a.out1 = nullptr;
+        SmallTArgs a; a.n = 1; a.k = d_in(d); a.post = nullptr; a.out0 = g->g_x; a.out1 = nullptr; a.acc0 = g->x_accumulate;
         a.j[0].W = d->base_w0; a.j[0].d = ws + W.dzb0; a.j[0].rows = d_mid(d);
         hipLaunchKernelGGL(gemv_t_small_kernel, dim3((d_in(d) + STC - 1) / STC), dim3(1024), 0, s, a);
     }

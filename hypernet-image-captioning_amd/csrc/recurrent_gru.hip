@@ -552,11 +552,11 @@ __global__ void ctx_kernel(int P, int F, int T, const float* __restrict__ alphas
 }
 // df[b,p,k] = sum_t alpha[b,t,p] dctx[b,t,k] + dmean[b,k] / P
 __global__ void df_kernel(int P, int F, int T, const float* __restrict__ alphas, const float* __restrict__ dctx,
-                          const float* __restrict__ dmean, float* __restrict__ df) {
+                          const float* __restrict__ dmean, const float* __restrict__ dmean2, float* __restrict__ df) {
     const int b = blockIdx.x, p = blockIdx.y;
     const float invP = 1.0f / (float)P;
     for (int k = threadIdx.x; k < F; k += blockDim.x) {
-        float s = dmean[(size_t)b * F + k] * invP;
+        float s = (dmean2 ? dmean[(size_t)b * F + k] + dmean2[(size_t)b * F + k] : dmean[(size_t)b * F + k]) * invP;
         int t = 0;
         for (; t + 8 <= T; t += 8) {
             float a[8], v[8];
@@ -693,8 +693,9 @@ int caphn_launch_ctx(int B, int T, int P, int F, const float* alphas, const floa
     hipLaunchKernelGGL(ctx_kernel, dim3(B, T), dim3(F >= 192 ? 256 : 64), 0, s, P, F, T, alphas, f, ctx, ldc);
     return caphn_launch_status();
 }
-int caphn_launch_df(int B, int T, int P, int F, const float* alphas, const float* dctx, const float* dmean, float* df, hipStream_t s) {
-    hipLaunchKernelGGL(df_kernel, dim3(B, P), dim3(F >= 192 ? 256 : 64), 0, s, P, F, T, alphas, dctx, dmean, df);
+int caphn_launch_df(int B, int T, int P, int F, const float* alphas, const float* dctx, const float* dmean, float* df, hipStream_t s,
+                    const float* dmean2) {
+    hipLaunchKernelGGL(df_kernel, dim3(B, P), dim3(F >= 192 ? 256 : 64), 0, s, P, F, T, alphas, dctx, dmean, dmean2, df);
     return caphn_launch_status();
 }
 int caphn_launch_init_state(int B, int P, int F, int H, const float* f, const float* Wh, const float* bh, const float* Wc,

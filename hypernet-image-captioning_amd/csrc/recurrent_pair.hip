@@ -952,6 +952,30 @@ __global__ __launch_bounds__(NT) void rec_pair_bwd_kernel(RecBwdArgs a) {
         a.dh0[(size_t)b * H + k0 + kk] = dh_s[kk];
         if (LSTM) a.dc0[(size_t)b * H + k0 + kk] = dc_s[kk];
     }
+    // init_hidden's backward over my k (models/decoderlstm.py:122-135: h0 = init_h(mean_P f)): d mean_f[f] += sum_k dh0[k] W_inith[k][f]
+    // (+ dc0 W_initc), eight rows' loads in flight; it was a 128-workgroup kernel of its own on the chain behind this one
+    if (a.dmean_part != nullptr && bt0 == 0) {
+        const int F = a.F;
+        for (int f = tid; f < F; f += NT) {
+            float s0 = 0.f;
+            int kk = 0;
+            for (; kk + 8 <= nk; kk += 8) {
+                float wv[8], cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    wv[u] = a.inith_w[(size_t)(k0 + kk + u) * F + f];
+                    cv[u] = LSTM ? a.initc_w[(size_t)(k0 + kk + u) * F + f] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s0 += dh_s[kk + u] * wv[u]; if (LSTM) s0 += dc_s[kk + u] * cv[u]; }
+            }
+            for (; kk < nk; ++kk) {
+                s0 += dh_s[kk] * a.inith_w[(size_t)(k0 + kk) * F + f];
+                if (LSTM) s0 += dc_s[kk] * a.initc_w[(size_t)(k0 + kk) * F + f];
+            }
+            a.dmean_part[((size_t)hh * a.B + b) * F + f] = s0;
+        }
+    }
     if (fuse) {
         const float vk = va_s[m.k];
 #pragma unroll

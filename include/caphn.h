@@ -172,6 +172,9 @@ typedef struct caphn_hyper_grads {
     float* g_w1[CAPHN_MAX_HEADS]; float* g_b1[CAPHN_MAX_HEADS];
     float* g_w2[CAPHN_MAX_HEADS]; float* g_b2[CAPHN_MAX_HEADS];
     float* g_x;                   /* [d_in] gradient w.r.t. the style/domain embedding row */
+    int x_accumulate;             /* 1: g_x is ADDED to (fp32 atomics) instead of written -- point g_x at the style token's row of the
+                                     embedding gradient (hypernet_attention.py:139-142: x = captioner.embed(style)) and the row's VJP
+                                     needs no scatter-add launch of its own; the row must hold its other contributions or zero */
 } caphn_hyper_grads;
 size_t caphn_hyper_backward_workspace_bytes(const caphn_hyper_desc* d);
 /* VJP of caphn_hyper_forward with dtheta (what autograd would give the reference had utils.py:57
@@ -209,7 +212,9 @@ typedef struct caphn_decoder_dims {
                            launches anyway) and the backward skips its own zero fill.  Bit 16 (with bit 1): the
                            caphn_decoder_precompute call ran on another stream and the caller did NOT wait for it: the forward
                            waits for it itself -- for the feature_fc output before its G GEMM, for the rest before the
-                           recurrent kernel (not inside a stream capture) */
+                           recurrent kernel (not inside a stream capture).  Bit 32, given to BOTH the forward and the backward of a
+                           training step: the forward also leaves the context vectors ctx_t = sum_p alpha_tp f_p (the operand of
+                           dW_ih it never forms itself) in the workspace, and the backward skips that kernel on its chain to d theta */
     int layers;         /* num_layers of AttentionGru (models/decoderlstm.py:34-36): 1 (or 0) = the cell alone; L > 1 adds L - 1 GRUCells
                            applied as h = layer(h, h) after the attention cell at every time step (:101-103).  Then the time loop
                            runs one launch window per step (the extra cells are small batched GEMMs + a gate kernel between the
