@@ -113,6 +113,7 @@ SIGNATURES = {
                                         c_fp, c_fp, c_fp, c_fp]),
     "caphn_decoder_precompute": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp, c_fp, c_fp]),
     "caphn_decoder_inputs": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp, c_fp]),
+    "caphn_decoder_lookup": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp, c_fp]),
     "caphn_decoder_prepare_rows": (C.c_int, [C.POINTER(DecoderDims), c_fp, C.c_int64, c_fp, c_fp]),
     "caphn_decoder_forward_sampled": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
                                                 C.c_char_p, c_fp, c_fp, c_fp, c_fp]),

@@ -384,7 +384,13 @@ class FusedTrainer:
             x = self._view(self.flat_p, "captioner.embed.weight")[style_token]
         else:
             x = x_style.reshape(-1).to(device=self.dev, dtype=torch.float32)
-        ops.zero_(self.flat_g)          # every split-K / atomic target of the backward lives in this arena
+        # every split-K / atomic target of the backward lives in this arena.  When the previous optimiser pass announced this
+        # minibatch, everything behind d theta was cleared on the side stream beside the rank-1 Adam passes (which still read
+        # d theta as their row factor): only that head of the arena is cleared here
+        zero_lo_only = bool(getattr(self, "_zero_hi_done", False))
+        self._zero_hi_done = False
+        if zero_lo_only:                    # this stream must not run ahead of the side clear (nothing has written the arena since)
+            torch.cuda.current_stream().wait_event(self._lookup_done)
         theta = getattr(self, "_theta", None)
         if theta is None:
             theta = self._theta = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)
@@ -405,18 +411,32 @@ class FusedTrainer:
         fdims = dims
         rows_done = False
         pre = 0
+        looked_up = False
         if self._pre_key is not None:
             kf, kc, kB, kT, kP, level = self._pre_key
             if (kf, kB, kT, kP) == (_tkey(features), B, T, P) and not self._readopted:
                 pre = 7 if (level == 2 and kc == _tkey(captions) and theta is self._theta_pre) else 1
+                # level 1 with the captions announced: the live-row map and the embedding lookup are in the workspace already
+                looked_up = pre == 1 and kc is not None and kc == _tkey(captions)
             self._pre_key = None
             self._pre_hold = None
             if pre == 1 and validate is False:
                 # what does not depend on the side stream's work goes first, so it hides behind the wait
-                if dims.rows:
-                    ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
+                if looked_up:
+                    # ... except the lookup itself, which a side stream did (waited for above: the gate GEMM reads its rows)
                     rows_done = True
-                ops.decoder_inputs(dims, params, captions, buf["ws"])
+                    d64 = buf.get("d64")
+                    if d64 is None or dims is not buf["dims"]:
+                        import dataclasses as _dc
+                        d64 = _dc.replace(dims, pre=64)
+                        if dims is buf["dims"]:
+                            buf["d64"] = d64
+                    ops.decoder_inputs(d64, params, captions, buf["ws"])
+                else:
+                    if dims.rows:
+                        ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
+                        rows_done = True
+                    ops.decoder_inputs(dims, params, captions, buf["ws"])
                 pre = 5
                 if self._pre_token is not None and ops.precompute_epoch(self.dev) == self._pre_token:
                     pre |= 16     # bit 16: the forward composite waits for the side stream's precompute itself, piecewise
@@ -426,6 +446,10 @@ class FusedTrainer:
                 torch.cuda.current_stream().wait_event(self._pre_done)      # even if the announced batch did not come
             if pre == 7:
                 rows_done = True
+        if zero_lo_only:
+            ops.zero_(self.flat_g[:_up4(self.theta_size)])
+        else:
+            ops.zero_(self.flat_g)
         # bit 8 on both sides of the step: the forward zero-fills the backward's d Hs accumulator inside a kernel it launches
         # anyway, the backward skips its own fill (it sat on the chain between the loss and the first backward GEMM)
         dv = buf.get("dims_variants") if dims is buf["dims"] else None
@@ -697,6 +721,28 @@ class FusedTrainer:
             self._pre_stream.wait_event(after)
         else:
             self._pre_stream.wait_stream(main)
+        lookup = (level == 1 and captions is not None and captions.dtype == torch.int64 and captions.is_contiguous()
+                  and tuple(captions.shape) == (B, T) and not dp.active(self.group))
+        if lookup:
+            # caption-only work of the next forward's front (live-row map, embedding lookup from the table adam_dense just
+            # updated) and the clear of the gradient arena behind d theta (the rank-1 passes still read d theta itself): three
+            # small launches on a stream of their own -- in front of the feature_fc GEMM on the precompute stream they delayed it,
+            # and with it init_hidden / W_a f, which the next recurrent kernel waits for
+            aux = getattr(self, "_aux_stream", None)
+            if aux is None:
+                aux = self._aux_stream = torch.cuda.Stream(device=self.dev)
+                self._lookup_done = torch.cuda.Event()
+            if after is not None:
+                aux.wait_event(after)
+            else:
+                aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                ops.zero_(self.flat_g[_up4(self.theta_size):])
+                if dims.rows:
+                    ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
+                ops.decoder_lookup(dims, params, captions, buf["ws"])
+                self._lookup_done.record(aux)
+            self._zero_hi_done = True
         with torch.cuda.stream(self._pre_stream):
             if level == 2:
                 cl = captions
@@ -708,7 +754,7 @@ class FusedTrainer:
             self._pre_done.record(self._pre_stream)
         self._pre_token = ops.precompute_epoch(self.dev)
         self._theta_pre = theta if level == 2 else None
-        self._pre_key = (_tkey(features), _tkey(captions) if (level == 2 and captions is not None) else None, B, T, P, level)
+        self._pre_key = (_tkey(features), _tkey(captions) if ((level == 2 or lookup) and captions is not None) else None, B, T, P, level)
         self._pre_hold = (features, captions)         # announced tensors stay alive: their addresses cannot be recycled
 
     def optimizer_step(self, next_x_style=None, next_style_token=None, next_batch=None, next_domain_input=None):
@@ -756,6 +802,9 @@ class FusedTrainer:
                 # earlier eager step (its event would be waited on by a capturing stream), a prefetched theta
                 if self._pre_key is not None:
                     torch.cuda.current_stream().wait_event(self._pre_done)
+                if getattr(self, "_zero_hi_done", False):       # a side clear of the arena issued by an eager step: join it here;
+                    torch.cuda.current_stream().wait_event(self._lookup_done)      # the captured step clears the whole arena
+                    self._zero_hi_done = False
                 self._pre_key = self._pre_hold = self._next_key = self._next_hold = None
                 torch.cuda.current_stream().wait_stream(self._pre_stream)
                 g = torch.cuda.CUDAGraph()

@@ -456,6 +456,18 @@ def decoder_inputs(dims: DecDims, params: Dict[str, torch.Tensor], captions: tor
                                      L.stream_ptr()), "caphn_decoder_inputs")
 
 
+def decoder_lookup(dims: DecDims, params: Dict[str, torch.Tensor], captions: torch.Tensor, ws: torch.Tensor) -> None:
+    """Only the embedding lookup of decoder_inputs (needs the captions and the table, not the generated weights): ahead of time,
+    beside the optimiser; follow with decoder_inputs / decoder_forward on dims with pre | 64."""
+    lib = L.load()
+    if tuple(captions.shape) != (dims.B, dims.T):
+        raise L.CaphnError(f"captions {tuple(captions.shape)} do not match {dims}")
+    cd = dims.c()
+    ps = _dec_struct(L.DecoderParams, dims, params)
+    L.check(lib.caphn_decoder_lookup(C.byref(cd), C.byref(ps), L.ptr(captions, torch.int64), C.c_void_p(ws.data_ptr()),
+                                     L.stream_ptr()), "caphn_decoder_lookup")
+
+
 def decoder_forward(dims: DecDims, params: Dict[str, torch.Tensor], features: torch.Tensor, captions: torch.Tensor,
                     ws: torch.Tensor, logits: Optional[torch.Tensor] = None, alphas: Optional[torch.Tensor] = None,
                     validate: bool = True, want_alphas: bool = True):

@@ -337,7 +337,10 @@ static int decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_p
     Side* sdp = side_here();
     if (!sdp) return CAPHN_ELAUNCH;
     Side& sd = *sdp;
-    RUN(sd.begin(s, g_tune_fork != 0 && (parts & 1)));
+    // (mark: the call comes from caphn_decoder_precompute, beside the optimiser on the caller's side stream -- init_hidden and W_a f
+    //  then run behind feature_fc on that stream: a fork and a join are two event hops of ~25 us each, more than the 27 + 16 us the
+    //  two kernels take in a row, and the next recurrent kernel waits for the later of them)
+    RUN(sd.begin(s, g_tune_fork != 0 && (parts & 1) && !mark));
     Side::Scope scope(sd);
     if (mark && hipEventRecord(sd.pre_f, s) != hipSuccess) return CAPHN_ELAUNCH;      // f exists: a later forward's G GEMM may go
     if (parts & 1) {
@@ -457,10 +460,13 @@ extern "C" int caphn_decoder_prepare_rows(const caphn_decoder_dims* d, const int
 // x side of the forward that needs the captions and the generated W_ih: embedding lookup with the reference's zeroed
 // first two inputs, then the gate pre-activations for all T
 static int decoder_inputs(const caphn_decoder_dims* d, const caphn_decoder_params* p, const Ws& w, float* ws,
-                          const int64_t* captions, hipStream_t s) {
+                          const int64_t* captions, hipStream_t s, int parts = 3) {
     const int BT = d->B * d->T, E = d->E, GH = w.NG * d->H, EF = d->E + d->F;
     int64_t* idx = reinterpret_cast<int64_t*>(ws + w.idx);
-    hipLaunchKernelGGL(teacher_inputs_kernel, dim3(BT), dim3(256), 0, s, d->T, E, captions, p->embed_w, idx, ws + w.Xe, EF);
+    // part 1: the lookup (needs the captions and the embedding table, not the generated weights); part 2: the gate GEMM
+    if ((parts & 1) && !(d->precomputed & 64))
+        hipLaunchKernelGGL(teacher_inputs_kernel, dim3(BT), dim3(256), 0, s, d->T, E, captions, p->embed_w, idx, ws + w.Xe, EF);
+    if (parts & 2)
     RUN(caphn_gemm_f32(0, 1, BT, GH, E, ws + w.Xe, EF, p->w_ih, EF, ws + w.Xg, GH, p->b_ih, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
     return CAPHN_OK;
 }
@@ -489,6 +495,13 @@ extern "C" int caphn_decoder_inputs(const caphn_decoder_dims* d, const caphn_dec
     if (!dims_ok(d) || !p || !captions || !ws_ || !p->embed_w || !p->w_ih || !p->b_ih) return CAPHN_EINVAL;
     const Ws w = layout(d);
     RUN(decoder_inputs(d, p, w, static_cast<float*>(ws_), captions, static_cast<hipStream_t>(stream)));
+    return caphn_launch_status();
+}
+extern "C" int caphn_decoder_lookup(const caphn_decoder_dims* d, const caphn_decoder_params* p, const int64_t* captions,
+                                    void* ws_, caphn_stream_t stream) {
+    if (!dims_ok(d) || !p || !captions || !ws_ || !p->embed_w) return CAPHN_EINVAL;
+    const Ws w = layout(d);
+    RUN(decoder_inputs(d, p, w, static_cast<float*>(ws_), captions, static_cast<hipStream_t>(stream), 1));
     return caphn_launch_status();
 }
 

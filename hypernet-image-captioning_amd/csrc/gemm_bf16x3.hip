@@ -33,6 +33,7 @@ extern "C" int caphn_debug_gemm_prof(unsigned long long* out, int reset) {
 #define GSTAMP(i) do { } while (0)
 #endif
 
+extern int g_tune_gemm_waves;
 namespace {
 
 constexpr int BK = 32;
@@ -285,7 +286,7 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __u
 // MODE 2: ONE product on operands rounded to bf16 (round to nearest even) at staging -- the reduced-precision side mode
 //         (caphn_tune key 11; never the default, never the headline measurement)
 template <int BM, int BN, bool TA, bool TB, int MODE>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_bf16x3_body(GemmArgs g) {
     constexpr bool PL = MODE == 1;
     constexpr bool SINGLE = MODE == 2;
     constexpr bool DB = MODE == 3;          // MODE 0 with TWO LDS images of a slab (ping-pong): see mainloop_db
@@ -730,6 +731,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 #endif
 }
 
+template <int BM, int BN, bool TA, bool TB, int MODE>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) { gemm_bf16x3_body<BM, BN, TA, TB, MODE>(g); }
+// occupancy experiment (caphn_tune key 25): the same body compiled for 5 / 6 waves per SIMD (<= 96 / 80 VGPRs instead of 112-122):
+// the kernel is bound by per-slab latencies, which more resident workgroups per CU could hide
+template <int BM, int BN, bool TA, bool TB, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void gemm_bf16x3_kernel_w5(GemmArgs g) { gemm_bf16x3_body<BM, BN, TA, TB, MODE>(g); }
+template <int BM, int BN, bool TA, bool TB, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void gemm_bf16x3_kernel_w6(GemmArgs g) { gemm_bf16x3_body<BM, BN, TA, TB, MODE>(g); }
+
 template <int BM, int BN, bool TA, bool TB, int PL>
 int launch_one(const GemmArgs& g, hipStream_t s) {
     using TileA = TileS<BM, !TA>;
@@ -746,6 +756,10 @@ int launch_one(const GemmArgs& g, hipStream_t s) {
         attr_set[dev] = true;
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk > 1 ? g.splitk : 1);
+    if constexpr (BM == 64 && PL == 0) {
+        if (g_tune_gemm_waves == 5) { hipLaunchKernelGGL((gemm_bf16x3_kernel_w5<BM, BN, TA, TB, PL>), grid, dim3(256), lds, s, g); return caphn_launch_status(); }
+        if (g_tune_gemm_waves == 6) { hipLaunchKernelGGL((gemm_bf16x3_kernel_w6<BM, BN, TA, TB, PL>), grid, dim3(256), lds, s, g); return caphn_launch_status(); }
+    }
     hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, PL>), grid, dim3(256), lds, s, g);
     return caphn_launch_status();
 }
@@ -766,6 +780,7 @@ int g_tune_gemm_single = 0;   // reduced-precision side modes (caphn_tune key 11
                               // as two bf16 planes (16 significand bits), three products: ~2e-5 relative, inside the north star's 1e-4 on logits
 int g_tune_gemm_order = 1;    // tile walk inside an XCD: 0 n fastest always, 1 (default) m fastest when B outgrows L2 and A is the smaller, 2 m fastest always
 int g_tune_gemm_xcd = 1;      // 1 (default): XCD-aware tile order
+int g_tune_gemm_waves = 0;    // 0 (default): as the compiler allocates (4 waves per SIMD); 5 / 6: the 64x64 six-product kernel compiled for that occupancy
 int g_tune_gemm_db = 0;       // layouts that run the 64x64 tile with ping-pong LDS images (MODE 3): bit 0 NT, bit 1 NN, bit 2 TN
 int g_tune_gemm_fast = 1;     // 1 (default): branch-free loads (static vmcnt) where alignment allows
 // Tile choice: 128x128 when that alone gives >= 512 workgroups and K >= 512, else 64x64 (four workgroups per CU:

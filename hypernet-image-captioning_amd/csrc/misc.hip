@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(int nparts, const double
 // 33 us: 754 fences and tickets cost more than the kernel boundary they replace.)
 //   blocks [0, nb_s): one SUMSQ_CHUNK of x each                      -> part[blk]
 //   then per (job, which, pair, chunk): one chunk of one dot product -> gram slot
-constexpr int NORM_CHUNKS = 16;
+constexpr int NORM_CHUNKS = 64;       // (16: a chunk of the 240000-long d theta dot product was 59 dependent fp64 FMAs per thread -- the
+                                      //  longest block of the launch; 64 chunks x eight loads in flight: 18.6 -> see DESIGN.md section 6)
 __global__ __launch_bounds__(256) void grad_norm_partials_kernel(size_t n, const float* __restrict__ x, int vec, int nb_s, int R,
                                                                  GramJobs jobs, double* __restrict__ part) {
     __shared__ double red[4];
@@ -376,7 +377,15 @@ __global__ __launch_bounds__(256) void grad_norm_partials_kernel(size_t n, const
         const int len = which ? J.k : J.rows;
         const int per = (len + NORM_CHUNKS - 1) / NORM_CHUNKS;
         const int i0 = chunk * per, i1 = min(len, i0 + per);
-        for (int i = i0 + tid; i < i1; i += 256) mine += (double)u[i] * (double)v[i];
+        int i = i0 + tid;
+        for (; i + 7 * 256 < i1; i += 8 * 256) {
+            float uu[8], vv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { uu[e] = u[i + 256 * e]; vv[e] = v[i + 256 * e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mine += (double)uu[e] * (double)vv[e];
+        }
+        for (; i < i1; i += 256) mine += (double)u[i] * (double)v[i];
     }
     mine = wave_sum_d(mine);
     if ((tid & 63) == 0) red[tid >> 6] = mine;
@@ -739,7 +748,15 @@ __global__ __launch_bounds__(256) void grad_norm_multi_partials_kernel(MTJobs T,
         const int len = which ? J.k : J.rows;
         const int per = (len + NORM_CHUNKS - 1) / NORM_CHUNKS;
         const int i0 = chunk * per, i1 = min(len, i0 + per);
-        for (int i = i0 + tid; i < i1; i += 256) mine += (double)u[i] * (double)v[i];
+        int i = i0 + tid;
+        for (; i + 7 * 256 < i1; i += 8 * 256) {
+            float uu[8], vv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { uu[e] = u[i + 256 * e]; vv[e] = v[i + 256 * e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mine += (double)uu[e] * (double)vv[e];
+        }
+        for (; i < i1; i += 256) mine += (double)u[i] * (double)v[i];
     }
     mine = wave_sum_d(mine);
     if ((tid & 63) == 0) red[tid >> 6] = mine;

@@ -214,7 +214,8 @@ typedef struct caphn_decoder_dims {
                            waits for it itself -- for the feature_fc output before its G GEMM, for the rest before the
                            recurrent kernel (not inside a stream capture).  Bit 32, given to BOTH the forward and the backward of a
                            training step: the forward also leaves the context vectors ctx_t = sum_p alpha_tp f_p (the operand of
-                           dW_ih it never forms itself) in the workspace, and the backward skips that kernel on its chain to d theta */
+                           dW_ih it never forms itself) in the workspace, and the backward skips that kernel on its chain to d theta.
+                           Bit 64: the embedding lookup (caphn_decoder_lookup) is already in the workspace */
     int layers;         /* num_layers of AttentionGru (models/decoderlstm.py:34-36): 1 (or 0) = the cell alone; L > 1 adds L - 1 GRUCells
                            applied as h = layer(h, h) after the attention cell at every time step (:101-103).  Then the time loop
                            runs one launch window per step (the extra cells are small batched GEMMs + a gate kernel between the
@@ -277,6 +278,11 @@ int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_pa
  * captions and the generated W_ih / b_ih but not the features: a trainer waiting for a side-stream precompute can issue
  * it first (dims.precomputed |= 4). */
 int caphn_decoder_inputs(const caphn_decoder_dims* d, const caphn_decoder_params* p, const int64_t* captions, void* ws,
+                         caphn_stream_t stream);
+/* Only the embedding lookup of caphn_decoder_inputs (token ids + input rows, decoderlstm.py:62, :82-88): needs the captions and the
+ * embedding table but NOT the generated cell weights, so a trainer that knows the next minibatch's captions can issue it beside
+ * the optimiser; caphn_decoder_inputs / _forward with dims.precomputed bit 64 then skip the lookup and run the gate GEMM only. */
+int caphn_decoder_lookup(const caphn_decoder_dims* d, const caphn_decoder_params* p, const int64_t* captions, void* ws,
                          caphn_stream_t stream);
 /* Compacts the (b,t) rows whose target differs from ignore_index into a row map kept in the workspace (count stays on
  * the device: no host synchronisation).  Call before caphn_decoder_forward / _backward with dims.row_subset = 1. */

@@ -23,17 +23,20 @@ SHAPES = [  # name, ta, tb, M, N, K, splitk
 def main():
     lib = _lib.load()
     dev = "cuda"
+    # usage: microbench_gemm_db.py [tune key] [value of the variant]   (default: key 23 = ping-pong LDS images, value 7)
+    KEY = int(sys.argv[1]) if len(sys.argv) > 1 else 23
+    VAR = int(sys.argv[2]) if len(sys.argv) > 2 else 7
     g = torch.Generator(device=dev).manual_seed(0)
     for name, ta, tb, M, N, K, sk in SHAPES:
         A = torch.randn((K, M) if ta else (M, K), generator=g, device=dev)
         B = torch.randn((N, K) if tb else (K, N), generator=g, device=dev) * 0.07
         ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
         out = torch.zeros(M, N, device=dev)
-        res = {0: [], 7: []}
+        res = {0: [], VAR: []}
         err = {}
         for rnd in range(5):
-            for mode in (0, 7):
-                lib.caphn_tune(23, mode)
+            for mode in (0, VAR):
+                lib.caphn_tune(KEY, mode)
                 if sk > 1:
                     out.zero_()
                 torch.cuda.synchronize()
@@ -42,9 +45,9 @@ def main():
                 torch.cuda.synchronize()
                 res[mode].append(s.elapsed_time(e) * 1e3)
                 err[mode] = float((out.double() - ref).abs().max())
-        t0, t1 = float(np.median(res[0][1:])), float(np.median(res[7][1:]))
-        print(f"{name:9s} M={M:5d} N={N:5d} K={K:5d} sk={sk:2d} | one image {t0:7.1f} us err {err[0]:.2e} | ping-pong {t1:7.1f} us err {err[7]:.2e} | x{t0 / t1:.2f}")
-    lib.caphn_tune(23, 0)
+        t0, t1 = float(np.median(res[0][1:])), float(np.median(res[VAR][1:]))
+        print(f"{name:9s} M={M:5d} N={N:5d} K={K:5d} sk={sk:2d} | default {t0:7.1f} us err {err[0]:.2e} | key {KEY} = {VAR}: {t1:7.1f} us err {err[VAR]:.2e} | x{t0 / t1:.2f}")
+    lib.caphn_tune(KEY, 0)
 
 
 if __name__ == "__main__":
