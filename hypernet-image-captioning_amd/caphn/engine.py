@@ -534,7 +534,10 @@ class FusedTrainer:
             # the row factors and the column factors (row pitch = the packed length: the rank-R kernels take leading dimensions)
             L = self._acts.numel()
             tp = _up4(th)
-            self._fac_snap = torch.zeros(_up4(tp + L), dtype=torch.float32, device=self.dev)
+            # (torch.empty, not zeros: a fill kernel would run on the CALLER's stream, unordered against the snapshot copies the
+            #  communication stream makes below -- on the first step it could land after them and wipe the factors; the pad
+            #  columns are never read)
+            self._fac_snap = torch.empty(_up4(tp + L), dtype=torch.float32, device=self.dev)
             self._fac_all = torch.empty(R, _up4(tp + L), dtype=torch.float32, device=self.dev)
             self._gfac_all = self._fac_all[:, :th]
             self._acts_all = self._fac_all[:, tp:tp + L]

@@ -23,6 +23,9 @@ int g_tune_splitk_target = 1280;   // workgroups a split-K GEMM of the composite
                                    // Same-box A/B: 1024 1.907/1.911, 1152 1.909/1.904, 1280 1.897/1.901 ms (256, 512, 2048: slower)
 int g_tune_chain_main = 0;  // 1: with the hypernet VJP hooked in, the chain to it runs on the caller's stream (see "after BPTT");
                             // measured 30 us per step WORSE than 0 (2.026/2.023 vs 1.996/1.994 ms, same box, alternating)
+int g_tune_hops = 0;        // 1: cross-stream dependencies of the composites as stream memory operations (struct Side) -- 4 us per hop in isolation
+                            // (tools/native/hop_latency.hip) but the STEP went from 1.68 to 2.02 ms with them (same box, alternating;
+                            // profiles/r03_hops_by_value_ab.txt): off.  caphn_tune key 26
 int g_tune_fork = 4;        // 0: one stream; 1: independent branches on side streams, the vocabulary weight gradient (dW_fc) starting
                             // after BPTT; 2: dW_fc beside BPTT; 3: as 1, the big leaves held back until df exists; 4 (default): 2 when
                             // the pair kernels run BPTT (512-thread workgroups leave wave slots, registers and 60 KB of LDS per CU
@@ -38,9 +41,18 @@ namespace {
 // thread-safe: one host thread drives one device (as the reference's training loop does).
 struct Side {
     hipStream_t st[3];
-    hipEvent_t fork, join[3], x[6];
-    hipEvent_t ms[CAPHN_MS_COUNT];     // milestones of the last backward composite (caphn_decoder_backward_milestone)
-    hipEvent_t pre_f, pre_all;         // last caphn_decoder_precompute on this device: feature_fc output ready / everything ready
+    // A dependency slot: "everything enqueued on `from` so far" -> a later wait on another stream.  Two forms.  Events
+    // (hipEventRecord + hipStreamWaitEvent): capturable into a graph, but the waiting queue is released ~10 us after the producer
+    // ends on an idle chip and 20-27 us inside the step (tools/native/hop_latency.hip; the kernel trace shows it after every fork
+    // whose producer has only just finished).  Stream memory operations (hipStreamWriteValue32 of a sequence number +
+    // hipStreamWaitValue32 >= that number, on a word of device memory): 4 us idle -- the command processor polls the word itself --
+    // but not capturable.  begin() picks per composite call: memory operations unless the caller's stream is capturing.
+    enum { D_FORK = 0, D_JOIN = 1, D_X = 4, D_MS = 10, D_PRE_F = 14, D_PRE_ALL = 15, D_COUNT = 16 };
+    struct Dep { hipEvent_t ev; unsigned seq = 0; bool by_value = false; };
+    Dep deps[D_COUNT];
+    unsigned* vals = nullptr;          // D_COUNT words of device memory (zero at start); slot values only grow
+    unsigned counter = 0;
+    bool values = false;               // form chosen by the current composite call
     bool pre_valid = false;
     const void* pre_ws = nullptr;      // workspace of that precompute: a forward that waits on pre_f / pre_all itself (bit 16) must own it
     bool ready = false, on = false;
@@ -52,41 +64,58 @@ struct Side {
         std::lock_guard<std::mutex> lock(mu);
         if (ready) return CAPHN_OK;
         for (auto& s : st) if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return CAPHN_ELAUNCH;
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
-        for (auto& e : join) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
-        for (auto& e : x) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
-        for (auto& e : ms) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
-        if (hipEventCreateWithFlags(&pre_f, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
-        if (hipEventCreateWithFlags(&pre_all, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
+        for (auto& d : deps) if (hipEventCreateWithFlags(&d.ev, hipEventDisableTiming) != hipSuccess) return CAPHN_ELAUNCH;
+        void* p = nullptr;
+        if (hipMalloc(&p, sizeof(unsigned) * D_COUNT) == hipSuccess && hipMemset(p, 0, sizeof(unsigned) * D_COUNT) == hipSuccess)
+            vals = static_cast<unsigned*>(p);
+        else (void)hipGetLastError();          // no word memory: events only
         ready = true;
         return CAPHN_OK;
+    }
+    int post(int slot, hipStream_t from) {
+        Dep& d = deps[slot];
+        if (values) {
+            d.seq = ++counter; d.by_value = true;
+            return hipStreamWriteValue32(from, vals + slot, d.seq, 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+        }
+        d.by_value = false;
+        return hipEventRecord(d.ev, from) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+    }
+    int await(int slot, hipStream_t to) {
+        Dep& d = deps[slot];
+        if (d.by_value)
+            return hipStreamWaitValue32(to, vals + slot, d.seq, hipStreamWaitValueGte, 0xffffffffu) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+        return hipStreamWaitEvent(to, d.ev, 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
     }
     // milestone k is reached once everything enqueued on `from` so far has run
     int milestone(int k, hipStream_t from) {
         if (init() != CAPHN_OK) return CAPHN_ELAUNCH;
-        return hipEventRecord(ms[k], from) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+        return post(D_MS + k, from);
     }
     int begin(hipStream_t m, bool enable) {
         main = m; on = enable;
-        return init();
+        if (init() != CAPHN_OK) return CAPHN_ELAUNCH;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        values = g_tune_hops != 0 && vals != nullptr && hipStreamIsCapturing(m, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+        return CAPHN_OK;
     }
     hipStream_t s(int i) const { return (on && ((g_tune_branch_mask >> i) & 1)) ? st[i] : main; }
     // branch i starts after everything enqueued on main so far
     int forkto(int i) {
         if (!on || !((g_tune_branch_mask >> i) & 1)) return CAPHN_OK;
-        if (hipEventRecord(fork, main) != hipSuccess) return CAPHN_ELAUNCH;
-        if (hipStreamWaitEvent(st[i], fork, 0) != hipSuccess) return CAPHN_ELAUNCH;
+        if (post(D_FORK, main) != CAPHN_OK) return CAPHN_ELAUNCH;
+        if (await(D_FORK, st[i]) != CAPHN_OK) return CAPHN_ELAUNCH;
         forked[i] = true;
         return CAPHN_OK;
     }
-    // several branches start at the same point of main: ONE event record (a record costs the recording stream ~5-7 us of
+    // several branches start at the same point of main: ONE record (a record costs the recording stream ~5-7 us of
     // queue time -- three of them sat between the BPTT kernel and the first kernel of the chain behind it)
     int fork_many(std::initializer_list<int> ids) {
         if (!on) return CAPHN_OK;
-        if (hipEventRecord(fork, main) != hipSuccess) return CAPHN_ELAUNCH;
+        if (post(D_FORK, main) != CAPHN_OK) return CAPHN_ELAUNCH;
         for (int i : ids) {
             if (!((g_tune_branch_mask >> i) & 1)) continue;       // branch folded into the caller's stream
-            if (hipStreamWaitEvent(st[i], fork, 0) != hipSuccess) return CAPHN_ELAUNCH;
+            if (await(D_FORK, st[i]) != CAPHN_OK) return CAPHN_ELAUNCH;
             forked[i] = true;
         }
         return CAPHN_OK;
@@ -95,8 +124,8 @@ struct Side {
     int jointo(int i) {
         if (!on || !((g_tune_branch_mask >> i) & 1)) return CAPHN_OK;
         forked[i] = false;
-        if (hipEventRecord(join[i], st[i]) != hipSuccess) return CAPHN_ELAUNCH;
-        return hipStreamWaitEvent(main, join[i], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+        if (post(D_JOIN + i, st[i]) != CAPHN_OK) return CAPHN_ELAUNCH;
+        return await(D_JOIN + i, main);
     }
     // A composite that returns early (a failed launch) must not leave a branch forked: inside a stream capture an
     // unjoined branch makes hipStreamEndCapture fail (hipErrorStreamCaptureUnjoined) -- every composite holds a Scope.
@@ -111,17 +140,17 @@ struct Side {
     int record(int k, hipStream_t from) {
         if (!on) return CAPHN_OK;
         xfrom[k] = from;
-        return hipEventRecord(x[k], from) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+        return post(D_X + k, from);
     }
     int wait(int k, hipStream_t to) {
         if (!on || xfrom[k] == to) return CAPHN_OK;
-        return hipStreamWaitEvent(to, x[k], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+        return await(D_X + k, to);
     }
-    // `to` waits for what `from` has enqueued so far (cross-branch dependency), via event slot k
+    // `to` waits for what `from` has enqueued so far (cross-branch dependency), via slot k
     int dep(hipStream_t from, hipStream_t to, int k) {
         if (!on || from == to) return CAPHN_OK;
-        if (hipEventRecord(x[k], from) != hipSuccess) return CAPHN_ELAUNCH;
-        return hipStreamWaitEvent(to, x[k], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+        if (post(D_X + k, from) != CAPHN_OK) return CAPHN_ELAUNCH;
+        return await(D_X + k, to);
     }
 };
 constexpr int MAX_DEVICES = 64;
@@ -342,7 +371,7 @@ static int decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_p
     //  two kernels take in a row, and the next recurrent kernel waits for the later of them)
     RUN(sd.begin(s, g_tune_fork != 0 && (parts & 1) && !mark));
     Side::Scope scope(sd);
-    if (mark && hipEventRecord(sd.pre_f, s) != hipSuccess) return CAPHN_ELAUNCH;      // f exists: a later forward's G GEMM may go
+    if (mark) RUN(sd.post(Side::D_PRE_F, s));      // f exists: a later forward's G GEMM may go
     if (parts & 1) {
         RUN(sd.fork_many({0, 1}));
         // branch 0 -- init_hidden: mean over positions -> Linear(F,H) (and init_c for the LSTM)      :122-135 / :255-260
@@ -484,7 +513,7 @@ extern "C" int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn
     RUN(decoder_precompute(d, p, w, static_cast<float*>(ws_), features, &f, s, captions ? 3 : 1, true));
     if (captions) RUN(decoder_inputs(d, p, w, static_cast<float*>(ws_), captions, s));
     Side* sd = side_here();
-    if (!sd || hipEventRecord(sd->pre_all, s) != hipSuccess) return CAPHN_ELAUNCH;
+    if (!sd || sd->post(Side::D_PRE_ALL, s) != CAPHN_OK) return CAPHN_ELAUNCH;
     sd->pre_valid = true;
     sd->pre_ws = ws_;
     return caphn_launch_status();
@@ -533,11 +562,11 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     if (pc & 16) {
         // the events are per device: they belong to this call only if the last precompute issued on this device filled THIS workspace
         if (!sdw || !sdw->pre_valid || sdw->pre_ws != ws_) return CAPHN_EINVAL;
-        if (hipStreamWaitEvent(s, sdw->pre_f, 0) != hipSuccess) return CAPHN_ELAUNCH;
+        RUN(sdw->await(Side::D_PRE_F, s));
     }
     RUN(decoder_precompute(d, p, w, ws, features, &f, s, ((pc & 1) ? 0 : 1) | ((pc & 2) ? 0 : 2)));
     if (pc & 16)
-        if (hipStreamWaitEvent(s, sdw->pre_all, 0) != hipSuccess) return CAPHN_ELAUNCH;
+        RUN(sdw->await(Side::D_PRE_ALL, s));
 
     RecFwdArgs a;
     a.B = B; a.T = T; a.P = P; a.H = H; a.RG = RG;
@@ -809,7 +838,7 @@ extern "C" int caphn_decoder_backward_milestone(int which, caphn_stream_t waiter
     Side* sd = side_here();
     if (!sd) return CAPHN_ELAUNCH;
     if (!sd->ready) return CAPHN_OK;      // no backward composite has run on this device: nothing to wait for
-    return hipStreamWaitEvent(static_cast<hipStream_t>(waiter), sd->ms[which], 0) == hipSuccess ? CAPHN_OK : CAPHN_ELAUNCH;
+    return sd->await(Side::D_MS + which, static_cast<hipStream_t>(waiter));
 }
 
 // Free-running / scheduled-sampling forward (no backward state kept: validation and inference).

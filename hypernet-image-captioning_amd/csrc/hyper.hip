@@ -572,6 +572,7 @@ extern int g_tune_gemm_order;
 extern int g_tune_branch_mask;
 extern int g_tune_gemm_db;
 extern int g_tune_gemm_waves;
+extern int g_tune_hops;
 extern int g_tune_vocab_order;
 extern int g_det_vocab;
 int caphn_rec_pair_debug_skip(int v);
@@ -596,6 +597,7 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 17) { if (value < 1 || value > 65536) return CAPHN_EINVAL; g_tune_splitk_target = value; return CAPHN_OK; }
     if (key == 16) { if (value < 0 || value > 2) return CAPHN_EINVAL; g_tune_rec_cache = value; return CAPHN_OK; }
     if (key == 15) { g_tune_chain_main = value != 0; return CAPHN_OK; }
+    if (key == 26) { g_tune_hops = value != 0; return CAPHN_OK; }
     if (key == 25) { if (value != 0 && value != 5 && value != 6) return CAPHN_EINVAL; g_tune_gemm_waves = value; return CAPHN_OK; }
     if (key == 24) return caphn_rec_pair_debug_opts(value);
     if (key == 23) { if (value < 0 || value > 7) return CAPHN_EINVAL; g_tune_gemm_db = value; return CAPHN_OK; }
