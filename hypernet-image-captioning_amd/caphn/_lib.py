@@ -55,6 +55,11 @@ class AdamHParams(C.Structure):
                 ("step", C.c_int), ("dev_scalars", c_fp)]
 
 
+class RankJob(C.Structure):
+    _fields_ = [("W", c_fp), ("m", c_fp), ("v", c_fp), ("gfac", c_fp), ("ldg", C.c_size_t), ("afac", c_fp), ("lda", C.c_size_t),
+                ("next_a", c_fp), ("next_bias", c_fp), ("next_theta", c_fp), ("rows", C.c_int), ("k", C.c_int)]
+
+
 MAX_LAYERS = 4
 
 
@@ -181,6 +186,7 @@ SIGNATURES = {
                                       c_fp, C.c_size_t, c_fp, C.POINTER(AdamHParams), c_fp]),
     "caphn_adam_rank_gemv_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_size_t,
                                            c_fp, C.c_size_t, c_fp, C.POINTER(AdamHParams), c_fp, c_fp, c_fp, c_fp]),
+    "caphn_adam_rank_multi_f32": (C.c_int, [C.c_int, C.c_int, C.POINTER(RankJob), c_fp, C.POINTER(AdamHParams), c_fp]),
     "caphn_hyper_forward_acts": (C.c_int, [C.POINTER(HyperDesc), c_fp, c_fp, c_fp]),
     "caphn_stream_copy_f32": (C.c_int, [C.c_size_t, c_fp, c_fp, c_fp]),
     "caphn_outer_f32": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),

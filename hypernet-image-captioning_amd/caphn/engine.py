@@ -115,8 +115,16 @@ class FusedTrainer:
         self._gfac_all = None
         self._acts_all = None
         self.overlap_after_head = 0      # the side stream forks after this head's Adam pass (-1: before the first)
-        self.overlap_level = 1           # 2: also G / embedding / x-side gates once the next W_ih exists (measured: no gain,
-                                         # the extra side-stream work slows the concurrent Adam pass by as much)
+        self.overlap_level = int(os.environ.get("CAPHN_OVERLAP_LEVEL", "1"))
+        # 1: the theta-independent front (feature_fc / init_hidden / W_a f) forked after the head-0 pass.
+        # 2: the WHOLE front, forked after the W_ih / b_ih / b_hh passes, beside the W_hh pass (round 2: no gain -- feature_fc does
+        #    not fit beside one 150 us pass).
+        # 3 (default): passes in the order W_ih, b_ih, b_hh, W_hh; the theta-independent front AND G fork after the W_ih pass, the
+        #    x-side gate GEMM goes to the caption-side stream behind the b_ih pass: the next forward starts at the recurrent
+        #    kernel's prep launch (the two GEMMs that need theta no longer sit between the last pass and the recurrent kernel)
+        self._bih_ev = None
+        self._aux_pending = False
+        self._main_ev = self._zero_lo_done = None
 
     # ------------------------------------------------------------------ parameter arenas
     def _build_arena(self):
@@ -389,8 +397,9 @@ class FusedTrainer:
         # d theta as their row factor): only that head of the arena is cleared here
         zero_lo_only = bool(getattr(self, "_zero_hi_done", False))
         self._zero_hi_done = False
-        if zero_lo_only:                    # this stream must not run ahead of the side clear (nothing has written the arena since)
-            torch.cuda.current_stream().wait_event(self._lookup_done)
+        if zero_lo_only or self._aux_pending:   # this stream must not run ahead of the side clear (nothing has written the arena since)
+            torch.cuda.current_stream().wait_event(self._lookup_done)      # / of the caption-side work in the workspace
+        self._aux_pending = False
         theta = getattr(self, "_theta", None)
         if theta is None:
             theta = self._theta = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)
@@ -415,7 +424,7 @@ class FusedTrainer:
         if self._pre_key is not None:
             kf, kc, kB, kT, kP, level = self._pre_key
             if (kf, kB, kT, kP) == (_tkey(features), B, T, P) and not self._readopted:
-                pre = 7 if (level == 2 and kc == _tkey(captions) and theta is self._theta_pre) else 1
+                pre = 7 if (level >= 2 and kc == _tkey(captions) and theta is self._theta_pre) else 1
                 # level 1 with the captions announced: the live-row map and the embedding lookup are in the workspace already
                 looked_up = pre == 1 and kc is not None and kc == _tkey(captions)
             self._pre_key = None
@@ -438,7 +447,7 @@ class FusedTrainer:
                         rows_done = True
                     ops.decoder_inputs(dims, params, captions, buf["ws"])
                 pre = 5
-                if self._pre_token is not None and ops.precompute_epoch(self.dev) == self._pre_token:
+                if level != 3 and self._pre_token is not None and ops.precompute_epoch(self.dev) == self._pre_token:
                     pre |= 16     # bit 16: the forward composite waits for the side stream's precompute itself, piecewise
                                   # (feature_fc output before G, the rest before the recurrent kernel).  The library keeps those
                                   # events per DEVICE: only valid while nobody has issued another precompute since ours
@@ -446,8 +455,21 @@ class FusedTrainer:
                 torch.cuda.current_stream().wait_event(self._pre_done)      # even if the announced batch did not come
             if pre == 7:
                 rows_done = True
+        zero_lo_side = False
         if zero_lo_only:
-            ops.zero_(self.flat_g[:_up4(self.theta_size)])
+            # d theta was the rank-1 passes' row factor until a moment ago and is written again by the backward's weight-gradient
+            # GEMMs, half a millisecond from now: its clear goes to the caption-side stream, behind this point of the caller's
+            # stream, and is joined in front of the backward (a dependency satisfied that early costs nothing; in line it was a
+            # launch between the last Adam pass and the recurrent kernel)
+            aux = self._aux_stream
+            if self._main_ev is None:
+                self._main_ev, self._zero_lo_done = torch.cuda.Event(), torch.cuda.Event()
+            self._main_ev.record()
+            aux.wait_event(self._main_ev)
+            with torch.cuda.stream(aux):
+                ops.zero_(self.flat_g[:_up4(self.theta_size)])
+                self._zero_lo_done.record(aux)
+            zero_lo_side = True
         else:
             ops.zero_(self.flat_g)
         # bit 8 on both sides of the step: the forward zero-fills the backward's d Hs accumulator inside a kernel it launches
@@ -494,6 +516,8 @@ class FusedTrainer:
         # Flickr path on one rank: the style row's VJP is added to its row of the embedding gradient by the VJP's last kernel
         # (data parallel: the row goes to the communication stream, in front of the embedding bucket's all-reduce)
         direct = style_token is not None and not dp.active(self.group)
+        if zero_lo_side:
+            torch.cuda.current_stream().wait_event(self._zero_lo_done)
         gx = ops.decoder_hyper_backward(dv[0], params, features, captions, dlogits, grads, buf["ws"],
                                         self.shape, hp, self._acts, hg, self._hyper_ws,
                                         want_x=(style_token is not None or domain_input is not None) and not direct,
@@ -679,32 +703,65 @@ class FusedTrainer:
         # Order of the rank-1 passes when the next minibatch is known: everything the front of the next forward needs
         # (W_ih, b_ih -- heads 0, 2; and the tiny b_hh head) first, then the side stream starts the next forward's
         # front end while the W_hh pass (head 1, HBM-bound) is still streaming.
-        full = (self.overlap_level >= 2 and prefetch and next_batch is not None and next_batch[1] is not None and len(segs) == 4 and
-                next_batch[1].dtype == torch.int64 and next_batch[1].is_contiguous())
-        order = [0, 2, 3, 1] if full else list(range(len(segs)))
+        known = (prefetch and next_batch is not None and next_batch[1] is not None and len(segs) == 4 and
+                 next_batch[1].dtype == torch.int64 and next_batch[1].is_contiguous())
+        full = self.overlap_level == 2 and known
+        split = self.overlap_level >= 3 and known and self.overlap_after_head == 0
+        order = [0, 2, 3, 1] if (full or split) else list(range(len(segs)))
         fork_after = order[-2] if full else self.overlap_after_head
         if next_batch is not None and not full and self.overlap_after_head < 0:
             self._precompute_next(*next_batch, level=1)
+        # consecutive small heads (the bias heads: [3H, k]) go out as ONE launch -- each is ~11 us of launch-bound kernel
+        groups = []
         for i in order:
-            gi, ai, o, w, ao, an = segs[i]
-            kw = {}
-            if prefetch:
-                kw = dict(next_a=self._acts_next[ao:ao + an], next_bias=self._owned[f"hn_heads.{i}.2.bias"].data,
-                          next_theta=self._theta_next[o:o + w])
-            ops.adam_rank(self.W2[i].data, self.W2_m[i], self.W2_v[i], gi, ai, self._coef, self.lr, step,
-                          self.betas, self.eps, dev_scalars=self._adam_dev if self._graph_scalars else None, **kw)
-            if i == fork_after and next_batch is not None:
+            small = segs[i][3] <= 16384
+            if groups and small and groups[-1][1]:
+                groups[-1][0].append(i)
+            else:
+                groups.append(([i], small))
+        dev_sc = self._adam_dev if self._graph_scalars else None
+        for members, _ in groups:
+            jobs = []
+            for i in members:
+                gi, ai, o, w, ao, an = segs[i]
+                job = [self.W2[i].data, self.W2_m[i], self.W2_v[i], gi, ai]
+                if prefetch:
+                    job += [self._acts_next[ao:ao + an], self._owned[f"hn_heads.{i}.2.bias"].data, self._theta_next[o:o + w]]
+                jobs.append(job)
+            if len(jobs) == 1:
+                j = jobs[0]
+                kw = dict(next_a=j[5], next_bias=j[6], next_theta=j[7]) if prefetch else {}
+                ops.adam_rank(j[0], j[1], j[2], j[3], j[4], self._coef, self.lr, step, self.betas, self.eps, dev_scalars=dev_sc, **kw)
+            else:
+                ops.adam_rank_multi(jobs, self._coef, self.lr, step, self.betas, self.eps, dev_scalars=dev_sc)
+            if fork_after in members and next_batch is not None:
                 # the side stream starts HERE on the device (an event), but its launches are enqueued after the remaining passes:
                 # the host otherwise spends ~50 us on the precompute's launches before it gets to the next pass
                 if self._fork_ev is None:
                     self._fork_ev = torch.cuda.Event()
                 self._fork_ev.record()
-                fork_level = 2 if full else 1
-            if i == fork_after and next_batch is not None and not self.fork_late:
+                fork_level = 2 if full else 3 if split else 1
+            if split and order[-2] in members:         # b_ih (and b_hh) exist: the x-side gate GEMM may go
+                if self._bih_ev is None:
+                    self._bih_ev = torch.cuda.Event()
+                self._bih_ev.record()
+            if fork_after in members and next_batch is not None and not (self.fork_late or split):
                 self._precompute_next(*next_batch, level=fork_level)
-        if next_batch is not None and fork_after >= 0 and fork_after in order and self.fork_late:
+        if next_batch is not None and fork_after >= 0 and fork_after in order and (self.fork_late or split):
             self._precompute_next(*next_batch, level=fork_level, after=self._fork_ev)
         return self._coef
+
+    @staticmethod
+    def _dims_pre(buf, dims, bits):
+        """dims with the given dims.precomputed bits (cached per shape while the dims are the cached ones)."""
+        import dataclasses
+        if dims is not buf["dims"]:
+            return dataclasses.replace(dims, pre=bits)
+        c = buf.setdefault("dims_pre", {})
+        d = c.get(bits)
+        if d is None:
+            d = c[bits] = dataclasses.replace(dims, pre=bits)
+        return d
 
     def _precompute_next(self, features, captions, T, level=1, after=None):
         """The decoder's dense parameters are final (adam_dense ran) and the workspace is free (backward is done):
@@ -716,7 +773,7 @@ class FusedTrainer:
         B, P, _ = features.shape
         buf = self._buffers(B, T, P)
         dims = buf["dims"]
-        theta = self._theta_next if level == 2 else (self._theta if getattr(self, "_theta", None) is not None
+        theta = self._theta_next if level >= 2 else (self._theta if getattr(self, "_theta", None) is not None
                                                      else torch.empty(self.theta_size, device=self.dev))
         params = self._dec_tensors(theta, grads=False)
         main = torch.cuda.current_stream()
@@ -724,8 +781,10 @@ class FusedTrainer:
             self._pre_stream.wait_event(after)
         else:
             self._pre_stream.wait_stream(main)
-        lookup = (level == 1 and captions is not None and captions.dtype == torch.int64 and captions.is_contiguous()
-                  and tuple(captions.shape) == (B, T) and not dp.active(self.group))
+        lookup = (level in (1, 3) and captions is not None and captions.dtype == torch.int64 and captions.is_contiguous()
+                  and tuple(captions.shape) == (B, T) and (level == 3 or not dp.active(self.group)))
+        if level == 3 and not lookup:
+            level = 1
         if lookup:
             # caption-only work of the next forward's front (live-row map, embedding lookup from the table adam_dense just
             # updated) and the clear of the gradient arena behind d theta (the rank-1 passes still read d theta itself): three
@@ -739,25 +798,35 @@ class FusedTrainer:
                 aux.wait_event(after)
             else:
                 aux.wait_stream(main)
+            clear = not dp.active(self.group)
             with torch.cuda.stream(aux):
-                ops.zero_(self.flat_g[_up4(self.theta_size):])
+                if clear:
+                    ops.zero_(self.flat_g[_up4(self.theta_size):])
                 if dims.rows:
                     ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
                 ops.decoder_lookup(dims, params, captions, buf["ws"])
+                if level == 3:
+                    # the x-side gate pre-activations Xe W_ih[:, :E]^T + b_ih of the NEXT theta: W_ih exists since the fork, b_ih
+                    # since the event behind its pass
+                    aux.wait_event(self._bih_ev)
+                    ops.decoder_inputs(self._dims_pre(buf, dims, 64), params, captions, buf["ws"])
                 self._lookup_done.record(aux)
-            self._zero_hi_done = True
+            self._zero_hi_done = clear
+            self._aux_pending = True
         with torch.cuda.stream(self._pre_stream):
             if level == 2:
                 cl = captions
                 if dims.rows:
                     ops.decoder_prepare_rows(dims, cl, 0, buf["ws"])
                 ops.decoder_precompute(dims, params, features, buf["ws"], captions=cl)
+            elif level == 3:     # theta-independent front, then G (pre bit 4 on this call: the x side is the other stream's)
+                ops.decoder_precompute(self._dims_pre(buf, dims, 4), params, features, buf["ws"], captions=captions)
             else:
                 ops.decoder_precompute(dims, params, features, buf["ws"])
             self._pre_done.record(self._pre_stream)
         self._pre_token = ops.precompute_epoch(self.dev)
-        self._theta_pre = theta if level == 2 else None
-        self._pre_key = (_tkey(features), _tkey(captions) if ((level == 2 or lookup) and captions is not None) else None, B, T, P, level)
+        self._theta_pre = theta if level >= 2 else None
+        self._pre_key = (_tkey(features), _tkey(captions) if ((level >= 2 or lookup) and captions is not None) else None, B, T, P, level)
         self._pre_hold = (features, captions)         # announced tensors stay alive: their addresses cannot be recycled
 
     def optimizer_step(self, next_x_style=None, next_style_token=None, next_batch=None, next_domain_input=None):
@@ -805,9 +874,9 @@ class FusedTrainer:
                 # earlier eager step (its event would be waited on by a capturing stream), a prefetched theta
                 if self._pre_key is not None:
                     torch.cuda.current_stream().wait_event(self._pre_done)
-                if getattr(self, "_zero_hi_done", False):       # a side clear of the arena issued by an eager step: join it here;
-                    torch.cuda.current_stream().wait_event(self._lookup_done)      # the captured step clears the whole arena
-                    self._zero_hi_done = False
+                if getattr(self, "_zero_hi_done", False) or self._aux_pending:     # a side clear of the arena / caption-side work issued
+                    torch.cuda.current_stream().wait_event(self._lookup_done)      # by an eager step: join it here; the captured step
+                    self._zero_hi_done = self._aux_pending = False                 # clears the whole arena
                 self._pre_key = self._pre_hold = self._next_key = self._next_hold = None
                 torch.cuda.current_stream().wait_stream(self._pre_stream)
                 g = torch.cuda.CUDAGraph()

@@ -899,6 +899,27 @@ def adam_rank(W, m, v, gfac, afac, coef, lr, step, betas=(0.9, 0.999), eps=1e-8,
                                              L.stream_ptr()), "caphn_adam_rank_gemv_f32")
 
 
+def adam_rank_multi(members, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_scalars=None) -> None:
+    """adam_rank over several members in one launch (the hypernet's small heads are launch-bound one by one).  members: tuples
+    (W, m, v, gfac, afac) or (W, m, v, gfac, afac, next_a, next_bias, next_theta); all with the same number of factors R."""
+    lib = L.load()
+    hp = _hp(lr, betas, eps, step, dev_scalars)
+    jobs = (L.RankJob * len(members))()
+    R = members[0][3].shape[0]
+    for j, mb in zip(jobs, members):
+        W, m, v, gfac, afac = mb[:5]
+        rows, k = W.shape
+        assert gfac.shape == (R, rows) and afac.shape == (R, k) and gfac.stride(1) == 1 and afac.stride(1) == 1
+        j.W, j.m, j.v = L.ptr(W), L.ptr(m), L.ptr(v)
+        j.gfac, j.ldg, j.afac, j.lda = gfac.data_ptr(), gfac.stride(0), afac.data_ptr(), afac.stride(0)
+        j.rows, j.k = rows, k
+        if len(mb) > 5 and mb[5] is not None:
+            na, nb, nt = mb[5:8]
+            assert na.numel() == k and nb.numel() == rows and nt.numel() == rows
+            j.next_a, j.next_bias, j.next_theta = na.data_ptr(), nb.data_ptr(), nt.data_ptr()
+    L.check(lib.caphn_adam_rank_multi_f32(R, len(members), jobs, L.ptr(coef), C.byref(hp), L.stream_ptr()), "caphn_adam_rank_multi_f32")
+
+
 def hyper_forward_acts(shape: HyperShape, p: Dict[str, torch.Tensor], x: torch.Tensor, acts: torch.Tensor) -> None:
     """hn_base and the heads' first layers only (fills acts; no pass over the big second layers)."""
     lib = L.load()

@@ -511,7 +511,9 @@ extern "C" int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn
     const float* f = nullptr;
     // captions given: the generated W_ih / b_ih are final too, so G and the x-side gates can be done as well
     RUN(decoder_precompute(d, p, w, static_cast<float*>(ws_), features, &f, s, captions ? 3 : 1, true));
-    if (captions) RUN(decoder_inputs(d, p, w, static_cast<float*>(ws_), captions, s));
+    // (dims.precomputed bit 4 on THIS call: the x side is issued elsewhere -- caphn_decoder_inputs on another stream, as soon as
+    //  b_ih exists -- so only G is added here)
+    if (captions && !(d->precomputed & 4)) RUN(decoder_inputs(d, p, w, static_cast<float*>(ws_), captions, s));
     Side* sd = side_here();
     if (!sd || sd->post(Side::D_PRE_ALL, s) != CAPHN_OK) return CAPHN_ELAUNCH;
     sd->pre_valid = true;

@@ -632,6 +632,30 @@ __global__ __launch_bounds__(256) void adam_rank_kernel(int R, int rows, int k, 
         }
     }
 }
+// Several SMALL rank-R members in one launch (blockIdx.y = member): the bias heads of the hypernet are two [600, k] matrices, 11 us
+// of launch-bound kernel each on the optimiser's chain.  Same row code; the members share k's width class and R.
+struct RankJob { float* W; float* m; float* v; const float* gfac; size_t ldg; const float* afac; size_t lda; NextGemv nx; int rows, k; };
+struct RankJobs { RankJob j[4]; };
+template <int RB, bool NTL, bool NTS, int QMAX, bool MULTI>
+__global__ __launch_bounds__(256) void adam_rank_jobs_kernel(int R, RankJobs jobs, const float* coef, AdamK K, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 a_lds[];
+    const RankJob& J = jobs.j[blockIdx.y];
+    if ((long)blockIdx.x * 4 * RB >= J.rows) return;          // block-uniform: the grid is sized for the largest member
+    const float c = coef[0];
+    if (K.dev) { K.lr_bc1 = K.dev[0]; K.sqrt_bc2 = K.dev[1]; }
+    const f32x4* a_s = nullptr;
+    if (R > 1 && use_lds) {
+        const int k4 = J.k >> 2;
+        for (int i = threadIdx.x; i < R * k4; i += 256) {
+            const int r = i / k4, cc = i - r * k4;
+            a_lds[i] = reinterpret_cast<const f32x4*>(J.afac + (size_t)r * J.lda)[cc];
+        }
+        __syncthreads();
+        a_s = a_lds;
+    }
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4, lane = threadIdx.x & 63;
+    adam_rank_rows<QMAX, RB, NTL, NTS, MULTI>(R, J.rows, J.k, J.W, J.m, J.v, J.gfac, J.ldg, J.afac, J.lda, c, K, wave_g, nwaves, lane, J.nx, a_s);
+}
 // Long rows of any width / alignment (hypernet.py's heads: k = 11250, 8437 -- rows that are only 8 or 4 byte aligned):
 // one wave per row, lane-contiguous dword streams (256 B per wave instruction whatever the alignment), U columns per
 // lane in flight for each of W, m, v.  The element-linear fallback below (a 64-bit divide per element) moved 1.4 TB/s
@@ -1095,6 +1119,57 @@ extern "C" int caphn_adam_rank_gemv_f32(int R, int rows, int k, float* W, float*
                                         caphn_stream_t stream) {
     if (!next_a || !next_bias || !next_theta) return CAPHN_EINVAL;
     return adam_rank_launch(R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, hp, NextGemv{next_a, next_bias, next_theta}, stream);
+}
+
+extern "C" int caphn_adam_rank_multi_f32(int R, int njobs, const caphn_rank_job* jobs, const float* coef, const caphn_adam_hparams* hp,
+                                         caphn_stream_t stream) {
+    if (njobs <= 0 || !jobs || !coef || !hp || hp->step < 1 || R <= 0 || R > RMAX) return CAPHN_EINVAL;
+    // one launch when the members fit the row kernel's fast path with one width class (and all or none carry the fused GEMV)
+    auto qclass = [](int k) { return k <= 256 ? 1 : k <= 512 ? 2 : k <= 1024 ? 4 : 8; };
+    bool one = njobs >= 2 && njobs <= 4 && g_tune_adam != 0;
+    int maxrows = 0; size_t a_bytes = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const caphn_rank_job& j = jobs[i];
+        if (j.rows <= 0 || j.k <= 0 || !j.W || !j.m || !j.v || !j.gfac || !j.afac) return CAPHN_EINVAL;
+        if ((j.next_a != nullptr) != (j.next_theta != nullptr) || (j.next_a != nullptr) != (j.next_bias != nullptr)) return CAPHN_EINVAL;
+        const bool vec = (j.k % 4 == 0) && (j.lda % 4 == 0) && caphn_aligned16(j.W) && caphn_aligned16(j.m) && caphn_aligned16(j.v) &&
+                         caphn_aligned16(j.afac) && (!j.next_a || caphn_aligned16(j.next_a));
+        one = one && vec && j.k <= 2048 && qclass(j.k) == qclass(jobs[0].k) && ((j.next_a != nullptr) == (jobs[0].next_a != nullptr)) &&
+              j.rows <= 4 * g_tune_adam_cap;
+        maxrows = std::max(maxrows, j.rows);
+        a_bytes = std::max(a_bytes, sizeof(float) * (size_t)R * j.k);
+    }
+    if (!one) {
+        for (int i = 0; i < njobs; ++i) {
+            const caphn_rank_job& j = jobs[i];
+            int rc = adam_rank_launch(R, j.rows, j.k, j.W, j.m, j.v, j.gfac, j.ldg, j.afac, j.lda, coef, hp,
+                                      NextGemv{j.next_a, j.next_bias, j.next_theta}, stream);
+            if (rc != CAPHN_OK) return rc;
+        }
+        return CAPHN_OK;
+    }
+    RankJobs J;
+    for (int i = 0; i < njobs; ++i) {
+        const caphn_rank_job& j = jobs[i];
+        J.j[i] = RankJob{j.W, j.m, j.v, j.gfac, j.ldg, j.afac, j.lda, NextGemv{j.next_a, j.next_bias, j.next_theta}, j.rows, j.k};
+    }
+    const int use_lds = R > 1 && a_bytes <= 60 * 1024;
+    const size_t shm = use_lds ? a_bytes : 0;
+    const AdamK K = make_adam(hp);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int q = qclass(jobs[0].k);
+    const bool gemv = jobs[0].next_a != nullptr;
+    const int RB = gemv ? (q == 1 ? 4 : 2) : (g_tune_adam == 3 ? 1 : 2);       // as adam_rank_launch picks them
+    const dim3 grid((unsigned)((maxrows + 4 * RB - 1) / (4 * RB)), (unsigned)njobs);
+#define RANK_JOBS_Q(RBv, Q) do { \
+        if (R == 1) hipLaunchKernelGGL((adam_rank_jobs_kernel<RBv, true, true, Q, false>), grid, dim3(256), shm, s, R, J, coef, K, use_lds); \
+        else hipLaunchKernelGGL((adam_rank_jobs_kernel<RBv, true, true, Q, true>), grid, dim3(256), shm, s, R, J, coef, K, use_lds); } while (0)
+#define RANK_JOBS(RBv) do { if (q == 1) RANK_JOBS_Q(RBv, 1); else if (q == 2) RANK_JOBS_Q(RBv, 2); else if (q == 4) RANK_JOBS_Q(RBv, 4); \
+                            else RANK_JOBS_Q(RBv, 8); } while (0)
+    if (RB == 4) RANK_JOBS(4); else if (RB == 2) RANK_JOBS(2); else RANK_JOBS(1);
+#undef RANK_JOBS
+#undef RANK_JOBS_Q
+    return caphn_launch_status();
 }
 
 extern "C" int caphn_abi_version(void) { return 1; }

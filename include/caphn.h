@@ -271,7 +271,8 @@ int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_decoder_param
  * init_hidden (init_c) and the hoisted W_a f.  A trainer that knows the next minibatch's features can issue it on
  * another stream while the optimiser streams the hypernet (then set dims.precomputed = 1 for that forward).  With
  * captions it also produces G = f W_ih[:,E:]^T, the embedding lookup and the x-side gate pre-activations, which need
- * the generated W_ih / b_ih of THAT forward (dims.precomputed = 2). */
+ * the generated W_ih / b_ih of THAT forward (dims.precomputed = 2).  dims.precomputed bit 4 given to THIS call: the x side is
+ * left out (the caller issues caphn_decoder_inputs itself, e.g. on a third stream once b_ih exists), G is still produced. */
 int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_params* p, const float* features,
                              const int64_t* captions /* optional, see dims.precomputed */, void* ws, caphn_stream_t stream);
 /* Embedding lookup (with the reference's zeroed first two inputs) and x-side gate pre-activations for all T; needs the
@@ -534,6 +535,18 @@ int caphn_adam_rank_gemv_f32(int R, int rows, int k, float* W, float* m, float* 
                              const float* gfac, size_t ldg, const float* afac, size_t lda,
                              const float* coef, const caphn_adam_hparams* hp,
                              const float* next_a, const float* next_bias, float* next_theta, caphn_stream_t stream);
+/* Several rank-R members in ONE launch (the hypernet's small heads -- the two [3H, k] bias heads -- are launch-bound on the optimiser's
+ * chain): same update as caphn_adam_rank_f32 / _gemv_f32 per member (next_* all NULL or all set).  Members that do not fit the
+ * shared fast path (k % 4, alignment, different width classes) are launched one by one; the result is the same either way. */
+typedef struct caphn_rank_job {
+    float* W; float* m; float* v;             /* [rows, k] */
+    const float* gfac; size_t ldg;            /* [R, rows] row factors, leading dimension */
+    const float* afac; size_t lda;            /* [R, k] column factors */
+    const float* next_a; const float* next_bias; float* next_theta;
+    int rows, k;
+} caphn_rank_job;
+int caphn_adam_rank_multi_f32(int R, int njobs, const caphn_rank_job* jobs, const float* coef, const caphn_adam_hparams* hp,
+                              caphn_stream_t stream);
 /* dst[0..n) = src[0..n) (n % 4 == 0, 16-byte aligned) with the access pattern of the streaming kernels (non-temporal dwordx4): the
  * copy microbenchmark behind bench.py's roofline.copy_ceiling_gbps. */
 int caphn_stream_copy_f32(size_t n, const float* src, float* dst, caphn_stream_t stream);

@@ -413,6 +413,31 @@ def test_adam_rank_long_odd_rows(ops, R, rows, k, fused):
         assert maxdiff(th.cpu(), (Wd.cpu().double() @ na.double() + nb.double()).float()) < 2e-5 * (k / 1000) ** 0.5 + 1e-5
 
 
+@pytest.mark.parametrize("R,fused,shapes", [(1, True, [(600, 200), (600, 200)]), (2, False, [(600, 200), (37, 132), (64, 8)]),
+                                             (1, True, [(600, 200), (90, 480)]), (1, False, [(50, 6), (9, 7)])])
+def test_adam_rank_multi_equals_one_by_one(ops, R, fused, shapes):
+    """Several rank-R members in one launch (the hypernet's two bias heads) == caphn_adam_rank(_gemv)_f32 member by member, bit for
+    bit; members of different width classes / unaligned widths take the one-by-one path inside the call."""
+    g = torch.Generator().manual_seed(len(shapes) * 10 + R)
+    coef = torch.tensor([0.6, 0.0], device=DEV)
+    one, many = [], []
+    for rows, k in shapes:
+        W = torch.randn(rows, k, generator=g).to(DEV)
+        gf, af = (torch.randn(R, rows, generator=g) * 0.1).to(DEV), torch.randn(R, k, generator=g).to(DEV)
+        na, nb = torch.randn(k, generator=g).to(DEV), torch.randn(rows, generator=g).to(DEV)
+        for lst in (one, many):
+            lst.append([W.clone(), torch.zeros(rows, k, device=DEV), torch.zeros(rows, k, device=DEV), gf, af] +
+                       ([na, nb, torch.zeros(rows, device=DEV)] if fused and k % 4 == 0 else []))
+    for step in (1, 2):
+        for j in one:
+            kw = dict(next_a=j[5], next_bias=j[6], next_theta=j[7]) if len(j) > 5 else {}
+            ops.adam_rank(j[0], j[1], j[2], j[3], j[4], coef, 1e-3, step, **kw)
+        ops.adam_rank_multi(many, coef, 1e-3, step)
+    for a, b in zip(one, many):
+        for x, y in zip(a[:3] + a[7:], b[:3] + b[7:]):
+            assert torch.equal(x, y)
+
+
 def test_cross_entropy_in_place_reads_target_logit_before_overwrite(ops):
     """d logits written over the logits (the engine's layout): the target logit of a row must be read before any wave of
     that row stores.  A delayed load showed up as a reported loss off by ~0.2 / n on some runs (gradients unaffected);

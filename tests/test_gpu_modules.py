@@ -399,10 +399,12 @@ def test_next_precompute_overlaps_optimizer(name):
     tb = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
     tc = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
     tc.overlap_level = 2
+    te = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
+    te.overlap_level = 3         # (the default) split front: G behind the W_ih pass, x-side gates behind the b_ih pass
     caps2 = caps.clone(); caps2[:, 2] = (caps2[:, 2] + 3) % dims.V
     cseq = [caps, caps2, caps, caps2, caps2]         # level 2 also announces the captions (last one wrong again)
     cann = [caps2, caps, caps2, caps, None]
-    la, lb, lc, ld = [], [], [], []
+    la, lb, lc, ld, le = [], [], [], [], []
     td = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
     for i, f in enumerate(seq):
         la.append(float(ta.step(f, caps, x_style=xs, style_token=tok)[0]))
@@ -413,12 +415,19 @@ def test_next_precompute_overlaps_optimizer(name):
         ld.append(float(td.step(f, cseq[i], x_style=xs, style_token=tok)[0]))
         lc.append(float(tc.step(f, cseq[i], x_style=xs, style_token=tok, next_x_style=xs, next_style_token=tok,
                                 next_features=ann[i], next_captions=cann[i])[0]))
+        le.append(float(te.step(f, cseq[i], x_style=xs, style_token=tok, next_x_style=xs, next_style_token=tok,
+                                next_features=ann[i], next_captions=cann[i])[0]))
         if ann[i] is not None:
             assert tc._pre_key is not None and tc._pre_key[-1] == 2
+            assert te._pre_key is not None and te._pre_key[-1] == 3
     assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
     assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 2e-5
     assert max(abs(a - b) for a, b in zip(ld, lc)) < 2e-5, (ld, lc)
     assert maxdiff(td.flat_p.cpu(), tc.flat_p.cpu()) < 2e-5
+    assert max(abs(a - b) for a, b in zip(ld, le)) < 2e-5, (ld, le)
+    assert maxdiff(td.flat_p.cpu(), te.flat_p.cpu()) < 2e-5
+    for a, b in zip(td.W2, te.W2):
+        assert maxdiff(a.data.cpu(), b.data.cpu()) < 2e-5
 
 
 @pytest.mark.parametrize("B,T,P", [(1, 1, 1), (1, 2, 1), (2, 3, 2), (3, 2, 64), (1, 5, 65)])
