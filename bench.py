@@ -343,7 +343,7 @@ def main():
     from caphn.engine import FusedTrainer
     from caphn import _lib
     from caphn import ops as ops_mod
-    for kv in args.tune:
+    for kv in list(args.tune) + [t for t in os.environ.get("CAPHN_TUNE", "").split(",") if t]:
         k, v = kv.split("=")
         assert _lib.load().caphn_tune(int(k), int(v)) == 0
     if args.dtype != "f32":
@@ -514,6 +514,7 @@ def main():
     off = args.warmup + spin["steps"]          # continue the batch cycle, so the announced next batch is the one that comes
     for i in range(args.steps):
         loss = run_step(off + i)
+    t_host = time.perf_counter() - t0          # the host has ENQUEUED the timed steps (how far it runs ahead of the GPU)
     barrier()
     dt = time.perf_counter() - t0
     ops.adam_rank = orig
@@ -570,7 +571,7 @@ def main():
                                       (" (one-rank RCCL group, collectives forced)" if forced else ""), "launch": "hipGraph" if use_graph else "eager",
                        "next_theta_in_adam_pass": not (use_graph or args.no_prefetch),
                        "next_precompute_beside_adam": not (use_graph or args.no_prefetch or args.no_overlap),
-                       "spinup_steps": spin["steps"], "cpu_affinity": numa,
+                       "spinup_steps": spin["steps"], "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 4), "cpu_affinity": numa,
                        "final_loss": final_loss},
             "roofline": {"bound": "hbm", "kernel": "adam_rank_kernel(hn_heads.0.2.weight)",
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

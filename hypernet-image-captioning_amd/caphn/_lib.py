@@ -52,7 +52,7 @@ class DecoderGrads(C.Structure):
 
 class AdamHParams(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("step", C.c_int), ("dev_scalars", c_fp)]
+                ("step", C.c_int), ("dev_scalars", c_fp), ("zero_gfac", C.c_int)]
 
 
 class RankJob(C.Structure):

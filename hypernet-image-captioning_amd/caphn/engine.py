@@ -115,7 +115,7 @@ class FusedTrainer:
         self._gfac_all = None
         self._acts_all = None
         self.overlap_after_head = 0      # the side stream forks after this head's Adam pass (-1: before the first)
-        self.overlap_level = int(os.environ.get("CAPHN_OVERLAP_LEVEL", "1"))
+        self.overlap_level = int(os.environ.get("CAPHN_OVERLAP_LEVEL", "4"))
         # 1: the theta-independent front (feature_fc / init_hidden / W_a f) forked after the head-0 pass.
         # 2: the WHOLE front, forked after the W_ih / b_ih / b_hh passes, beside the W_hh pass (round 2: no gain -- feature_fc does
         #    not fit beside one 150 us pass).
@@ -125,6 +125,10 @@ class FusedTrainer:
         self._bih_ev = None
         self._aux_pending = False
         self._main_ev = self._zero_lo_done = None
+        self.zero_by_adam = os.environ.get("CAPHN_ZERO_BY_ADAM", "1") == "1"
+        self._zero_lo_by_adam = False
+        self._aux_joined = False
+        self.ctx_in_forward = os.environ.get("CAPHN_CTX_IN_FORWARD", "0") == "1"
 
     # ------------------------------------------------------------------ parameter arenas
     def _build_arena(self):
@@ -397,9 +401,10 @@ class FusedTrainer:
         # d theta as their row factor): only that head of the arena is cleared here
         zero_lo_only = bool(getattr(self, "_zero_hi_done", False))
         self._zero_hi_done = False
+        joined, self._aux_joined = self._aux_joined and self._pre_key is not None, False
         if zero_lo_only or self._aux_pending:   # this stream must not run ahead of the side clear (nothing has written the arena since)
-            torch.cuda.current_stream().wait_event(self._lookup_done)      # / of the caption-side work in the workspace
-        self._aux_pending = False
+            torch.cuda.current_stream().wait_event(self._lookup_done)      # / of the caption-side work in the workspace (joined:
+        self._aux_pending = False                                          # that event also covers the precompute stream)
         theta = getattr(self, "_theta", None)
         if theta is None:
             theta = self._theta = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)
@@ -451,12 +456,16 @@ class FusedTrainer:
                     pre |= 16     # bit 16: the forward composite waits for the side stream's precompute itself, piecewise
                                   # (feature_fc output before G, the rest before the recurrent kernel).  The library keeps those
                                   # events per DEVICE: only valid while nobody has issued another precompute since ours
-            if not (pre & 16):
+            if not (pre & 16) and not joined:
                 torch.cuda.current_stream().wait_event(self._pre_done)      # even if the announced batch did not come
             if pre == 7:
                 rows_done = True
         zero_lo_side = False
-        if zero_lo_only:
+        lo_done, self._zero_lo_by_adam = self._zero_lo_by_adam, False
+        if lo_done:                    # the rank-1 passes of the last optimiser step cleared d theta behind their reads
+            if not zero_lo_only:
+                ops.zero_(self.flat_g[_up4(self.theta_size):])
+        elif zero_lo_only:
             # d theta was the rank-1 passes' row factor until a moment ago and is written again by the backward's weight-gradient
             # GEMMs, half a millisecond from now: its clear goes to the caption-side stream, behind this point of the caller's
             # stream, and is joined in front of the backward (a dependency satisfied that early costs nothing; in line it was a
@@ -477,8 +486,9 @@ class FusedTrainer:
         dv = buf.get("dims_variants") if dims is buf["dims"] else None
         if dv is None:
             import dataclasses
-            # bits 8 and 32 on both sides of the step: d Hs zero-filled by the forward's prep kernel, ctx left by the forward
-            dv = {p: dataclasses.replace(dims, pre=p | 8 | 32) for p in (0, 1, 5, 7, 21)}
+            # bit 8 on both sides of the step: d Hs zero-filled by the forward's prep kernel (bit 32 -- ctx left by the forward --
+            # is no longer used here: the backward forms ctx on its vocabulary-gradient branch, beside BPTT)
+            dv = {p: dataclasses.replace(dims, pre=p | 8 | (32 if self.ctx_in_forward else 0)) for p in (0, 1, 5, 7, 21)}
             if dims is buf["dims"]:          # (with decoder dropout the dims carry a fresh seed every step: not cached)
                 buf["dims_variants"] = dv
         fdims = dv[pre]
@@ -682,6 +692,18 @@ class FusedTrainer:
                                  1.0 / R, self._coef, self.lr, step, self.betas, self.eps,
                                  dev_scalars=self._adam_dev if self._graph_scalars else None, ce=ce)
         prefetch = (next_x_style is not None) or (next_style_token is not None) or (next_domain_input is not None)
+        known = (prefetch and next_batch is not None and next_batch[1] is not None and len(segs) == 4 and
+                 next_batch[1].dtype == torch.int64 and next_batch[1].is_contiguous())
+        full = self.overlap_level == 2 and known
+        split = self.overlap_level >= 3 and known and self.overlap_after_head == 0
+        # level 4: the theta-independent front does not wait for the W_ih pass at all -- it is forked HERE, behind the dense Adam
+        # launch and in front of the three tiny GEMVs of the next activations, so that its first GEMM has its workgroups on the chip
+        # before the W_ih pass arrives (ten microseconds of head start: 84 us instead of 256 for feature_fc.0 beside a rank-1 pass);
+        # beside the LAST pass only the two GEMMs that need theta are left (G, x-side gates: done long before the pass ends)
+        early = split and self.overlap_level >= 4
+        if early:
+            self._precompute_next(*next_batch, level=1, lookup_dp=True)
+            early = self._pre_key is not None and self._pre_key[1] is not None     # (the captions were looked up)
         if prefetch:
             # the small layers (and the style row of the embedding / the front-end) are already updated: compute the next
             # step's head activations, then let the rank-1 Adam pass emit theta_next = W2' a' + b2' row by row
@@ -703,13 +725,9 @@ class FusedTrainer:
         # Order of the rank-1 passes when the next minibatch is known: everything the front of the next forward needs
         # (W_ih, b_ih -- heads 0, 2; and the tiny b_hh head) first, then the side stream starts the next forward's
         # front end while the W_hh pass (head 1, HBM-bound) is still streaming.
-        known = (prefetch and next_batch is not None and next_batch[1] is not None and len(segs) == 4 and
-                 next_batch[1].dtype == torch.int64 and next_batch[1].is_contiguous())
-        full = self.overlap_level == 2 and known
-        split = self.overlap_level >= 3 and known and self.overlap_after_head == 0
         order = [0, 2, 3, 1] if (full or split) else list(range(len(segs)))
         fork_after = order[-2] if full else self.overlap_after_head
-        if next_batch is not None and not full and self.overlap_after_head < 0:
+        if next_batch is not None and not full and not early and self.overlap_after_head < 0:
             self._precompute_next(*next_batch, level=1)
         # consecutive small heads (the bias heads: [3H, k]) go out as ONE launch -- each is ~11 us of launch-bound kernel
         groups = []
@@ -720,6 +738,9 @@ class FusedTrainer:
             else:
                 groups.append(([i], small))
         dev_sc = self._adam_dev if self._graph_scalars else None
+        # one rank, the row factor is d theta in the arena itself: every pass clears its rows behind the read (it is their last
+        # reader), so the next forward has no fill of d theta to launch in front of its recurrent kernel
+        zg = self.zero_by_adam and R == 1 and not dp.active(self.group) and self.theta_size % 4 == 0
         for members, _ in groups:
             jobs = []
             for i in members:
@@ -731,9 +752,10 @@ class FusedTrainer:
             if len(jobs) == 1:
                 j = jobs[0]
                 kw = dict(next_a=j[5], next_bias=j[6], next_theta=j[7]) if prefetch else {}
-                ops.adam_rank(j[0], j[1], j[2], j[3], j[4], self._coef, self.lr, step, self.betas, self.eps, dev_scalars=dev_sc, **kw)
+                ops.adam_rank(j[0], j[1], j[2], j[3], j[4], self._coef, self.lr, step, self.betas, self.eps, dev_scalars=dev_sc,
+                              zero_gfac=zg, **kw)
             else:
-                ops.adam_rank_multi(jobs, self._coef, self.lr, step, self.betas, self.eps, dev_scalars=dev_sc)
+                ops.adam_rank_multi(jobs, self._coef, self.lr, step, self.betas, self.eps, dev_scalars=dev_sc, zero_gfac=zg)
             if fork_after in members and next_batch is not None:
                 # the side stream starts HERE on the device (an event), but its launches are enqueued after the remaining passes:
                 # the host otherwise spends ~50 us on the precompute's launches before it gets to the next pass
@@ -747,7 +769,10 @@ class FusedTrainer:
                 self._bih_ev.record()
             if fork_after in members and next_batch is not None and not (self.fork_late or split):
                 self._precompute_next(*next_batch, level=fork_level)
-        if next_batch is not None and fork_after >= 0 and fork_after in order and (self.fork_late or split):
+        self._zero_lo_by_adam = zg
+        if early:
+            self._front_theta_next(*next_batch)
+        elif next_batch is not None and fork_after >= 0 and fork_after in order and (self.fork_late or split):
             self._precompute_next(*next_batch, level=fork_level, after=self._fork_ev)
         return self._coef
 
@@ -763,7 +788,37 @@ class FusedTrainer:
             d = c[bits] = dataclasses.replace(dims, pre=bits)
         return d
 
-    def _precompute_next(self, features, captions, T, level=1, after=None):
+    def _front_theta_next(self, features, captions, T):
+        """Second half of the split front (overlap_level 4; the first half is _precompute_next(level=1), issued before the rank-1
+        passes): G on the precompute stream behind the W_ih pass, the x-side gate GEMM on the caption-side stream behind the b_ih
+        pass.  Upgrades the announcement to level 3."""
+        B, P, _ = features.shape
+        buf = self._buffers(B, T, P)
+        dims = buf["dims"]
+        theta = self._theta_next
+        params = self._dec_tensors(theta, grads=False)
+        aux = self._aux_stream
+        aux.wait_event(self._bih_ev)
+        with torch.cuda.stream(aux):
+            ops.decoder_inputs(self._dims_pre(buf, dims, 64), params, captions, buf["ws"])
+        self._aux_pending = True
+        self._pre_stream.wait_event(self._fork_ev)
+        with torch.cuda.stream(self._pre_stream):
+            # (pre bits on this call: 1 = the theta-independent part is in the workspace already, 4 = the x side is the other stream's)
+            ops.decoder_precompute(self._dims_pre(buf, dims, 1 | 4), params, features, buf["ws"], captions=captions)
+            self._pre_done.record(self._pre_stream)
+        # the caption-side stream joins the precompute stream (G and the gate GEMM ran side by side): the next forward then waits
+        # for ONE event in front of its recurrent kernel -- every wait on the caller's stream is a packet between the last Adam
+        # pass and that kernel
+        aux.wait_event(self._pre_done)
+        self._lookup_done.record(aux)
+        self._aux_joined = True
+        self._pre_token = ops.precompute_epoch(self.dev)
+        self._theta_pre = theta
+        kf, kc, kB, kT, kP, _ = self._pre_key
+        self._pre_key = (kf, kc, kB, kT, kP, 3)
+
+    def _precompute_next(self, features, captions, T, level=1, after=None, lookup_dp=False):
         """The decoder's dense parameters are final (adam_dense ran) and the workspace is free (backward is done):
         run the front of the next minibatch's forward on a side stream while the remaining Adam pass streams the
         hypernet (HBM-bound).  level 1: feature_fc / init_hidden / W_a f (theta-independent).  level 2 (next theta's
@@ -782,7 +837,7 @@ class FusedTrainer:
         else:
             self._pre_stream.wait_stream(main)
         lookup = (level in (1, 3) and captions is not None and captions.dtype == torch.int64 and captions.is_contiguous()
-                  and tuple(captions.shape) == (B, T) and (level == 3 or not dp.active(self.group)))
+                  and tuple(captions.shape) == (B, T) and (level == 3 or lookup_dp or not dp.active(self.group)))
         if level == 3 and not lookup:
             level = 1
         if lookup:
@@ -879,7 +934,8 @@ class FusedTrainer:
                     self._zero_hi_done = self._aux_pending = False                 # clears the whole arena
                 self._pre_key = self._pre_hold = self._next_key = self._next_hold = None
                 torch.cuda.current_stream().wait_stream(self._pre_stream)
-                g = torch.cuda.CUDAGraph()
+                self._zero_lo_by_adam = False       # the captured forward clears the WHOLE arena: a replay must not depend on what
+                g = torch.cuda.CUDAGraph()          # ran before it (an eager forward_backward without its optimiser step)
                 with torch.cuda.graph(g):
                     loss = self.forward_backward(features, captions, x_style, style_token, defer_loss=True)
                     self._optimizer_impl()

@@ -852,9 +852,9 @@ def clip_coef(partial: torch.Tensor, extra: Optional[torch.Tensor], max_norm: fl
     return out
 
 
-def _hp(lr, betas, eps, step, dev_scalars=None):
+def _hp(lr, betas, eps, step, dev_scalars=None, zero_gfac=False):
     return L.AdamHParams(float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
-                         dev_scalars.data_ptr() if dev_scalars is not None else None)
+                         dev_scalars.data_ptr() if dev_scalars is not None else None, 1 if zero_gfac else 0)
 
 
 def adam_scalars(lr, betas, step):
@@ -877,12 +877,12 @@ def adam_dense(p, m, v, g, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_sca
 
 
 def adam_rank(W, m, v, gfac, afac, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_scalars=None,
-              next_a=None, next_bias=None, next_theta=None) -> None:
+              next_a=None, next_bias=None, next_theta=None, zero_gfac=False) -> None:
     """Adam on W [rows,k] with gradient coef * sum_r gfac[r,:,None] * afac[r,None,:] (never materialised).
     With next_a / next_bias / next_theta the pass also emits next_theta = W' next_a + next_bias (the next
-    step's forward GEMV on the updated weights, at no extra HBM traffic)."""
+    step's forward GEMV on the updated weights, at no extra HBM traffic).  zero_gfac (one factor only): the pass clears gfac."""
     lib = L.load()
-    hp = _hp(lr, betas, eps, step, dev_scalars)
+    hp = _hp(lr, betas, eps, step, dev_scalars, zero_gfac)
     rows, k = W.shape
     R = gfac.shape[0]
     assert gfac.shape[1] == rows and afac.shape[1] == k and afac.shape[0] == R
@@ -899,11 +899,11 @@ def adam_rank(W, m, v, gfac, afac, coef, lr, step, betas=(0.9, 0.999), eps=1e-8,
                                              L.stream_ptr()), "caphn_adam_rank_gemv_f32")
 
 
-def adam_rank_multi(members, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_scalars=None) -> None:
+def adam_rank_multi(members, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_scalars=None, zero_gfac=False) -> None:
     """adam_rank over several members in one launch (the hypernet's small heads are launch-bound one by one).  members: tuples
     (W, m, v, gfac, afac) or (W, m, v, gfac, afac, next_a, next_bias, next_theta); all with the same number of factors R."""
     lib = L.load()
-    hp = _hp(lr, betas, eps, step, dev_scalars)
+    hp = _hp(lr, betas, eps, step, dev_scalars, zero_gfac)
     jobs = (L.RankJob * len(members))()
     R = members[0][3].shape[0]
     for j, mb in zip(jobs, members):

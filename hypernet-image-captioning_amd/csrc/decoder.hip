@@ -510,7 +510,8 @@ extern "C" int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float* f = nullptr;
     // captions given: the generated W_ih / b_ih are final too, so G and the x-side gates can be done as well
-    RUN(decoder_precompute(d, p, w, static_cast<float*>(ws_), features, &f, s, captions ? 3 : 1, true));
+    // (dims.precomputed bit 1 on THIS call: the theta-independent part was issued by an earlier call -- only G is left)
+    RUN(decoder_precompute(d, p, w, static_cast<float*>(ws_), features, &f, s, (captions ? 3 : 1) & ~(d->precomputed & 1), true));
     // (dims.precomputed bit 4 on THIS call: the x side is issued elsewhere -- caphn_decoder_inputs on another stream, as soon as
     //  b_ih exists -- so only G is added here)
     if (captions && !(d->precomputed & 4)) RUN(decoder_inputs(d, p, w, static_cast<float*>(ws_), captions, s));
@@ -685,6 +686,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
         RUN(sd.milestone(CAPHN_MS_VOCAB, sd.s(0)));
     }
     const bool dhs_zero = (d->precomputed & 8) != 0;      // the forward of this step left d Hs zero-filled (dims.precomputed bit 8)
+    bool ctx_side = false;
     if (rmap) {   // rows of ignored targets have d logits == 0: dHs of those rows is zero, the others are gathered
         if (!dhs_zero) RUN(caphn_zero_f32(ws + w.dHs, (size_t)BT * H, s));
         RUN(caphn_gemm_mapped(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, pick_splitk(BT, H, V),
@@ -694,6 +696,16 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     if (!late && !wg_first) {
         // ... or only beside BPTT: dHs = dlogits W_fc sits on the chain into BPTT and ran 135 instead of ~105 us with the
         // vocabulary gradients streaming the same 99 MB of d logits next to it; BPTT alone is long enough to cover them
+        // the context vectors ctx_t = sum_p alpha_tp f_p (second operand of dW_ih, which the forward never forms) go to a branch of
+        // their own, beside BPTT: in front of the dW_ih GEMM they were 27 us on the chain to d theta, behind the logits GEMM in the
+        // forward (dims.precomputed bit 32) 9 us + a launch gap between the loss and BPTT; here nothing waits for them (beside BPTT
+        // the kernel is starved to ~180 us and still ends before BPTT does)
+        if (!(d->precomputed & 32) && sd.s(0) != s && sd.s(2) != s) {
+            RUN(sd.fork_many({0, 2}));
+            RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, EF, sd.s(2)));
+            RUN(sd.record(5, sd.s(2)));
+            ctx_side = true;
+        } else
         RUN(sd.forkto(0));
         RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, sd.s(0), gz));
         RUN(sd.milestone(CAPHN_MS_VOCAB, sd.s(0)));
@@ -753,7 +765,8 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     }
     // sT -- input weights dW_ih = dgi^T [Xe | ctx] (ctx lands beside the embeddings, so this is ONE GEMM: two back to back on the
     // chain to d theta cost 72 + 57 us)
-    if (!(d->precomputed & 32)) RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, EF, sT));      // (else: left by the forward)
+    if (ctx_side) RUN(sd.wait(5, sT));
+    else if (!(d->precomputed & 32)) RUN(caphn_launch_ctx(B, T, P, F, ws + w.alphas, f, ws + w.ctx, EF, sT));      // (else: left by the forward)
     if (lstm) RUN(gemm_auto(1, 0, GH, EF, BT, dgi, GH, ws + w.Xe, EF, g->w_ih, EF, nullptr, 0, sT, nullptr, 0, gz));
     else RUN(wgrad_bias(GH, EF, BT, dgi, GH, ws + w.Xe, EF, g->w_ih, EF, g->b_ih, nullptr, cw1, sT, gz));      // + db_ih
     // b2 -- recurrent weights dW_hh = dgh^T Hprev (+ db_hh), then the embedding gradient

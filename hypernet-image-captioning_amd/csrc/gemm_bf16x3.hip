@@ -289,7 +289,9 @@ template <int BM, int BN, bool TA, bool TB, int MODE>
 __device__ __forceinline__ void gemm_bf16x3_body(GemmArgs g) {
     constexpr bool PL = MODE == 1;
     constexpr bool SINGLE = MODE == 2;
-    constexpr bool DB = MODE == 3;          // MODE 0 with TWO LDS images of a slab (ping-pong): see mainloop_db
+    constexpr bool WS = MODE == 5;          // wave-specialised: 512 threads -- waves 4..7 load / split / stage, waves 0..3 only read
+                                            // fragments and issue MFMAs; two LDS images, one barrier per slab (see the WS loop)
+    constexpr bool DB = MODE == 3 || WS;    // MODE 0 with TWO LDS images of a slab (ping-pong): see mainloop_db
     constexpr bool TWO = MODE == 4;         // two planes (hi + mid, 16 significand bits), three products: the bf16x2 side mode
     using TileA = TileS<BM, !TA>;
     using TileB = TileS<BN, TB>;
@@ -301,7 +303,9 @@ __device__ __forceinline__ void gemm_bf16x3_body(GemmArgs g) {
     __bf16* As1 = DB ? lds + TILE_ELEMS : As;
     __bf16* Bs1 = DB ? lds + TILE_ELEMS + TileA::ELEMS : Bs;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (WS: `tid` is the index inside the role's 256 threads -- the staging code and the multiply / epilogue code both count to 256)
+    const bool producer = WS && threadIdx.x >= 256;
+    const int tid = WS ? (threadIdx.x & 255) : threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, kh = lane >> 5;
 #ifdef CAPHN_GEMM_PROFILE
@@ -579,6 +583,37 @@ __device__ __forceinline__ void gemm_bf16x3_body(GemmArgs g) {
                 __syncthreads();
             }
         }
+    } else if constexpr (WS) {
+        // Wave-specialised ping-pong: in iteration i the producer waves split and store slab i + 1 into image (i + 1) & 1 (its
+        // registers were requested two iterations ago) and request slab i + 3, while the consumer waves multiply slab i out of
+        // image i & 1; ONE workgroup barrier per slab orders both hand-overs.  The consumers' instruction stream is fragment reads
+        // and MFMAs only -- the split arithmetic (4.5 vector instructions per element) and the global-load waits live in other
+        // waves of the same SIMD, so the hardware overlaps them instead of the compiler's schedule inside one wave.
+        auto loop = [&](auto fc) {
+            constexpr bool F = decltype(fc)::value;
+            const int last = slab1 - 1;
+            if (producer) {
+                gload(ra0, rb0, slab0, fc);
+                if (F || slab0 + 1 < slab1) gload(ra1, rb1, min(slab0 + 1, last), fc);
+                stage(ra0, rb0, slab0, fc, As, Bs);
+                if (F || slab0 + 2 < slab1) gload(ra0, rb0, min(slab0 + 2, last), fc);
+            }
+            __syncthreads();
+            for (int slab = slab0; slab < slab1; slab += 2) {
+                if (producer) {
+                    if (slab + 1 < slab1) stage(ra1, rb1, slab + 1, fc, As1, Bs1);
+                    if (F || slab + 3 < slab1) gload(ra1, rb1, min(slab + 3, last), fc);
+                } else multiply(slab, As, Bs);
+                __syncthreads();
+                if (slab + 1 >= slab1) break;
+                if (producer) {
+                    if (slab + 2 < slab1) stage(ra0, rb0, slab + 2, fc, As, Bs);
+                    if (F || slab + 4 < slab1) gload(ra0, rb0, min(slab + 4, last), fc);
+                } else multiply(slab + 1, As1, Bs1);
+                __syncthreads();
+            }
+        };
+        if (fast) loop(std::true_type{}); else loop(std::false_type{});
     } else if constexpr (DB) {
         // Ping-pong LDS: slab s is multiplied out of image s & 1 while slab s + 1 is split and stored into the other image -- no
         // barrier between a slab's MFMAs and the next slab's staging, ONE barrier per slab instead of two, and a wave that has
@@ -631,10 +666,13 @@ __device__ __forceinline__ void gemm_bf16x3_body(GemmArgs g) {
             constexpr int CG = BM / 4, RG = 256 / CG;      // column groups, threads per group
             float* red = reinterpret_cast<float*>(lds);
             const int cg = tid % CG, rg = tid / CG;
+            const bool mine = !WS || producer;             // (WS: the staging waves hold the column sums)
+            if (mine) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) red[rg * BM + cg * 4 + e] = csum[e];
+                for (int e = 0; e < 4; ++e) red[rg * BM + cg * 4 + e] = csum[e];
+            }
             __syncthreads();
-            if (tid < BM && m0 + tid < g.M) {
+            if (mine && tid < BM && m0 + tid < g.M) {
                 float v = 0.f;
                 for (int r = 0; r < RG; ++r) v += red[r * BM + tid];
                 atomicAdd(g.colsum_a + m0 + tid, v);
@@ -642,6 +680,7 @@ __device__ __forceinline__ void gemm_bf16x3_body(GemmArgs g) {
         }
     }
 
+    if (WS && producer) return;              // (no barrier below this point)
     if constexpr (DUAL) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[0][0][r];
@@ -740,28 +779,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 template <int BM, int BN, bool TA, bool TB, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void gemm_bf16x3_kernel_w6(GemmArgs g) { gemm_bf16x3_body<BM, BN, TA, TB, MODE>(g); }
 
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_bf16x3_kernel_ws(GemmArgs g) { gemm_bf16x3_body<BM, BN, TA, TB, 5>(g); }
+
 template <int BM, int BN, bool TA, bool TB, int PL>
 int launch_one(const GemmArgs& g, hipStream_t s) {
     using TileA = TileS<BM, !TA>;
     using TileB = TileS<BN, TB>;
-    constexpr size_t lds_tiles = sizeof(__bf16) * (TileA::ELEMS + TileB::ELEMS) * (PL == 3 ? 2 : 1);
+    constexpr size_t lds_tiles = sizeof(__bf16) * (TileA::ELEMS + TileB::ELEMS) * ((PL == 3 || PL == 5) ? 2 : 1);
     size_t lds = lds_tiles;
     if (g.kmap_lds > 0) lds += sizeof(int) * (size_t)g.kmap_lds;
     static bool attr_set[64];              // one flag per instantiation AND device (the attribute is per device)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CAPHN_ELAUNCH;
     if (lds_tiles + 16384 > 48 * 1024 && !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<BM, BN, TA, TB, PL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_tiles + 16384)) != hipSuccess) return CAPHN_ELAUNCH;
+        const void* fn = PL == 5 ? reinterpret_cast<const void*>(gemm_bf16x3_kernel_ws<BM, BN, TA, TB>)
+                                 : reinterpret_cast<const void*>(gemm_bf16x3_kernel<BM, BN, TA, TB, PL == 5 ? 0 : PL>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_tiles + 16384)) != hipSuccess) return CAPHN_ELAUNCH;
         attr_set[dev] = true;
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk > 1 ? g.splitk : 1);
+    if constexpr (PL == 5) {
+        hipLaunchKernelGGL((gemm_bf16x3_kernel_ws<BM, BN, TA, TB>), grid, dim3(512), lds, s, g);
+        return caphn_launch_status();
+    } else {
     if constexpr (BM == 64 && PL == 0) {
         if (g_tune_gemm_waves == 5) { hipLaunchKernelGGL((gemm_bf16x3_kernel_w5<BM, BN, TA, TB, PL>), grid, dim3(256), lds, s, g); return caphn_launch_status(); }
         if (g_tune_gemm_waves == 6) { hipLaunchKernelGGL((gemm_bf16x3_kernel_w6<BM, BN, TA, TB, PL>), grid, dim3(256), lds, s, g); return caphn_launch_status(); }
     }
     hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, PL>), grid, dim3(256), lds, s, g);
     return caphn_launch_status();
+    }
 }
 template <int BM, int BN, int PL>
 int launch_cfg(const GemmArgs& g, int ta, int tb, hipStream_t s) {
@@ -781,6 +829,7 @@ int g_tune_gemm_single = 0;   // reduced-precision side modes (caphn_tune key 11
 int g_tune_gemm_order = 1;    // tile walk inside an XCD: 0 n fastest always, 1 (default) m fastest when B outgrows L2 and A is the smaller, 2 m fastest always
 int g_tune_gemm_xcd = 1;      // 1 (default): XCD-aware tile order
 int g_tune_gemm_waves = 0;    // 0 (default): as the compiler allocates (4 waves per SIMD); 5 / 6: the 64x64 six-product kernel compiled for that occupancy
+int g_tune_gemm_ws = 0;       // wave-specialised kernel (MODE 5; caphn_tune key 29): 0 off, 64 / 128: that tile for every layout
 int g_tune_gemm_db = 0;       // layouts that run the 64x64 tile with ping-pong LDS images (MODE 3): bit 0 NT, bit 1 NN, bit 2 TN
 int g_tune_gemm_fast = 1;     // 1 (default): branch-free loads (static vmcnt) where alignment allows
 // Tile choice: 128x128 when that alone gives >= 512 workgroups and K >= 512, else 64x64 (four workgroups per CU:
@@ -853,6 +902,8 @@ int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
         if (tiles128 >= 512) return launch_cfg<128, 128, 4>(g, ta, tb, s);
         return launch_cfg<64, 64, 4>(g, ta, tb, s);
     }
+    if (g_tune_gemm_ws == 128 && !(ta && tb)) return launch_cfg<128, 128, 5>(g, ta, tb, s);
+    if (g_tune_gemm_ws == 64 && !(ta && tb)) return launch_cfg<64, 64, 5>(g, ta, tb, s);
     if (tiles128 >= 512) return launch_cfg<128, 128, 0>(g, ta, tb, s);
     // ping-pong LDS images for the 64x64 tile (caphn_tune key 23: bit 0 NT, bit 1 NN, bit 2 TN layouts)
     const int lay = (!ta && tb) ? 1 : (!ta && !tb) ? 2 : (ta && !tb) ? 4 : 0;

@@ -164,6 +164,92 @@ __global__ __launch_bounds__(256) void gemv_fwd_kernel(GemvJobs jobs) {
         gemv_rows_oct(J, lb, tid);
     }
 }
+
+// ---------------------------------------------------------------- hn_base and the heads' first layers in ONE launch
+// x -> a0 = lrelu(Wb0 x + b) -> base = lrelu(Wb2 a0 + b) -> a_i = lrelu(W1_i base + b1_i): three dependent GEMVs of 40-220 k
+// multiply-adds each.  As three launches they are 20 us of kernels and two launch gaps on the optimiser's chain, between the dense
+// Adam launch and the first rank-1 pass (which needs a_i of the NEXT step).  Here every workgroup computes a0 and base for itself
+// in LDS (80 k multiply-adds, 320 KB of L2 reads per workgroup: nothing to exchange, no barrier between workgroups) and then its
+// share of the heads' rows; workgroup 0 also stores x, a0 and base.  Per row the arithmetic is gemv_rows_wave's (lane partials
+// over 16-byte chunks in order, wave_sum): results are bit-identical to the three-launch form.
+int g_tune_acts_fused = 0;      // caphn_tune key 28: 1 = one launch (measured: 14.6 us alone against 3 x 3.5 us + two gaps, and in the
+                                // step its 1024-thread workgroups are placed late beside the feature_fc GEMM: +4 us per step), 0 (default) = three launches
+struct ActsFusedArgs {
+    const float* x; int d_in, d_mid, he, nh, rtot;
+    const float* w0; const float* b0; const float* w2; const float* b2;
+    const float* w1[CAPHN_MAX_HEADS]; const float* b1[CAPHN_MAX_HEADS]; float* out[CAPHN_MAX_HEADS]; int k[CAPHN_MAX_HEADS];
+    float* a_x; float* a_a0; float* a_base;
+};
+struct RowRef { const float* w; const float* b; float* og; int r; };
+// RB rows per wave iteration: rows wv, wv + nw, ...; `in` (LDS) has kin floats; result to out_s (LDS, may be null) / the row's og.
+// RB = 16 (widths <= 256) / 8: with 16 waves a 200-row layer is ONE iteration -- every load of the phase in flight at once (four
+// rows per iteration were four dependent L2 round trips per phase: the kernel took 25 us alone)
+template <int QMAX, typename Locate>
+__device__ __forceinline__ void fused_rows(Locate locate, int nrows, int kin, const float* in, int wv, int nw, float* out_s, int lane) {
+    constexpr int RB = QMAX == 1 ? 16 : 8;
+    const int k4 = kin >> 2;
+    f32x4 xr[QMAX];
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+        const int c = lane + 64 * q;
+        xr[q] = c < k4 ? reinterpret_cast<const f32x4*>(in)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int r0 = wv; r0 < nrows; r0 += nw * RB) {
+        // (wv is wave-uniform and comes in through readfirstlane: row references live in scalar registers and are formed again at
+        //  the store -- sixteen of them held in vector registers spilled)
+        f32x4 w[RB][QMAX];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = r0 + i * nw;
+            const RowRef rr = r < nrows ? locate(r) : RowRef{nullptr, nullptr, nullptr, 0};
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) {
+                const int c = lane + 64 * q;
+                w[i][q] = (rr.w && c < k4) ? reinterpret_cast<const f32x4*>(rr.w + (size_t)rr.r * kin)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = r0 + i * nw;
+            if (r >= nrows) continue;               // (wave-uniform)
+            float sacc = 0.f;
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q)
+                sacc += w[i][q][0] * xr[q][0] + w[i][q][1] * xr[q][1] + w[i][q][2] * xr[q][2] + w[i][q][3] * xr[q][3];
+            const float t = wave_sum(sacc);
+            if (lane == 0) {
+                const RowRef rr = locate(r);
+                const float v = lrelu(t + rr.b[rr.r]);
+                if (out_s) out_s[r] = v;
+                if (rr.og) rr.og[rr.r] = v;
+            }
+        }
+    }
+}
+template <int QMAX>
+__global__ __launch_bounds__(1024) void hyper_acts_fused_kernel(ActsFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xs = sm;
+    float* a0s = xs + ((a.d_in + 3) & ~3);
+    float* bs = a0s + ((a.d_mid + 3) & ~3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wg = blockIdx.x;
+    const bool w0g = wg == 0;
+    for (int i = tid; i < a.d_in; i += 1024) {
+        const float v = a.x[i];
+        xs[i] = v;
+        if (w0g && a.a_x != a.x) a.a_x[i] = v;
+    }
+    __syncthreads();
+    fused_rows<QMAX>([&](int r) { return RowRef{a.w0, a.b0, w0g ? a.a_a0 : nullptr, r}; }, a.d_mid, a.d_in, xs, wave, 16, a0s, lane);
+    __syncthreads();
+    fused_rows<QMAX>([&](int r) { return RowRef{a.w2, a.b2, w0g ? a.a_base : nullptr, r}; }, a.he, a.d_mid, a0s, wave, 16, bs, lane);
+    __syncthreads();
+    fused_rows<QMAX>([&](int r) {
+        int i = 0;
+        while (i + 1 < a.nh && r >= a.k[i]) { r -= a.k[i]; ++i; }
+        return RowRef{a.w1[i], a.b1[i], a.out[i], r};
+    }, a.rtot, a.he, bs, wg * 16 + wave, (int)gridDim.x * 16, nullptr, lane);
+}
 }  // namespace
 int g_tune_gemv = 1;      // 0: plain loads  1 (default): non-temporal loads (115 vs 126 us on the canonical hypernet)
 namespace {
@@ -187,7 +273,7 @@ struct GemvTJob {
     const float* W; const float* d; float* partial;   // partial [nblocks, k]
     int rows, k, vec, block0, nblocks;
 };
-struct GemvTJobs { GemvTJob j[CAPHN_MAX_HEADS]; int n; };
+struct GemvTJobs { GemvTJob j[CAPHN_MAX_HEADS]; int n; unsigned* bar = nullptr; };    // bar: the fused tail's phase counters, cleared here
 
 template <int QMAX>
 __device__ __forceinline__ void gemv_t_wave(const GemvTJob& J, int lb, int tid, float* red /* [4][k] */) {
@@ -234,6 +320,7 @@ __global__ __launch_bounds__(256) void gemv_t_partial_kernel(GemvTJobs jobs) {
     for (int i = 1; i < jobs.n; ++i) if ((int)blockIdx.x >= jobs.j[i].block0) ji = i;
     const GemvTJob& J = jobs.j[ji];
     const int lb = blockIdx.x - J.block0, tid = threadIdx.x;
+    if (jobs.bar && blockIdx.x == 0 && tid < 4) jobs.bar[tid] = 0u;
     if (J.vec && J.k <= 256 * QMAX) {
         gemv_t_wave<QMAX>(J, lb, tid, red);
     } else {
@@ -349,6 +436,209 @@ __global__ __launch_bounds__(256) void outer_kernel(OuterJobs jobs) {
         if (idx < n) J.out[idx] = J.g[idx / J.k] * J.a[idx % J.k];
 }
 
+
+// ---------------------------------------------------------------- fused tail of the backward (one launch)
+// Behind the transposed GEMV the VJP needs four tiny dependent steps -- reduce the per-block partials to dz_i, dbase = sum_i
+// W1_i^T dz_i, da0 = Wb2^T dzb2, dx = Wb0^T dzb0 -- and the rank-1 weight gradients of the small layers: five launches, 1 MB of
+// traffic, 60-75 us on the chain to the optimiser when the chip is busy with the weight-gradient GEMMs.  Here they are phases of
+// ONE launch of <= 64 workgroups separated by counter barriers.  Inter-workgroup data (dz, dzb2, dzb0: a few KB) is written with
+// agent-scope (sc1, write-through) stores, drained by every storing wave (s_waitcnt vmcnt(0)) in front of the workgroup barrier
+// that precedes the workgroup's ONE counter add, and read with agent-scope loads behind the poll + workgroup barrier
+// (MI355X_MICROARCH.md, hand-off table, first row) -- no fences, so no write-back of whatever the GEMMs running beside this
+// kernel have dirtied in the L2.  Every workgroup must become resident for the barriers to complete: the grid is at most 64
+// workgroups and nothing it waits for depends on this stream; the polls are bounded in wall-clock time like the pair kernels'
+// (device error word, CAPHN_ETIMEOUT).  Summation orders are fixed: results are reproducible run to run.
+int g_tune_hyper_tail = 0;      // caphn_tune key 27: 1 = this kernel, 0 (default) = the five-launch form (measured equal in the step,
+                                // 29 us against 31 us + four gaps alone: the branches behind BPTT are throughput-bound)
+struct TailHead { const float* partial; const float* post; const float* w1; float* g_b1; float* g_w1; int k, nblocks, dzo; };
+struct TailArgs {
+    TailHead h[CAPHN_MAX_HEADS]; int nh;
+    int he, d_mid, d_in;
+    const float* base_act;      // acts: hn_base output (post-activation) -- the column factor of g_w1 and the mask of dzb2
+    const float* a0_act;        // acts: hn_base hidden layer (post-activation)
+    const float* x_in;          // acts: the input row
+    const float* base_w2; const float* base_w0;
+    float* g_base_b2; float* g_base_b0; float* g_base_w2; float* g_base_w0; float* g_x; int x_acc;
+    float* dz; float* dzb2; float* dzb0;       // workspace (exchanged between workgroups)
+    unsigned* bar;
+    int* err; long long limit;
+};
+__device__ __forceinline__ float ld_x(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_x(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tail_barrier(unsigned* cnt, unsigned target, int* err, long long limit) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();
+        for (int spin = 1; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((spin & 255) == 0 && wall_clock64() - t0 > limit) {
+                if (err) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+// The exchanged vector (dz, dzb2 or dzb0: produced by OTHER workgroups of this launch) is brought into LDS once per phase with
+// agent-scope loads, all in flight at once; the phases' loops then run on plain loads.  (Agent-scope loads inside the loops were
+// kept in program order by the compiler: nine dependent L2 round trips per thread and phase -- the kernel took 38 us alone.)
+__device__ __forceinline__ void tail_stage(const float* src, int n, float* dst) {
+    for (int i = threadIdx.x; i < n; i += 1024) dst[i] = ld_x(src + i);
+    __syncthreads();
+}
+// y[c] = (sum_r W[r][c] d[r]) * lrelu'(post[c]) for the 8 columns of `unit`, d in LDS (rows entries; W row-major [rows, k])
+__device__ __forceinline__ void tail_smallt(const float* W, const float* ds, int rows, int k, const float* post, float* out_x, float* out_g,
+                                            int acc_g, int unit, float (*red)[STC + 1]) {
+    const int cl = threadIdx.x & (STC - 1), rl = threadIdx.x / STC;
+    const int c = unit * STC + cl;
+    float acc = 0.f;
+    if (c < k) {
+        int r = rl;
+        for (; r + 3 * STR < rows; r += 4 * STR) {           // four independent loads in flight
+            const float w0 = W[(size_t)r * k + c], w1 = W[(size_t)(r + STR) * k + c], w2 = W[(size_t)(r + 2 * STR) * k + c],
+                        w3 = W[(size_t)(r + 3 * STR) * k + c];
+            acc += w0 * ds[r]; acc += w1 * ds[r + STR]; acc += w2 * ds[r + 2 * STR]; acc += w3 * ds[r + 3 * STR];
+        }
+        for (; r < rows; r += STR) acc += W[(size_t)r * k + c] * ds[r];
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64 * STC) {
+        const int col = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        float s = wave_sum(red[lane][col] + red[lane + 64][col]);
+        const int cc = unit * STC + col;
+        if (lane == 0 && cc < k) {
+            if (post) s *= lrelu_grad(post[cc]);
+            if (out_x) st_x(out_x + cc, s);
+            if (out_g) { if (acc_g) atomicAdd(out_g + cc, s); else out_g[cc] = s; }
+        }
+    }
+    __syncthreads();
+}
+// out[r][c] = g[r] * a[c] for the 4096 elements of `unit`; g in LDS
+__device__ __forceinline__ void tail_outer(const float* gs, const float* a, float* out, int rows, int k, int unit) {
+    const size_t n = (size_t)rows * k;
+    size_t idx = (size_t)unit * 4096 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i, idx += 1024)
+        if (idx < n) out[idx] = gs[idx / k] * a[idx % k];
+}
+__global__ __launch_bounds__(1024) void hyper_tail_kernel(TailArgs a) {
+    __shared__ float red[STR][STC + 1];            // 1152 floats; phase 1 uses it as [RL][65] (1040)
+    extern __shared__ __attribute__((aligned(16))) float vec_s[];      // the phase's exchanged vector: max(sum k_i, he, d_mid) floats
+    const int wg = blockIdx.x, NB = gridDim.x, tid = threadIdx.x;
+    {   // phase 1: dz_i[c] = (sum_b partial_i[b][c]) * lrelu'(a_i[c]); units of 64 columns dealt round-robin
+        float (*r16)[65] = reinterpret_cast<float (*)[65]>(&red[0][0]);
+        int u0 = 0;
+        for (int i = 0; i < a.nh; ++i) {
+            const TailHead& H = a.h[i];
+            const int nu = (H.k + 63) / 64;
+            for (int u = 0; u < nu; ++u) {
+                if ((u0 + u) % NB != wg) continue;
+                const int c = u * 64 + (tid & 63), rl = tid >> 6;
+                float acc = 0.f;
+                if (c < H.k) {
+                    int b = rl;
+                    for (; b + 7 * RL < H.nblocks; b += 8 * RL) {        // eight independent loads in flight, added in order
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = H.partial[(size_t)(b + q * RL) * H.k + c];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc += v[q];
+                    }
+                    for (; b < H.nblocks; b += RL) acc += H.partial[(size_t)b * H.k + c];
+                }
+                r16[rl][tid & 63] = acc;
+                __syncthreads();
+                if (rl == 0 && c < H.k) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int q = 0; q < RL; ++q) s += r16[q][tid & 63];
+                    s *= lrelu_grad(H.post[c]);
+                    st_x(a.dz + H.dzo + c, s);
+                    if (H.g_b1) H.g_b1[c] = s;
+                }
+                __syncthreads();
+            }
+            u0 += nu;
+        }
+    }
+    tail_barrier(a.bar + 0, NB, a.err, a.limit);
+    {   // phase 2: dzb2 = (sum_i W1_i^T dz_i) * lrelu'(base);  g_w1_i = dz_i (x) base
+        const TailHead& HL = a.h[a.nh - 1];
+        const int ktot = HL.dzo + HL.k;                  // dz_i are laid out back to back (4-float aligned starts)
+        tail_stage(a.dz, ktot, vec_s);
+        const int nu = (a.he + STC - 1) / STC;
+        for (int u = wg; u < nu; u += NB) {
+            // (the heads' first layers W1_i [k_i, he] one after the other: same column c, rows continue through the heads)
+            const int cl = tid & (STC - 1), rl = tid / STC, c = u * STC + cl;
+            float acc = 0.f;
+            if (c < a.he)
+                for (int i = 0; i < a.nh; ++i) {
+                    const float* W = a.h[i].w1; const float* ds = vec_s + a.h[i].dzo; const int rows = a.h[i].k, k = a.he;
+                    int r = rl;
+                    for (; r + 3 * STR < rows; r += 4 * STR) {
+                        const float w0 = W[(size_t)r * k + c], w1 = W[(size_t)(r + STR) * k + c], w2 = W[(size_t)(r + 2 * STR) * k + c],
+                                    w3 = W[(size_t)(r + 3 * STR) * k + c];
+                        acc += w0 * ds[r]; acc += w1 * ds[r + STR]; acc += w2 * ds[r + 2 * STR]; acc += w3 * ds[r + 3 * STR];
+                    }
+                    for (; r < rows; r += STR) acc += W[(size_t)r * k + c] * ds[r];
+                }
+            red[rl][cl] = acc;
+            __syncthreads();
+            if (tid < 64 * STC) {
+                const int col = tid >> 6, lane = tid & 63;
+                float sres = wave_sum(red[lane][col] + red[lane + 64][col]);
+                const int cc = u * STC + col;
+                if (lane == 0 && cc < a.he) {
+                    sres *= lrelu_grad(a.base_act[cc]);
+                    st_x(a.dzb2 + cc, sres);
+                    if (a.g_base_b2) a.g_base_b2[cc] = sres;
+                }
+            }
+            __syncthreads();
+        }
+        int v0 = 0;                                  // outer-product units go to the workgroups from the far end
+        for (int i = 0; i < a.nh; ++i) {
+            const int nv = (int)(((size_t)a.h[i].k * a.he + 4095) / 4096);
+            if (a.h[i].g_w1)
+                for (int v = 0; v < nv; ++v)
+                    if ((v0 + v) % NB == NB - 1 - wg) tail_outer(vec_s + a.h[i].dzo, a.base_act, a.h[i].g_w1, a.h[i].k, a.he, v);
+            v0 += nv;
+        }
+    }
+    tail_barrier(a.bar + 1, NB, a.err, a.limit);
+    {   // phase 3: dzb0 = (Wb2^T dzb2) * lrelu'(a0);  g_base_w2 = dzb2 (x) a0
+        tail_stage(a.dzb2, a.he, vec_s);
+        const int nu = (a.d_mid + STC - 1) / STC;
+        for (int u = wg; u < nu; u += NB) tail_smallt(a.base_w2, vec_s, a.he, a.d_mid, a.a0_act, a.dzb0, a.g_base_b0, 0, u, red);
+        if (a.g_base_w2) {
+            const int nv = (int)(((size_t)a.he * a.d_mid + 4095) / 4096);
+            for (int v = 0; v < nv; ++v)
+                if (v % NB == NB - 1 - wg) tail_outer(vec_s, a.a0_act, a.g_base_w2, a.he, a.d_mid, v);
+        }
+    }
+    if (!a.g_x && !a.g_base_w0) return;
+    tail_barrier(a.bar + 2, NB, a.err, a.limit);
+    {   // phase 4: dx = Wb0^T dzb0;  g_base_w0 = dzb0 (x) x
+        tail_stage(a.dzb0, a.d_mid, vec_s);
+        if (a.g_x) {
+            const int nu = (a.d_in + STC - 1) / STC;
+            for (int u = wg; u < nu; u += NB) tail_smallt(a.base_w0, vec_s, a.d_mid, a.d_in, nullptr, nullptr, a.g_x, a.x_acc, u, red);
+        }
+        if (a.g_base_w0) {
+            const int nv = (int)(((size_t)a.d_mid * a.d_in + 4095) / 4096);
+            for (int v = 0; v < nv; ++v)
+                if (v % NB == NB - 1 - wg) tail_outer(vec_s, a.x_in, a.g_base_w0, a.d_mid, a.d_in, v);
+        }
+    }
+}
 inline int gemv_blocks(int rows, int k, int vec) {
     // enough waves to cover the chip; big jobs grid-stride
     long want = (vec && k >= 128) ? ((long)rows + 15) / 16 : ((long)rows + 31) / 32;
@@ -410,6 +700,27 @@ static int hyper_forward_impl(const caphn_hyper_desc* d, const float* x, float* 
         J.vec = vec_ok(W, in, k); J.block0 = 0; J.nblocks = gemv_blocks(rows, k, J.vec);
         launch_gemv_fwd(jobs, J.nblocks, s);
     };
+    // the three small layers in one launch when every width fits the wave-per-row 16-byte path (the canonical sizes do)
+    bool fused = g_tune_acts_fused != 0;
+    {
+        const int widths[3] = {d_in(d), d_mid(d), d->he};
+        for (int wdt : widths) fused = fused && wdt % 4 == 0 && wdt >= 128 && wdt <= 512;
+        fused = fused && (long)d_mid(d) * d_in(d) + (long)d->he * d_mid(d) <= 262144 && caphn_aligned16(x) && caphn_aligned16(acts) &&
+                caphn_aligned16(d->base_w0) && caphn_aligned16(d->base_w2);
+        for (int i = 0; i < d->n_heads; ++i) fused = fused && caphn_aligned16(d->w1[i]);
+    }
+    if (fused) {
+        ActsFusedArgs a;
+        a.x = x; a.d_in = d_in(d); a.d_mid = d_mid(d); a.he = d->he; a.nh = d->n_heads; a.rtot = 0;
+        a.w0 = d->base_w0; a.b0 = d->base_b0; a.w2 = d->base_w2; a.b2 = d->base_b2;
+        for (int i = 0; i < d->n_heads; ++i) { a.w1[i] = d->w1[i]; a.b1[i] = d->b1[i]; a.out[i] = acts + L.a[i]; a.k[i] = d->k[i]; a.rtot += d->k[i]; }
+        a.a_x = acts + L.x; a.a_a0 = acts + L.a0; a.a_base = acts + L.base;
+        const int nb = std::max(1, std::min(64, (a.rtot + 15) / 16));
+        const size_t shm = sizeof(float) * (size_t)(((a.d_in + 3) & ~3) + ((a.d_mid + 3) & ~3) + ((a.he + 3) & ~3));
+        const int wmax = std::max(a.d_in, std::max(a.d_mid, a.he));
+        if (wmax <= 256) hipLaunchKernelGGL(hyper_acts_fused_kernel<1>, dim3(nb), dim3(1024), shm, s, a);
+        else hipLaunchKernelGGL(hyper_acts_fused_kernel<2>, dim3(nb), dim3(1024), shm, s, a);
+    } else {
     one(d->base_w0, d->base_b0, x, acts + L.a0, d_mid(d), d_in(d), 1, x == acts + L.x ? nullptr : acts + L.x);
     one(d->base_w2, d->base_b2, acts + L.a0, acts + L.base, d->he, d_mid(d), 1, nullptr);
     {   // first layers of all heads in one launch
@@ -421,6 +732,7 @@ static int hyper_forward_impl(const caphn_hyper_desc* d, const float* x, float* 
             J.block0 = b0; J.nblocks = gemv_blocks(J.rows, J.k, J.vec); b0 += J.nblocks;
         }
         launch_gemv_fwd(jobs, b0, s);
+    }
     }
     if (theta) {   // second layers: theta = cat_i (W2_i a_i + b2_i)
         GemvJobs jobs; jobs.n = d->n_heads; int b0 = 0; size_t off = 0;
@@ -437,7 +749,7 @@ static int hyper_forward_impl(const caphn_hyper_desc* d, const float* x, float* 
 
 namespace {
 struct BwdWs { size_t partial[CAPHN_MAX_HEADS]; int nblocks[CAPHN_MAX_HEADS]; size_t dz[CAPHN_MAX_HEADS];
-               size_t dzb2, dzb0, total; };
+               size_t dzb2, dzb0, bar, total; };
 inline BwdWs bwd_ws(const caphn_hyper_desc* d) {
     BwdWs w; size_t o = 0;
     for (int i = 0; i < d->n_heads; ++i) {
@@ -449,6 +761,8 @@ inline BwdWs bwd_ws(const caphn_hyper_desc* d) {
     for (int i = 0; i < d->n_heads; ++i) { w.dz[i] = o; o += caphn_align_up(d->k[i], 4); }
     w.dzb2 = o; o += caphn_align_up(d->he, 4);
     w.dzb0 = o; o += caphn_align_up(d_mid(d), 4);
+    o = caphn_align_up(o, 32);
+    w.bar = o; o += 32;               // the fused tail's phase counters, on a 128-byte line of their own
     w.total = o;
     return w;
 }
@@ -484,6 +798,10 @@ extern "C" int caphn_hyper_backward(const caphn_hyper_desc* d, const float* dthe
             J.block0 = b0; J.nblocks = W.nblocks[i]; b0 += J.nblocks;
             kmax = std::max(kmax, J.k);
         }
+        size_t vec_floats = std::max(d->he, d_mid(d));
+        { size_t kt = 0; for (int i = 0; i < nh; ++i) kt += caphn_align_up(d->k[i], 4); vec_floats = std::max(vec_floats, kt); }
+        const bool fused_tail = g_tune_hyper_tail != 0 && vec_floats * sizeof(float) <= 64 * 1024;
+        if (fused_tail) jobs.bar = reinterpret_cast<unsigned*>(ws + W.bar);
         int kv = 0;
         for (int i = 0; i < nh; ++i) if (jobs.j[i].vec && jobs.j[i].k <= 2048) kv = std::max(kv, jobs.j[i].k);
         const size_t shm = sizeof(float) * 4 * (kv > 0 ? kv : 1);      // only the wave path (k <= 2048, aligned) uses LDS
@@ -491,6 +809,37 @@ extern "C" int caphn_hyper_backward(const caphn_hyper_desc* d, const float* dthe
         else if (kv <= 512) hipLaunchKernelGGL(gemv_t_partial_kernel<2>, dim3(b0), dim3(256), shm, s, jobs);
         else if (kv <= 1024) hipLaunchKernelGGL(gemv_t_partial_kernel<4>, dim3(b0), dim3(256), shm, s, jobs);
         else hipLaunchKernelGGL(gemv_t_partial_kernel<8>, dim3(b0), dim3(256), shm, s, jobs);
+        if (fused_tail) {
+            TailArgs a;
+            a.nh = nh; a.he = d->he; a.d_mid = d_mid(d); a.d_in = d_in(d);
+            a.base_act = acts + L.base; a.a0_act = acts + L.a0; a.x_in = acts + L.x;
+            a.base_w2 = d->base_w2; a.base_w0 = d->base_w0;
+            a.g_base_b2 = g->g_base_b2; a.g_base_b0 = g->g_base_b0; a.g_base_w2 = g->g_base_w2; a.g_base_w0 = g->g_base_w0;
+            a.g_x = g->g_x; a.x_acc = g->x_accumulate;
+            a.dz = ws + W.dz[0]; a.dzb2 = ws + W.dzb2; a.dzb0 = ws + W.dzb0;
+            a.bar = reinterpret_cast<unsigned*>(ws + W.bar);
+            a.err = caphn_errword(); a.limit = g_tune_xch_timeout;
+            int units = (d->he + STC - 1) / STC, p1 = 0, outer = 0;
+            for (int i = 0; i < nh; ++i) {
+                TailHead& H = a.h[i];
+                H.partial = ws + W.partial[i]; H.post = acts + L.a[i]; H.w1 = d->w1[i]; H.g_b1 = g->g_b1[i]; H.g_w1 = g->g_w1[i];
+                H.k = d->k[i]; H.nblocks = W.nblocks[i]; H.dzo = (int)(W.dz[i] - W.dz[0]);
+                p1 += (H.k + 63) / 64;
+                if (H.g_w1) outer += (int)(((size_t)H.k * d->he + 4095) / 4096);
+            }
+            units = std::max(units + outer, std::max(p1, std::max((d_mid(d) + STC - 1) / STC, (d_in(d) + STC - 1) / STC)));
+            const int nb = std::max(1, std::min(64, units));
+            hipLaunchKernelGGL(hyper_tail_kernel, dim3(nb), dim3(1024), vec_floats * sizeof(float), s, a);
+            for (int i = 0; i < nh; ++i)     // second-layer weight grads only when asked for (dense 576 MB at the canonical size)
+                if (g->g_w2[i]) {
+                    OuterJobs o2; o2.n = 1;
+                    OuterJob& J = o2.j[0];
+                    J.g = dtheta + toff[i]; J.a = acts + L.a[i]; J.out = g->g_w2[i]; J.rows = d->w[i]; J.k = d->k[i]; J.block0 = 0;
+                    long nbo = ((long)J.rows * J.k + 1023) / 1024;
+                    hipLaunchKernelGGL(outer_kernel, dim3((unsigned)nbo), dim3(256), 0, s, o2);
+                }
+            return caphn_launch_status();
+        }
         // dz_i = da_i * lrelu'(a_i)  (also the first-layer bias grad)
         ReduceJobs rj; rj.n = nh;
         for (int i = 0; i < nh; ++i) {
@@ -571,6 +920,7 @@ extern int g_tune_splitk_target;
 extern int g_tune_gemm_order;
 extern int g_tune_branch_mask;
 extern int g_tune_gemm_db;
+extern int g_tune_gemm_ws;
 extern int g_tune_gemm_waves;
 extern int g_tune_hops;
 extern int g_tune_vocab_order;
@@ -598,6 +948,9 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 16) { if (value < 0 || value > 2) return CAPHN_EINVAL; g_tune_rec_cache = value; return CAPHN_OK; }
     if (key == 15) { g_tune_chain_main = value != 0; return CAPHN_OK; }
     if (key == 26) { g_tune_hops = value != 0; return CAPHN_OK; }
+    if (key == 27) { g_tune_hyper_tail = value != 0; return CAPHN_OK; }
+    if (key == 28) { g_tune_acts_fused = value != 0; return CAPHN_OK; }
+    if (key == 29) { if (value != 0 && value != 64 && value != 128) return CAPHN_EINVAL; g_tune_gemm_ws = value; return CAPHN_OK; }
     if (key == 25) { if (value != 0 && value != 5 && value != 6) return CAPHN_EINVAL; g_tune_gemm_waves = value; return CAPHN_OK; }
     if (key == 24) return caphn_rec_pair_debug_opts(value);
     if (key == 23) { if (value < 0 || value > 7) return CAPHN_EINVAL; g_tune_gemm_db = value; return CAPHN_OK; }

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void grad_norm_finish_kernel(int nb_s, int R, 
 }
 
 // ------------------------------------------------------------------ Adam (torch.optim.Adam, single-tensor form)
-struct AdamK { float lr_bc1, b1, b2, eps, sqrt_bc2; const float* dev; };
+struct AdamK { float lr_bc1, b1, b2, eps, sqrt_bc2; const float* dev; int zg = 0; };    // zg: rank-1 passes clear their row factor (R == 1)
 __device__ __forceinline__ float adam_elem(float p, float g, float& m, float& v, const AdamK& k) {
     m = m + (g - m) * (1.0f - k.b1);                       // exp_avg.lerp_(grad, 1 - beta1)
     v = v * k.b2 + (1.0f - k.b2) * g * g;                  // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
@@ -559,6 +559,15 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
 #pragma unroll
             for (int r = 0; r < (MULTI ? RMAX : 1); ++r)
                 grs[i][r] = (r < R && row0 + i < rows) ? gfac[(size_t)r * ldg + row0 + i] : 0.f;
+        if constexpr (!MULTI) {
+            // caphn_adam_hparams::zero_gfac: this wave is the LAST reader of its rows' factor (d theta in the trainer's gradient
+            // arena, which the next backward accumulates into): clear it here instead of with a launch in front of the next forward
+            if (K.zg && lane == 0) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+                    if (row0 + i < rows) const_cast<float*>(gfac)[row0 + i] = 0.f;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             if (row0 + i >= rows) continue;
@@ -836,6 +845,7 @@ inline AdamK make_adam(const caphn_adam_hparams* hp) {
     k.b1 = hp->beta1; k.b2 = hp->beta2; k.eps = hp->eps;
     k.sqrt_bc2 = (float)sqrt(bc2);
     k.dev = hp->dev_scalars;
+    k.zg = hp->zero_gfac;
     return k;
 }
 
@@ -1066,7 +1076,11 @@ static int adam_rank_launch(int R, int rows, int k, float* W, float* m, float* v
     if (nb > g_tune_adam_cap) nb = g_tune_adam_cap;
     if (nb < 1) nb = 1;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const AdamK K = make_adam(hp);
+    AdamK K = make_adam(hp);
+    if (K.zg && R != 1) return CAPHN_EINVAL;
+    const bool rowpath = vec && k <= 2048;      // the kernels that clear the row factor themselves; the others get a fill behind them
+    const bool zero_after = K.zg && !rowpath;
+    if (zero_after) K.zg = 0;
     const bool longrow = !(vec && k <= 2048) && k >= 512;
     if (longrow) {
         long nl = ((long)rows + 3) / 4;
@@ -1076,6 +1090,7 @@ static int adam_rank_launch(int R, int rows, int k, float* W, float* m, float* v
         if (g_tune_adam == 7) hipLaunchKernelGGL((adam_rank_long_kernel<false, true>), dim3((unsigned)nl), dim3(256), 0, s, R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, nx);
         else if (g_tune_adam == 3) hipLaunchKernelGGL((adam_rank_long_kernel<true, true>), dim3((unsigned)nl), dim3(256), 0, s, R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, nx);
         else hipLaunchKernelGGL((adam_rank_long_kernel<false, false>), dim3((unsigned)nl), dim3(256), 0, s, R, rows, k, W, m, v, gfac, ldg, afac, lda, coef, K, nx);
+        if (zero_after) return caphn_zero_f32(const_cast<float*>(gfac), (size_t)rows, stream);
         return caphn_launch_status();
     }
     const bool fused = vec && k <= 2048;
@@ -1105,6 +1120,7 @@ static int adam_rank_launch(int R, int rows, int k, float* W, float* m, float* v
         long nr = ((long)rows + 31) / 32; if (nr > 2048) nr = 2048;
         hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)nr), dim3(256), 0, s, rows, k, W, nx);
     }
+    if (zero_after) return caphn_zero_f32(const_cast<float*>(gfac), (size_t)rows, stream);
     return caphn_launch_status();
 }
 extern "C" int caphn_adam_rank_f32(int R, int rows, int k, float* W, float* m, float* v,
@@ -1123,7 +1139,7 @@ extern "C" int caphn_adam_rank_gemv_f32(int R, int rows, int k, float* W, float*
 
 extern "C" int caphn_adam_rank_multi_f32(int R, int njobs, const caphn_rank_job* jobs, const float* coef, const caphn_adam_hparams* hp,
                                          caphn_stream_t stream) {
-    if (njobs <= 0 || !jobs || !coef || !hp || hp->step < 1 || R <= 0 || R > RMAX) return CAPHN_EINVAL;
+    if (njobs <= 0 || !jobs || !coef || !hp || hp->step < 1 || R <= 0 || R > RMAX || (hp->zero_gfac && R != 1)) return CAPHN_EINVAL;
     // one launch when the members fit the row kernel's fast path with one width class (and all or none carry the fused GEMV)
     auto qclass = [](int k) { return k <= 256 ? 1 : k <= 512 ? 2 : k <= 1024 ? 4 : 8; };
     bool one = njobs >= 2 && njobs <= 4 && g_tune_adam != 0;

@@ -272,7 +272,8 @@ int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_decoder_param
  * another stream while the optimiser streams the hypernet (then set dims.precomputed = 1 for that forward).  With
  * captions it also produces G = f W_ih[:,E:]^T, the embedding lookup and the x-side gate pre-activations, which need
  * the generated W_ih / b_ih of THAT forward (dims.precomputed = 2).  dims.precomputed bit 4 given to THIS call: the x side is
- * left out (the caller issues caphn_decoder_inputs itself, e.g. on a third stream once b_ih exists), G is still produced. */
+ * left out (the caller issues caphn_decoder_inputs itself, e.g. on a third stream once b_ih exists), G is still produced; bit 1
+ * given to THIS call: the theta-independent part is in the workspace already (an earlier call, before W_ih existed), only G is added. */
 int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn_decoder_params* p, const float* features,
                              const int64_t* captions /* optional, see dims.precomputed */, void* ws, caphn_stream_t stream);
 /* Embedding lookup (with the reference's zeroed first two inputs) and x-side gate pre-activations for all T; needs the
@@ -498,6 +499,9 @@ typedef struct caphn_adam_hparams {
     const float* dev_scalars;          /* optional DEVICE pointer to {lr / (1 - beta1^step), sqrt(1 - beta2^step)}:
                                           when non-NULL it overrides lr/step, so a captured hipGraph can be
                                           replayed for every step (the caller refreshes the two floats) */
+    int zero_gfac;                     /* rank-1 passes only (caphn_adam_rank*_f32, R == 1): 1 = the pass also CLEARS gfac[0..rows) --
+                                          it is the last reader of that row factor; a trainer whose factor is d theta inside its
+                                          gradient arena saves the fill in front of the next backward.  0 elsewhere. */
 } caphn_adam_hparams;
 /* p,m,v,g flat [n]; g is multiplied by coef[0] (device) first. */
 int caphn_adam_dense_f32(size_t n, float* p, float* m, float* v, const float* g, const float* coef,
@@ -576,7 +580,12 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * key 16 also takes 2 (default): the pair FORWARD kernel keeps ALL of a half's [U_a; W_hh] on chip when it fits; key 22: hand-off time
  * bound of the pair kernels in microseconds (default 1 000 000); key 23: bit mask of GEMM layouts (1 NT, 2 NN, 4 TN) that run the
  * 64x64 tile with ping-pong LDS images (default 0: measured slower or equal on every shape of the step); key 24: bit 0 switches
- * the same-XCD hand-off form of the pair kernels off (A/B).
+ * the same-XCD hand-off form of the pair kernels off (A/B); key 25: GEMM compiled for 5 / 6 waves per SIMD (0 default: measured
+ * slower); key 26: 1 = the composites' cross-stream dependencies as stream memory operations instead of events (0 default:
+ * measured slower); key 27: 1 = the tail of caphn_hyper_backward behind the transposed GEMV (reduce, three small
+ * transposed GEMVs, the small layers' rank-1 gradients) as ONE launch with counter barriers, 0 (default) = five launches (measured
+ * equal in the step); key 28: 1 = hn_base and the heads' first layers of caphn_hyper_forward / _forward_acts in ONE launch
+ * (bit-identical results), 0 (default) = three launches (measured 4 us faster in the step).
  * Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 

@@ -107,8 +107,17 @@ def test_colsum(ops):
         assert maxdiff(ops.colsum(A.to(DEV)).cpu(), A.double().sum(0)) < 1e-5 * math.sqrt(M) * 4
 
 
+@pytest.fixture(params=[1, 0], ids=["tail-fused", "tail-5-launches"])
+def hyper_tail(request):
+    """caphn_tune key 27: the tail of caphn_hyper_backward as one launch with counter barriers / as five launches (default)."""
+    import caphn._lib as L
+    L.load().caphn_tune(27, request.param)
+    yield request.param
+    L.load().caphn_tune(27, 0)
+
+
 @pytest.mark.parametrize("name", ["gru_tiny_flickr", "gru_tiny_cc", "gru_odd_cc"])
-def test_hyper_forward_backward_tiny(ops, name):
+def test_hyper_forward_backward_tiny(ops, name, hyper_tail):
     dims = TINY_DIMS[name]
     g, p = load_case(name)
     x, tok = style_args(g)
@@ -127,7 +136,7 @@ def test_hyper_forward_backward_tiny(ops, name):
     assert maxdiff(gx.cpu(), xr.grad) < 1e-6
 
 
-def test_hyper_forward_backward_canonical_shape(ops):
+def test_hyper_forward_backward_canonical_shape(ops, hyper_tail):
     """he=200 with the canonical head widths (480/240/200/200) but fewer rows: exercises the
     wave-per-row dwordx4 paths (k >= 128) incl. the 2-chunk 480 case and row tails."""
     torch.manual_seed(3)
@@ -148,6 +157,72 @@ def test_hyper_forward_backward_canonical_shape(ops):
     for n in grads:
         assert rel_err(grads[n], q[n].grad) < 2e-5, n
     assert rel_err(gx, xr.grad) < 2e-5
+
+
+def test_hyper_small_layers_in_one_launch_bit_identical(ops):
+    """caphn_tune key 28: hn_base and the heads' first layers as ONE launch (every workgroup recomputes the two 200 x 200 layers
+    for itself) == the three-launch form bit for bit (same per-row arithmetic), theta included."""
+    import caphn._lib as L
+    torch.manual_seed(11)
+    for he, heads in [(200, [(480, 4001), (240, 1999), (200, 600), (200, 600)]), (256, [(132, 77), (512, 300)])]:
+        shape = ops.HyperShape(he, heads)
+        pd = {n: ((torch.rand(s) - 0.5) * 0.3).to(DEV) for n, s in shape.param_shapes().items()}
+        x = torch.randn(he).to(DEV)
+        out = []
+        try:
+            for mode in (0, 1):
+                L.load().caphn_tune(28, mode)
+                theta, acts = ops.hyper_forward(shape, pd, x)
+                out.append((theta.clone(), acts.clone()))
+        finally:
+            L.load().caphn_tune(28, 0)
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+        assert float(out[1][1].abs().sum()) > 0
+
+
+def test_hyper_backward_fused_tail_hand_offs_under_load(ops):
+    """The one-launch tail exchanges dz / dzb2 / dzb0 between workgroups through write-through stores and agent-scope loads behind
+    counter barriers.  Alternating between two different d theta (a stale value of the other run would show), with GEMMs keeping
+    the chip busy on a second stream (uneven load), every gradient word must equal the five-launch form's up to summation order,
+    and repeated runs of the fused form must be bit-identical."""
+    import caphn._lib as L
+    torch.manual_seed(5)
+    he, heads = 200, [(480, 4001), (240, 1999), (200, 600), (200, 600)]
+    shape = ops.HyperShape(he, heads)
+    pd = {n: ((torch.rand(s) - 0.5) * 0.2).to(DEV) for n, s in shape.param_shapes().items()}
+    x = torch.randn(he).to(DEV)
+    theta, acts = ops.hyper_forward(shape, pd, x)
+    dths = [torch.randn(theta.numel()).to(DEV), (torch.randn(theta.numel()) * 3).to(DEV)]
+    names = [n for n in shape.param_shapes() if not n.endswith(".2.weight")]
+
+    def run(dth):
+        grads = {n: torch.full(s, float("nan"), device=DEV) for n, s in shape.param_shapes().items() if not n.endswith(".2.weight")}
+        gx = ops.hyper_backward(shape, pd, dth, acts, grads, want_x=True)
+        return {**{n: grads[n].clone() for n in names if n in grads}, "x": gx.clone()}
+    try:
+        L.load().caphn_tune(27, 0)
+        ref = [run(d) for d in dths]
+        L.load().caphn_tune(27, 1)
+        side = torch.cuda.Stream()
+        A = torch.randn(4096, 4096, device=DEV)
+        first = [None, None]
+        for it in range(24):
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    ops.gemm(A, A)
+            got = run(dths[it & 1])
+            torch.cuda.synchronize()
+            for n, t in got.items():
+                assert torch.isfinite(t).all(), n
+                assert rel_err(t, ref[it & 1][n]) < 1e-5, (it, n)
+            if first[it & 1] is None:
+                first[it & 1] = got
+            else:
+                for n, t in got.items():
+                    assert torch.equal(t, first[it & 1][n]), (it, n)
+        assert ops.device_error() == 0
+    finally:
+        L.load().caphn_tune(27, 0)
 
 
 @pytest.mark.parametrize("name", ["gru_tiny_flickr", "gru_tiny_cc", "gru_odd_cc"])

@@ -400,11 +400,13 @@ def test_next_precompute_overlaps_optimizer(name):
     tc = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
     tc.overlap_level = 2
     te = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
-    te.overlap_level = 3         # (the default) split front: G behind the W_ih pass, x-side gates behind the b_ih pass
+    te.overlap_level = 3         # split front: G behind the W_ih pass, x-side gates behind the b_ih pass
+    tf = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
+    tf.overlap_level = 4         # ... and the theta-independent part issued before the rank-1 passes
     caps2 = caps.clone(); caps2[:, 2] = (caps2[:, 2] + 3) % dims.V
     cseq = [caps, caps2, caps, caps2, caps2]         # level 2 also announces the captions (last one wrong again)
     cann = [caps2, caps, caps2, caps, None]
-    la, lb, lc, ld, le = [], [], [], [], []
+    la, lb, lc, ld, le, lf = [], [], [], [], [], []
     td = FusedTrainer(build_net(dims, p, cc=tok is None), lr=1e-3)
     for i, f in enumerate(seq):
         la.append(float(ta.step(f, caps, x_style=xs, style_token=tok)[0]))
@@ -420,6 +422,10 @@ def test_next_precompute_overlaps_optimizer(name):
         if ann[i] is not None:
             assert tc._pre_key is not None and tc._pre_key[-1] == 2
             assert te._pre_key is not None and te._pre_key[-1] == 3
+        lf.append(float(tf.step(f, cseq[i], x_style=xs, style_token=tok, next_x_style=xs, next_style_token=tok,
+                                next_features=ann[i], next_captions=cann[i])[0]))
+        if ann[i] is not None:
+            assert tf._pre_key is not None and tf._pre_key[-1] == 3 and tf._theta_pre is tf._theta_next
     assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
     assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 2e-5
     assert max(abs(a - b) for a, b in zip(ld, lc)) < 2e-5, (ld, lc)
@@ -428,6 +434,8 @@ def test_next_precompute_overlaps_optimizer(name):
     assert maxdiff(td.flat_p.cpu(), te.flat_p.cpu()) < 2e-5
     for a, b in zip(td.W2, te.W2):
         assert maxdiff(a.data.cpu(), b.data.cpu()) < 2e-5
+    assert max(abs(a - b) for a, b in zip(ld, lf)) < 2e-5, (ld, lf)
+    assert maxdiff(td.flat_p.cpu(), tf.flat_p.cpu()) < 2e-5
 
 
 @pytest.mark.parametrize("B,T,P", [(1, 1, 1), (1, 2, 1), (2, 3, 2), (3, 2, 64), (1, 5, 65)])
