@@ -128,7 +128,7 @@ class FusedTrainer:
         self.zero_by_adam = os.environ.get("CAPHN_ZERO_BY_ADAM", "1") == "1"
         self._zero_lo_by_adam = False
         self._aux_joined = False
-        self.ctx_in_forward = os.environ.get("CAPHN_CTX_IN_FORWARD", "0") == "1"
+        self.ctx_in_forward = os.environ.get("CAPHN_CTX_IN_FORWARD", "1") == "1"
 
     # ------------------------------------------------------------------ parameter arenas
     def _build_arena(self):
@@ -486,8 +486,9 @@ class FusedTrainer:
         dv = buf.get("dims_variants") if dims is buf["dims"] else None
         if dv is None:
             import dataclasses
-            # bit 8 on both sides of the step: d Hs zero-filled by the forward's prep kernel (bit 32 -- ctx left by the forward --
-            # is no longer used here: the backward forms ctx on its vocabulary-gradient branch, beside BPTT)
+            # bit 8 on both sides of the step: d Hs zero-filled by the forward's prep kernel; bit 32: ctx left by the forward (the
+            # alternative -- ctx_in_forward = False: the backward forms it on a branch of its own beside BPTT -- measured equal
+            # to 7 us slower, profiles/r03_step_boundary_ab.txt)
             dv = {p: dataclasses.replace(dims, pre=p | 8 | (32 if self.ctx_in_forward else 0)) for p in (0, 1, 5, 7, 21)}
             if dims is buf["dims"]:          # (with decoder dropout the dims carry a fresh seed every step: not cached)
                 buf["dims_variants"] = dv

@@ -10,7 +10,7 @@ python3 bench.py --steps 50 --warmup 5 "$@" > "$out/bench.json" 2> "$out/bench.e
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -o tr -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" > "$out/prof_bench.log" 2>&1
 f=$(find "$out/prof" -name "*kernel_trace.csv" | head -1)
 cp "$f" "$out/kernel_trace.csv"
-python3 tools/timeline.py "$f" > "$out/timeline.txt"
+python3 tools/timeline.py "$f" --marker grad_norm_partials --step 20 > "$out/timeline.txt"
 cp "$(find "$out/prof" -name "*kernel_stats.csv" | head -1)" "$out/kernel_stats.csv"
 rm -rf "$out/prof"
 grep -o '"ms_per_step": [0-9.]*' "$out/bench.json"
