@@ -128,6 +128,7 @@ class FusedTrainer:
         self.zero_by_adam = os.environ.get("CAPHN_ZERO_BY_ADAM", "1") == "1"
         self._zero_lo_by_adam = False
         self._aux_joined = False
+        self._fork0_ev = None
         self.ctx_in_forward = os.environ.get("CAPHN_CTX_IN_FORWARD", "1") == "1"
 
     # ------------------------------------------------------------------ parameter arenas
@@ -757,7 +758,7 @@ class FusedTrainer:
                               zero_gfac=zg, **kw)
             else:
                 ops.adam_rank_multi(jobs, self._coef, self.lr, step, self.betas, self.eps, dev_scalars=dev_sc, zero_gfac=zg)
-            if fork_after in members and next_batch is not None:
+            if fork_after in members and next_batch is not None and not early:
                 # the side stream starts HERE on the device (an event), but its launches are enqueued after the remaining passes:
                 # the host otherwise spends ~50 us on the precompute's launches before it gets to the next pass
                 if self._fork_ev is None:
@@ -803,7 +804,7 @@ class FusedTrainer:
         with torch.cuda.stream(aux):
             ops.decoder_inputs(self._dims_pre(buf, dims, 64), params, captions, buf["ws"])
         self._aux_pending = True
-        self._pre_stream.wait_event(self._fork_ev)
+        self._pre_stream.wait_event(self._bih_ev)      # (one record behind the bias heads serves both: W_ih is older than that)
         with torch.cuda.stream(self._pre_stream):
             # (pre bits on this call: 1 = the theta-independent part is in the workspace already, 4 = the x side is the other stream's)
             ops.decoder_precompute(self._dims_pre(buf, dims, 1 | 4), params, features, buf["ws"], captions=captions)
@@ -833,10 +834,14 @@ class FusedTrainer:
                                                      else torch.empty(self.theta_size, device=self.dev))
         params = self._dec_tensors(theta, grads=False)
         main = torch.cuda.current_stream()
-        if after is not None:
-            self._pre_stream.wait_event(after)
-        else:
-            self._pre_stream.wait_stream(main)
+        if after is None:
+            # ONE record on the caller's stream for both side streams (a record costs the recording stream ~6 us of queue time:
+            # two of them sat between the dense Adam launch and the GEMVs of the next activations)
+            if self._fork0_ev is None:
+                self._fork0_ev = torch.cuda.Event()
+            self._fork0_ev.record(main)
+            after = self._fork0_ev
+        self._pre_stream.wait_event(after)
         lookup = (level in (1, 3) and captions is not None and captions.dtype == torch.int64 and captions.is_contiguous()
                   and tuple(captions.shape) == (B, T) and (level == 3 or lookup_dp or not dp.active(self.group)))
         if level == 3 and not lookup:
@@ -850,10 +855,7 @@ class FusedTrainer:
             if aux is None:
                 aux = self._aux_stream = torch.cuda.Stream(device=self.dev)
                 self._lookup_done = torch.cuda.Event()
-            if after is not None:
-                aux.wait_event(after)
-            else:
-                aux.wait_stream(main)
+            aux.wait_event(after)
             clear = not dp.active(self.group)
             with torch.cuda.stream(aux):
                 if clear:
@@ -889,7 +891,9 @@ class FusedTrainer:
         """clip_grad_norm_(max_norm) over ALL gradients + Adam, on device, no host sync.
         If the NEXT minibatch's style row is already known (the data loader is one batch ahead), pass it:
         the Adam pass over the big second-layer weights then also produces the next step's theta, saving that
-        step's 576 MB forward read (the following forward_backward must be called with that same input)."""
+        step's 576 MB forward read (the following forward_backward must be called with that same input).
+        On one rank the rank-1 passes CONSUME d theta (they clear it behind their read, zero_by_adam): grad() of the generated
+        cell weights / w2_grad_dense() are meaningful between forward_backward and this call, not after it."""
         self._begin_step()
         return self._optimizer_impl(next_x_style, next_style_token, next_batch, next_domain_input)
 

@@ -259,6 +259,17 @@ def test_hypernet_lstm_module_and_engine():
     for _ in range(5):
         l = tr.step(feats, caps, x_style=x.to(DEV))
     assert float(l[0]) < l0
+    # the announced next minibatch (split front of the next forward beside the rank-1 passes, overlap_level 4) with the LSTM cell's
+    # four heads: same trajectory as the plain step
+    ta, tb = FusedTrainer(build(), lr=1e-3), FusedTrainer(build(), lr=1e-3)
+    xs = x.to(DEV)
+    la = [float(ta.step(feats, caps, x_style=xs)[0]) for _ in range(3)]
+    lb = []
+    for _ in range(3):
+        lb.append(float(tb.step(feats, caps, x_style=xs, next_x_style=xs, next_features=feats, next_captions=caps)[0]))
+        assert tb._pre_key is not None and tb._pre_key[-1] == 3
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
+    assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 2e-5
 
 
 @pytest.mark.parametrize("name", CASES)
