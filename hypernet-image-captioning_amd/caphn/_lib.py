@@ -57,7 +57,12 @@ class AdamHParams(C.Structure):
 
 class RankJob(C.Structure):
     _fields_ = [("W", c_fp), ("m", c_fp), ("v", c_fp), ("gfac", c_fp), ("ldg", C.c_size_t), ("afac", c_fp), ("lda", C.c_size_t),
-                ("next_a", c_fp), ("next_bias", c_fp), ("next_theta", c_fp), ("rows", C.c_int), ("k", C.c_int)]
+                ("next_a", c_fp), ("next_bias", c_fp), ("next_theta", c_fp), ("rows", C.c_int), ("k", C.c_int),
+                ("next_pack", c_fp), ("pack_H", C.c_int), ("pack_HA", C.c_int), ("pack_pitch", C.c_int), ("pack_hrows", C.c_int)]
+
+
+class PairPack(C.Structure):
+    _fields_ = [("wp", c_fp), ("H", C.c_int), ("HA", C.c_int), ("pitch", C.c_int), ("hrows", C.c_int)]
 
 
 MAX_LAYERS = 4
@@ -116,6 +121,8 @@ SIGNATURES = {
     "caphn_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDims)]),
     "caphn_decoder_forward": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp,
                                         c_fp, c_fp, c_fp, c_fp]),
+    "caphn_decoder_pair_prep": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp]),
+    "caphn_decoder_pair_pack_desc": (C.c_int, [C.POINTER(DecoderDims), c_fp, C.POINTER(PairPack)]),
     "caphn_decoder_precompute": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp, c_fp, c_fp]),
     "caphn_decoder_inputs": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp, c_fp]),
     "caphn_decoder_lookup": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), c_fp, c_fp, c_fp]),

@@ -128,6 +128,8 @@ class FusedTrainer:
         self.zero_by_adam = os.environ.get("CAPHN_ZERO_BY_ADAM", "1") == "1"
         self._zero_lo_by_adam = False
         self._aux_joined = False
+        self._pair_packed = None
+        self.pack_in_adam = os.environ.get("CAPHN_PACK_IN_ADAM", "1") == "1"
         self._fork0_ev = None
         self.ctx_in_forward = os.environ.get("CAPHN_CTX_IN_FORWARD", "1") == "1"
 
@@ -490,9 +492,14 @@ class FusedTrainer:
             # bit 8 on both sides of the step: d Hs zero-filled by the forward's prep kernel; bit 32: ctx left by the forward (the
             # alternative -- ctx_in_forward = False: the backward forms it on a branch of its own beside BPTT -- measured equal
             # to 7 us slower, profiles/r03_step_boundary_ab.txt)
-            dv = {p: dataclasses.replace(dims, pre=p | 8 | (32 if self.ctx_in_forward else 0)) for p in (0, 1, 5, 7, 21)}
+            dv = {p: dataclasses.replace(dims, pre=p | 8 | (32 if self.ctx_in_forward else 0)) for p in (0, 1, 5, 7, 21, 7 | 128)}
             if dims is buf["dims"]:          # (with decoder dropout the dims carry a fresh seed every step: not cached)
                 buf["dims_variants"] = dv
+        packed, self._pair_packed = self._pair_packed, None
+        if pre == 7 and packed is not None:
+            pk = ops.decoder_pair_pack_desc(dims, buf["ws"])
+            if pk is not None and packed == (pk.wp, theta.data_ptr()):
+                pre = 7 | 128        # the recurrent kernels' prep launch was issued beside the optimiser, W_hh packed by its pass
         fdims = dv[pre]
         if dims.rows and not rows_done:
             ops.decoder_prepare_rows(dims, captions, 0, buf["ws"])
@@ -703,9 +710,21 @@ class FusedTrainer:
         # before the W_ih pass arrives (ten microseconds of head start: 84 us instead of 256 for feature_fc.0 beside a rank-1 pass);
         # beside the LAST pass only the two GEMMs that need theta are left (G, x-side gates: done long before the pass ends)
         early = split and self.overlap_level >= 4
+        pack = None
         if early:
             self._precompute_next(*next_batch, level=1, lookup_dp=True)
             early = self._pre_key is not None and self._pre_key[1] is not None     # (the captions were looked up)
+            if early and self.pack_in_adam:
+                # the pair recurrent kernels' prep launch (exchange areas, d Hs, the U_a rows of the packed weight copy) goes to the
+                # caption-side stream now; the W_hh rows are written by the W_hh pass itself: nothing is left between the last
+                # rank-1 pass and the next recurrent kernel
+                nf, nc, nT = next_batch
+                nbuf = self._buffers(nf.shape[0], nT, nf.shape[1])
+                pack = ops.decoder_pair_pack_desc(nbuf["dims"], nbuf["ws"])
+                if pack is not None:
+                    with torch.cuda.stream(self._aux_stream):
+                        ops.decoder_pair_prep(nbuf["dims"], self._dec_tensors(self._theta, grads=False), nbuf["ws"])
+                        self._lookup_done.record(self._aux_stream)
         if prefetch:
             # the small layers (and the style row of the embedding / the front-end) are already updated: compute the next
             # step's head activations, then let the rank-1 Adam pass emit theta_next = W2' a' + b2' row by row
@@ -751,7 +770,10 @@ class FusedTrainer:
                 if prefetch:
                     job += [self._acts_next[ao:ao + an], self._owned[f"hn_heads.{i}.2.bias"].data, self._theta_next[o:o + w]]
                 jobs.append(job)
-            if len(jobs) == 1:
+            if len(jobs) == 1 and pack is not None and members[0] == 1:
+                ops.adam_rank_multi(jobs, self._coef, self.lr, step, self.betas, self.eps, dev_scalars=dev_sc, zero_gfac=zg, packs=[pack])
+                self._pair_packed = (pack.wp, self._theta_next.data_ptr())
+            elif len(jobs) == 1:
                 j = jobs[0]
                 kw = dict(next_a=j[5], next_bias=j[6], next_theta=j[7]) if prefetch else {}
                 ops.adam_rank(j[0], j[1], j[2], j[3], j[4], self._coef, self.lr, step, self.betas, self.eps, dev_scalars=dev_sc,

@@ -444,6 +444,25 @@ def decoder_precompute(dims: DecDims, params: Dict[str, torch.Tensor], features:
                                          L.stream_ptr()), "caphn_decoder_precompute")
 
 
+def decoder_pair_pack_desc(dims: DecDims, ws: torch.Tensor):
+    """Where the pair recurrent kernels keep their packed copy of W_hh inside `ws` (caphn_decoder_pair_pack_desc): a _lib.PairPack,
+    or None when these dims do not run the pair kernels."""
+    lib = L.load()
+    cd = dims.c()
+    out = L.PairPack()
+    rc = lib.caphn_decoder_pair_pack_desc(C.byref(cd), C.c_void_p(ws.data_ptr()), C.byref(out))
+    return out if rc == 0 else None
+
+
+def decoder_pair_prep(dims: DecDims, params: Dict[str, torch.Tensor], ws: torch.Tensor) -> None:
+    """The pair recurrent kernels' prep launch ahead of the forward (exchange areas, d Hs accumulator, U_a rows of the packed weight
+    copy; the W_hh rows come from adam_rank_multi(..., pack=...)): follow with decoder_forward(dims with pre | 128)."""
+    lib = L.load()
+    cd = dims.c()
+    ps = _dec_struct(L.DecoderParams, dims, params)
+    L.check(lib.caphn_decoder_pair_prep(C.byref(cd), C.byref(ps), C.c_void_p(ws.data_ptr()), L.stream_ptr()), "caphn_decoder_pair_prep")
+
+
 def decoder_inputs(dims: DecDims, params: Dict[str, torch.Tensor], captions: torch.Tensor, ws: torch.Tensor) -> None:
     """Embedding lookup + x-side gate pre-activations of the forward (decoderlstm.py:62, :82-88, :100) ahead of the
     rest; follow with decoder_forward(dims with pre | 4)."""
@@ -899,9 +918,10 @@ def adam_rank(W, m, v, gfac, afac, coef, lr, step, betas=(0.9, 0.999), eps=1e-8,
                                              L.stream_ptr()), "caphn_adam_rank_gemv_f32")
 
 
-def adam_rank_multi(members, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_scalars=None, zero_gfac=False) -> None:
+def adam_rank_multi(members, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_scalars=None, zero_gfac=False, packs=None) -> None:
     """adam_rank over several members in one launch (the hypernet's small heads are launch-bound one by one).  members: tuples
-    (W, m, v, gfac, afac) or (W, m, v, gfac, afac, next_a, next_bias, next_theta); all with the same number of factors R."""
+    (W, m, v, gfac, afac) or (W, m, v, gfac, afac, next_a, next_bias, next_theta); all with the same number of factors R.
+    packs: per member None or a _lib.PairPack (decoder_pair_pack_desc) -- next_theta is also stored in that packed W_hh copy."""
     lib = L.load()
     hp = _hp(lr, betas, eps, step, dev_scalars, zero_gfac)
     jobs = (L.RankJob * len(members))()
@@ -917,6 +937,10 @@ def adam_rank_multi(members, coef, lr, step, betas=(0.9, 0.999), eps=1e-8, dev_s
             na, nb, nt = mb[5:8]
             assert na.numel() == k and nb.numel() == rows and nt.numel() == rows
             j.next_a, j.next_bias, j.next_theta = na.data_ptr(), nb.data_ptr(), nt.data_ptr()
+    if packs is not None:
+        for j, pk in zip(jobs, packs):
+            if pk is not None:
+                j.next_pack, j.pack_H, j.pack_HA, j.pack_pitch, j.pack_hrows = pk.wp, pk.H, pk.HA, pk.pitch, pk.hrows
     L.check(lib.caphn_adam_rank_multi_f32(R, len(members), jobs, L.ptr(coef), C.byref(hp), L.stream_ptr()), "caphn_adam_rank_multi_f32")
 
 

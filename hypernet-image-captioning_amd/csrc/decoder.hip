@@ -522,6 +522,24 @@ extern "C" int caphn_decoder_precompute(const caphn_decoder_dims* d, const caphn
     return caphn_launch_status();
 }
 
+extern "C" int caphn_decoder_pair_prep(const caphn_decoder_dims* d, const caphn_decoder_params* p, void* ws_, caphn_stream_t stream) {
+    if (!dims_ok(d) || !p || !ws_ || !p->Ua_w || !use_pair(d)) return CAPHN_EINVAL;
+    const Ws w = layout(d);
+    float* ws = static_cast<float*>(ws_);
+    RUN(caphn_launch_rec_pair_prep(reinterpret_cast<unsigned long long*>(ws + w.xch), 2 * w.xch_floats * sizeof(float) / sizeof(unsigned long long),
+                                   p->Ua_w, nullptr, d->H, w.NG, ws + w.wp, ws + w.dHs, (size_t)d->B * d->T * d->H,
+                                   static_cast<hipStream_t>(stream)));
+    return caphn_launch_status();
+}
+extern "C" int caphn_decoder_pair_pack_desc(const caphn_decoder_dims* d, void* ws_, caphn_pair_pack* out) {
+    if (!dims_ok(d) || !ws_ || !out || !use_pair(d)) return CAPHN_EINVAL;
+    const Ws w = layout(d);
+    out->wp = static_cast<float*>(ws_) + w.wp;
+    out->H = d->H; out->HA = caphn_rec_pair_half_a(d->H); out->pitch = caphn_rec_pair_pitch(d->H);
+    out->hrows = (w.NG + 1) * out->HA;
+    return CAPHN_OK;
+}
+
 extern "C" int caphn_decoder_inputs(const caphn_decoder_dims* d, const caphn_decoder_params* p, const int64_t* captions,
                                     void* ws_, caphn_stream_t stream) {
     if (!dims_ok(d) || !p || !captions || !ws_ || !p->embed_w || !p->w_ih || !p->b_ih) return CAPHN_EINVAL;
@@ -585,6 +603,7 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     if (pair) {
         a.xch = reinterpret_cast<unsigned long long*>(ws + w.xch);
         a.WP = ws + w.wp; a.wp_pitch = caphn_rec_pair_pitch(H);
+        if (!(pc & 128))       // (bit 128: caphn_decoder_pair_prep + the optimiser's pass left everything in place)
         RUN(caphn_launch_rec_pair_prep(a.xch, 2 * w.xch_floats * sizeof(float) / sizeof(unsigned long long), p->Ua_w, p->w_hh, H, w.NG,
                                        ws + w.wp, (pc & 8) ? ws + w.dHs : nullptr, (size_t)BT * H, s));
         RUN(caphn_launch_rec_pair_fwd(a, lstm, s));

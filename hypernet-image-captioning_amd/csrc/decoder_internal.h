@@ -105,6 +105,7 @@ int caphn_rec_pair_resident_gates(int P, int H, int NG);
 size_t caphn_rec_pair_xch_bytes(int B, int P, int H);
 int caphn_rec_pair_bwd_groups(int P, int H);
 int caphn_rec_pair_pitch(int H);
+int caphn_rec_pair_half_a(int H);      // rows (and hidden indices) of the first half
 size_t caphn_rec_pair_wp_floats(int H, int NG);
 int caphn_launch_rec_pair_prep(unsigned long long* xch, size_t nxch, const float* U_a, const float* W_hh, int H, int NG, float* WP,
                                float* zbuf, size_t nz, hipStream_t s);      // zbuf (optional): nz floats zero-filled on the way

@@ -512,7 +512,21 @@ __global__ __launch_bounds__(256) void adam_dense_clip_kernel(size_t n, float* _
 // (row-contiguous dwordx4 streams of W, m and v: read 12 B, write 12 B per element).
 // RB rows per wave iteration (3*RB*QMAX independent dwordx4 loads in flight), NTL / NTS: non-temporal
 // loads / stores.  Variant chosen by caphn_tune(1, v) -- measured A/B.
-struct NextGemv { const float* a; const float* bias; float* theta; };   // theta[row] = W'[row,:] . a + bias[row]
+struct NextGemv {                      // theta[row] = W'[row,:] . a + bias[row]
+    const float* a; const float* bias; float* theta;
+    // optional second copy of theta[row] in the pair recurrent kernels' packed per-half layout (caphn_rank_job::next_pack): row is an
+    // element index of W_hh [NG H, H]; element (R, c) of gate block q = R / H, j = R % H goes to half hh = (j >= HA), local row
+    // (q + 1) nk_hh + (j - k0_hh), column c
+    float* pack = nullptr; int pH = 0, pHA = 0, ppitch = 0, phrows = 0;
+};
+__device__ __forceinline__ void next_store(const NextGemv& nx, int row, float v) {
+    nx.theta[row] = v;
+    if (nx.pack) {
+        const int R = row / nx.pH, c = row - R * nx.pH, q = R / nx.pH, j = R - q * nx.pH;
+        const int hh = j >= nx.pHA ? 1 : 0, kk = j - (hh ? nx.pHA : 0), nk = hh ? nx.pH - nx.pHA : nx.pHA;
+        nx.pack[((size_t)hh * nx.phrows + (size_t)(q + 1) * nk + kk) * nx.ppitch + c] = v;
+    }
+}
 template <int QMAX, int RB, bool NTL, bool NTS, bool MULTI>
 __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W, float* m, float* v,
                                                const float* gfac, size_t ldg, const float* afac, size_t lda,
@@ -602,7 +616,7 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
             }
             if (nx.a) {                      // wave-uniform
                 dot = wave_sum(dot);
-                if (lane == 0) nx.theta[row0 + i] = dot + nx.bias[row0 + i];
+                if (lane == 0) next_store(nx, row0 + i, dot + nx.bias[row0 + i]);
             }
         }
     }
@@ -717,7 +731,7 @@ __global__ __launch_bounds__(256) void adam_rank_long_kernel(int R, int rows, in
         }
         if (na) {
             dot = wave_sum(dot);
-            if (lane == 0) nx.theta[r] = dot + nx.bias[r];
+            if (lane == 0) next_store(nx, r, dot + nx.bias[r]);
         }
     }
 }
@@ -728,7 +742,7 @@ __global__ __launch_bounds__(256) void rowdot_kernel(int rows, int k, const floa
         float sum = 0.f;
         for (int c = s; c < k; c += 8) sum += W[(size_t)r * k + c] * nx.a[c];
         sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 1, 64);
-        if (s == 0) nx.theta[r] = sum + nx.bias[r];
+        if (s == 0) next_store(nx, r, sum + nx.bias[r]);
     }
 }
 
@@ -1148,6 +1162,8 @@ extern "C" int caphn_adam_rank_multi_f32(int R, int njobs, const caphn_rank_job*
         const caphn_rank_job& j = jobs[i];
         if (j.rows <= 0 || j.k <= 0 || !j.W || !j.m || !j.v || !j.gfac || !j.afac) return CAPHN_EINVAL;
         if ((j.next_a != nullptr) != (j.next_theta != nullptr) || (j.next_a != nullptr) != (j.next_bias != nullptr)) return CAPHN_EINVAL;
+        if (j.next_pack && (!j.next_a || j.pack_H <= 0 || j.pack_HA <= 0 || j.pack_HA > j.pack_H || j.pack_pitch < j.pack_H || j.pack_hrows <= 0 ||
+                            (long)j.rows % ((long)j.pack_H * j.pack_H) != 0)) return CAPHN_EINVAL;
         const bool vec = (j.k % 4 == 0) && (j.lda % 4 == 0) && caphn_aligned16(j.W) && caphn_aligned16(j.m) && caphn_aligned16(j.v) &&
                          caphn_aligned16(j.afac) && (!j.next_a || caphn_aligned16(j.next_a));
         one = one && vec && j.k <= 2048 && qclass(j.k) == qclass(jobs[0].k) && ((j.next_a != nullptr) == (jobs[0].next_a != nullptr)) &&
@@ -1159,7 +1175,7 @@ extern "C" int caphn_adam_rank_multi_f32(int R, int njobs, const caphn_rank_job*
         for (int i = 0; i < njobs; ++i) {
             const caphn_rank_job& j = jobs[i];
             int rc = adam_rank_launch(R, j.rows, j.k, j.W, j.m, j.v, j.gfac, j.ldg, j.afac, j.lda, coef, hp,
-                                      NextGemv{j.next_a, j.next_bias, j.next_theta}, stream);
+                                      NextGemv{j.next_a, j.next_bias, j.next_theta, j.next_pack, j.pack_H, j.pack_HA, j.pack_pitch, j.pack_hrows}, stream);
             if (rc != CAPHN_OK) return rc;
         }
         return CAPHN_OK;
@@ -1167,7 +1183,8 @@ extern "C" int caphn_adam_rank_multi_f32(int R, int njobs, const caphn_rank_job*
     RankJobs J;
     for (int i = 0; i < njobs; ++i) {
         const caphn_rank_job& j = jobs[i];
-        J.j[i] = RankJob{j.W, j.m, j.v, j.gfac, j.ldg, j.afac, j.lda, NextGemv{j.next_a, j.next_bias, j.next_theta}, j.rows, j.k};
+        J.j[i] = RankJob{j.W, j.m, j.v, j.gfac, j.ldg, j.afac, j.lda,
+                         NextGemv{j.next_a, j.next_bias, j.next_theta, j.next_pack, j.pack_H, j.pack_HA, j.pack_pitch, j.pack_hrows}, j.rows, j.k};
     }
     const int use_lds = R > 1 && a_bytes <= 60 * 1024;
     const size_t shm = use_lds ? a_bytes : 0;

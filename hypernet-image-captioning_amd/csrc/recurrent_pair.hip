@@ -1012,6 +1012,10 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(u64* __restrict__ xch, s
     // packed layout: WP[half][local row r = q' nk_half + kk][pitch], q' = 0 the rows of U_a, 1 + q gate block q of W_hh, restricted
     // to the half's k range [k0, k0 + nk); each half has room for (NG + 1) nkm rows (nkm = the wider half)
     const int HA = half_a(H), NGp1 = rows / H, hrows = NGp1 * HA;
+    // (W_hh == nullptr -- caphn_decoder_pair_prep: the W_hh rows are written by the optimiser's rank-1 pass; only their pad columns
+    //  are cleared here, the U_a rows are packed as usual)
+    const bool lite = W_hh == nullptr;
+    auto is_whh = [&](int hh, int r) { const int nk = hh ? H - HA : HA; return r >= nk && r < NGp1 * nk; };
     auto src_row = [&](int hh, int r) -> const float* {
         const int k0 = hh ? HA : 0, nk = hh ? H - HA : HA;
         if (r >= NGp1 * nk) return nullptr;
@@ -1024,12 +1028,20 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(u64* __restrict__ xch, s
         const int n4 = H >> 2, p4 = pitch >> 2;
         for (size_t j = i0; j < (size_t)2 * hrows * p4; j += stride) {
             const int rr = (int)(j / p4), c = (int)(j % p4);
+            if (lite && is_whh(rr / hrows, rr % hrows)) {
+                if (c >= n4) reinterpret_cast<f32x4*>(WP + (size_t)rr * pitch)[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
             const float* src = src_row(rr / hrows, rr % hrows);
             reinterpret_cast<f32x4*>(WP + (size_t)rr * pitch)[c] = (src && c < n4) ? reinterpret_cast<const f32x4*>(src)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     } else {
         for (size_t j = i0; j < (size_t)2 * hrows * pitch; j += stride) {
             const int rr = (int)(j / pitch), c = (int)(j % pitch);
+            if (lite && is_whh(rr / hrows, rr % hrows)) {
+                if (c >= H) WP[(size_t)rr * pitch + c] = 0.f;
+                continue;
+            }
             const float* src = src_row(rr / hrows, rr % hrows);
             WP[(size_t)rr * pitch + c] = (src && c < H) ? src[c] : 0.f;
         }
@@ -1039,6 +1051,7 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(u64* __restrict__ xch, s
 }  // namespace
 // (at least one full column block of the mat-vec, 32 JM floats: see the pad note in pair_prep_kernel)
 int caphn_rec_pair_pitch(int H) { const int p = (H + 31) & ~31; return p < 32 * JM ? 32 * JM : p; }
+int caphn_rec_pair_half_a(int H) { return half_a(H); }
 size_t caphn_rec_pair_wp_floats(int H, int NG) { return (size_t)2 * (NG + 1) * half_a(H) * caphn_rec_pair_pitch(H); }
 int caphn_launch_rec_pair_prep(unsigned long long* xch, size_t nxch, const float* U_a, const float* W_hh, int H, int NG, float* WP,
                                float* zbuf, size_t nz, hipStream_t s) {

@@ -215,7 +215,9 @@ typedef struct caphn_decoder_dims {
                            recurrent kernel (not inside a stream capture).  Bit 32, given to BOTH the forward and the backward of a
                            training step: the forward also leaves the context vectors ctx_t = sum_p alpha_tp f_p (the operand of
                            dW_ih it never forms itself) in the workspace, and the backward skips that kernel on its chain to d theta.
-                           Bit 64: the embedding lookup (caphn_decoder_lookup) is already in the workspace */
+                           Bit 64: the embedding lookup (caphn_decoder_lookup) is already in the workspace.  Bit 128 (pair recurrent
+                           kernels only): caphn_decoder_pair_prep has run on this workspace since the last backward AND the packed
+                           copy of W_hh is current (caphn_rank_job::next_pack): the forward skips its prep launch */
     int layers;         /* num_layers of AttentionGru (models/decoderlstm.py:34-36): 1 (or 0) = the cell alone; L > 1 adds L - 1 GRUCells
                            applied as h = layer(h, h) after the attention cell at every time step (:101-103).  Then the time loop
                            runs one launch window per step (the extra cells are small batched GEMMs + a gate kernel between the
@@ -286,6 +288,15 @@ int caphn_decoder_inputs(const caphn_decoder_dims* d, const caphn_decoder_params
  * the optimiser; caphn_decoder_inputs / _forward with dims.precomputed bit 64 then skip the lookup and run the gate GEMM only. */
 int caphn_decoder_lookup(const caphn_decoder_dims* d, const caphn_decoder_params* p, const int64_t* captions, void* ws,
                          caphn_stream_t stream);
+/* The pair recurrent kernels' prep launch, issued ahead of the forward (e.g. beside the optimiser's rank-1 passes, on a side stream;
+ * never while a forward / backward on this workspace is running): clears the exchange areas and the backward's d Hs accumulator and
+ * packs U_a (attention.U_a, a dense parameter) into the per-half weight copy; the W_hh rows of that copy are left to the caller --
+ * caphn_adam_rank_multi_f32 with caphn_rank_job::next_pack writes them while it produces the next theta.  CAPHN_EINVAL when these
+ * dims do not run the pair kernels.  caphn_decoder_pair_pack_desc: where and how (device address inside ws, H, HA = rows of the
+ * first half, row pitch, rows reserved per half). */
+typedef struct caphn_pair_pack { float* wp; int H, HA, pitch, hrows; } caphn_pair_pack;
+int caphn_decoder_pair_prep(const caphn_decoder_dims* d, const caphn_decoder_params* p, void* ws, caphn_stream_t stream);
+int caphn_decoder_pair_pack_desc(const caphn_decoder_dims* d, void* ws, caphn_pair_pack* out);
 /* Compacts the (b,t) rows whose target differs from ignore_index into a row map kept in the workspace (count stays on
  * the device: no host synchronisation).  Call before caphn_decoder_forward / _backward with dims.row_subset = 1. */
 /* Device address of the live-row count that caphn_decoder_prepare_rows leaves in the workspace. */
@@ -548,6 +559,10 @@ typedef struct caphn_rank_job {
     const float* afac; size_t lda;            /* [R, k] column factors */
     const float* next_a; const float* next_bias; float* next_theta;
     int rows, k;
+    /* optional (with next_*): the member is the generated W_hh [NG H, H] of the decoder and next_theta[row] is ALSO stored at its place
+     * in the pair recurrent kernels' packed per-half copy -- address and layout from caphn_decoder_pair_pack_desc -- so that the next
+     * forward needs no packing launch between this pass and its recurrent kernel (dims.precomputed bit 128).  NULL = off. */
+    float* next_pack; int pack_H, pack_HA, pack_pitch, pack_hrows;
 } caphn_rank_job;
 int caphn_adam_rank_multi_f32(int R, int njobs, const caphn_rank_job* jobs, const float* coef, const caphn_adam_hparams* hp,
                               caphn_stream_t stream);

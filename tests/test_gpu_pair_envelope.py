@@ -151,3 +151,58 @@ def test_a_partner_that_never_answers_is_reported_not_hidden(ops, lib):
     again = _run(ops, dims, p, batch, theta, backward=False)
     torch.cuda.synchronize()
     assert lib.caphn_device_error(0) == 0 and torch.equal(again["logits"], good["logits"])
+
+
+@pytest.mark.parametrize("H,B", [(200, 9), (12, 3)])
+def test_prep_ahead_and_weights_packed_by_the_adam_pass(ops, lib, H, B):
+    """caphn_decoder_pair_prep (exchange areas, d Hs, U_a rows) + caphn_adam_rank_multi_f32 with caphn_rank_job::next_pack (the W_hh
+    rows, written while the pass produces the next theta) leave the pair kernels' packed weight copy exactly as the forward's own prep
+    launch builds it from that theta -- and a forward given dims.precomputed bit 128 on top of them reproduces the ordinary forward and
+    backward bit for bit (models/decoderlstm.py:78-108; the optimiser of cc_train_hypernet.py:110-120 in front of it)."""
+    dims, p, batch, theta = _case(B, H=H, P=49 if H == 200 else 5, seed=8)
+    Bc, T = batch["captions"].shape
+    P = batch["features"].shape[1]
+    dd = dec_dims(dims, Bc, T, P)
+    feats, caps = batch["features"].to(DEV), batch["captions"].to(DEV)
+    # an "Adam pass" over a stand-in second layer W2 [3 H H, k] whose next theta = W2' a + b is the next W_hh
+    g = torch.Generator().manual_seed(H)
+    k, rows = 16, 3 * H * H
+    W = (torch.randn(rows, k, generator=g) * 0.05).to(DEV)
+    m, v = torch.zeros_like(W), torch.zeros_like(W)
+    gf, af = (torch.randn(1, rows, generator=g) * 0.01).to(DEV), torch.randn(1, k, generator=g).to(DEV)
+    na, nb = torch.randn(k, generator=g).to(DEV), (torch.randn(rows, generator=g) * 0.05).to(DEV)
+    whh_next = torch.zeros(rows, device=DEV)
+    coef = torch.tensor([1.0, 0.0], device=DEV)
+    ws_a = ops.decoder_workspace(dd, DEV)
+    ws_a.zero_()
+    pk = ops.decoder_pair_pack_desc(dd, ws_a)
+    assert pk is not None and pk.H == H
+    params0 = dec_params_from_oracle(p, theta, dims, DEV)
+    ops.decoder_pair_prep(dd, params0, ws_a)
+    ops.adam_rank_multi([[W, m, v, gf, af, na, nb, whh_next]], coef, 1e-3, 1, packs=[pk])
+    # the same theta with that W_hh through the ordinary forward (its own prep launch packs)
+    theta2 = theta.clone().to(DEV)
+    off = 3 * H * (dims.E + dims.F)
+    theta2[off:off + rows] = whh_next
+    params = dec_params_from_oracle(p, theta2.cpu(), dims, DEV)
+    ws_b = ops.decoder_workspace(dd, DEV)
+    ws_b.zero_()
+    ref_logits, _ = ops.decoder_forward(dd, params, feats, caps, ws_b)
+    o = pk.wp - ws_a.data_ptr()
+    n = 2 * pk.hrows * pk.pitch * 4
+    assert torch.equal(ws_a[o:o + n], ws_b[o:o + n])
+    # and the forward that trusts them (bit 128; bit 8: the prep cleared d Hs)
+    got_logits, _ = ops.decoder_forward(dataclasses.replace(dd, pre=128), params, feats, caps, ws_a)
+    assert torch.equal(got_logits, ref_logits)
+    _, dl = ops.cross_entropy_fwd_bwd(ref_logits.clone(), caps, 0)
+    ga = {n_: torch.full(s, float("nan"), device=DEV) for n_, s in dd.param_shapes().items()}
+    gb = {n_: torch.full(s, float("nan"), device=DEV) for n_, s in dd.param_shapes().items()}
+    lib.caphn_tune(13, dims.V)               # deterministic gradients: bit for bit
+    try:
+        ops.decoder_backward(dd, params, feats, caps, dl.clone(), ga, ws_a)
+        ops.decoder_backward(dd, params, feats, caps, dl.clone(), gb, ws_b)
+    finally:
+        lib.caphn_tune(13, 0)
+    for n_ in ga:
+        assert torch.equal(ga[n_], gb[n_]), n_
+    assert ops.device_error() == 0
