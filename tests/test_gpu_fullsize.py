@@ -239,3 +239,42 @@ def test_catr_transformer_full_size_against_torch_modules():
     assert rel(gsrc, src.grad) < 5e-3
     errs = sorted(rel(got[k], p.grad) for k, p in net.named_parameters())
     assert errs[len(errs) // 2] < 1e-3 and errs[-1] < 1e-2, (errs[len(errs) // 2], errs[-1])
+
+
+def test_full_size_announced_steps_follow_the_plain_trajectory():
+    """Canonical size, three optimiser steps over two alternating minibatches and styles: step() with the next minibatch announced
+    (next theta out of the Adam pass, the split front of the next forward beside the rank-1 passes, the W_hh pass writing the pair
+    kernels' packed weights, d theta cleared by the passes -- FusedTrainer.overlap_level 4) against the plain step() that does none of
+    it.  Same losses and parameters up to the fp32 atomics both paths share (split-K weight gradients, embedding scatter)."""
+    from hypernet_attention import HyperNet
+    from caphn.engine import FusedTrainer
+    dims = O.Dims()
+    p = O.init_params(dims, 11)
+    batches = [O.synth_batch(dims, 128, 20, 49, seed=12 + i) for i in range(2)]
+    dev = [(b["features"].to(DEV), b["captions"].to(DEV)) for b in batches]
+    toks = [4, 5]
+
+    def trainer():
+        net = HyperNet(dims.F, dims.E, dims.H, dims.V, _Vocab())
+        net.load_state_dict(p, strict=False)
+        return FusedTrainer(net.to(DEV), lr=1e-3, max_norm=5.0)
+    ta = trainer()
+    la = [float(ta.step(*dev[i % 2], style_token=toks[i % 2])[0]) for i in range(3)]
+    pa = (ta.flat_p.clone(), [w.data.clone() for w in ta.W2])
+    del ta
+    torch.cuda.empty_cache()
+    tb = trainer()
+    assert tb.overlap_level == 4
+    lb = []
+    for i in range(3):
+        nf, nc = dev[(i + 1) % 2]
+        lb.append(float(tb.step(*dev[i % 2], style_token=toks[i % 2], next_style_token=toks[(i + 1) % 2], next_features=nf,
+                                next_captions=nc)[0]))
+        assert tb._pre_key is not None and tb._pre_key[-1] == 3 and tb._pair_packed is not None
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-5, (la, lb)
+    assert la[-1] < la[0]
+    assert maxdiff(pa[0].cpu(), tb.flat_p.cpu()) < 3e-5
+    for a, b in zip(pa[1], tb.W2):
+        assert maxdiff(a.cpu(), b.data.cpu()) < 3e-5
+    from caphn import ops
+    assert ops.device_error() == 0
