@@ -83,7 +83,9 @@ def _worker(rank, world, port, same_batch, q, flickr=False, backend="gloo", step
         for _ in range(steps):
             if flickr:      # bench.py's configuration: next-step theta in the Adam pass + next precompute on a side stream
                 tok = 4 + rank
-                l = tr.step(feats_dev, caps_dev, style_token=tok, next_style_token=tok, next_features=feats_dev)
+                # (captions announced too: the split front -- G / gate GEMM beside the last rank-1 pass, packed W_hh from that pass)
+                l = tr.step(feats_dev, caps_dev, style_token=tok, next_style_token=tok, next_features=feats_dev, next_captions=caps_dev)
+                assert tr._pre_key is not None and tr._pre_key[-1] == 3
             else:
                 l = tr.step(batch["features"].cuda(), batch["captions"].cuda(), x_style=x)
             losses.append(float(l[0]))
@@ -181,7 +183,7 @@ def _single_process_reference(flickr, steps=4):
     losses = []
     for _ in range(steps):
         if flickr:
-            losses.append(float(tr.step(f, c, style_token=4, next_style_token=4, next_features=f)[0]))
+            losses.append(float(tr.step(f, c, style_token=4, next_style_token=4, next_features=f, next_captions=c)[0]))
         else:
             losses.append(float(tr.step(f, c, x_style=x)[0]))
     return losses, torch.cat([tr.flat_p] + [w.data.flatten() for w in tr.W2]).cpu()
