@@ -582,6 +582,9 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
                     if (row0 + i < rows) const_cast<float*>(gfac)[row0 + i] = 0.f;
             }
         }
+        float dots[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) dots[i] = 0.f;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             if (row0 + i >= rows) continue;
@@ -614,9 +617,38 @@ __device__ __forceinline__ void adam_rank_rows(int R, int rows, int k, float* W,
                     else { *qw = po; *qm = mo; *qv = vo; }
                 }
             }
-            if (nx.a) {                      // wave-uniform
-                dot = wave_sum(dot);
-                if (lane == 0) next_store(nx, row0 + i, dot + nx.bias[row0 + i]);
+            if (nx.a) dots[i] = wave_sum(dot);          // (wave-uniform)
+        }
+        if (nx.a && lane == 0) {
+            // the RB rows' results leave in ONE store each for theta and for the packed copy when the block is whole and aligned
+            // (scalar write-through stores are one fabric write each: 120 000 + 120 000 of them cost the W_hh pass ~10 us)
+            bool vec_ok = row0 + RB <= rows && ((reinterpret_cast<uintptr_t>(nx.theta + row0) & (sizeof(float) * RB - 1)) == 0) &&
+                          (RB == 2 || RB == 4);
+            if (vec_ok && nx.pack) vec_ok = (nx.pH % RB) == 0 && (nx.ppitch % RB) == 0 && (reinterpret_cast<uintptr_t>(nx.pack) & 15) == 0;
+            if (vec_ok) {
+                float vals[RB];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) vals[i] = dots[i] + nx.bias[row0 + i];
+                float* pd = nullptr;
+                if (nx.pack) {
+                    const int R = row0 / nx.pH, c = row0 - R * nx.pH, q = R / nx.pH, j = R - q * nx.pH;
+                    const int hh = j >= nx.pHA ? 1 : 0, kk = j - (hh ? nx.pHA : 0), nk = hh ? nx.pH - nx.pHA : nx.pHA;
+                    pd = nx.pack + ((size_t)hh * nx.phrows + (size_t)(q + 1) * nk + kk) * nx.ppitch + c;
+                }
+                if constexpr (RB == 4) {
+                    const f32x4 v4 = {vals[0], vals[1], vals[2], vals[3]};
+                    *reinterpret_cast<f32x4*>(nx.theta + row0) = v4;
+                    if (pd) *reinterpret_cast<f32x4*>(pd) = v4;
+                } else if constexpr (RB == 2) {
+                    typedef float f32x2v __attribute__((ext_vector_type(2)));
+                    const f32x2v v2 = {vals[0], vals[1]};
+                    *reinterpret_cast<f32x2v*>(nx.theta + row0) = v2;
+                    if (pd) *reinterpret_cast<f32x2v*>(pd) = v2;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+                    if (row0 + i < rows) next_store(nx, row0 + i, dots[i] + nx.bias[row0 + i]);
             }
         }
     }
