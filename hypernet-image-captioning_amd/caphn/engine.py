@@ -747,6 +747,8 @@ class FusedTrainer:
         # (W_ih, b_ih -- heads 0, 2; and the tiny b_hh head) first, then the side stream starts the next forward's
         # front end while the W_hh pass (head 1, HBM-bound) is still streaming.
         order = [0, 2, 3, 1] if (full or split) else list(range(len(segs)))
+        # (measured and dropped: W_hh and the bias passes FIRST with the front beside them and the W_ih pass last and alone -- G and the
+        #  gate GEMM then sit between the last pass and the recurrent kernel: 1.636/1.661 against 1.585/1.600 ms, same box)
         fork_after = order[-2] if full else self.overlap_after_head
         if next_batch is not None and not full and not early and self.overlap_after_head < 0:
             self._precompute_next(*next_batch, level=1)
