@@ -128,6 +128,8 @@ class FusedTrainer:
         self.zero_by_adam = os.environ.get("CAPHN_ZERO_BY_ADAM", "1") == "1"
         self._zero_lo_by_adam = False
         self._aux_joined = False
+        self._acts_ev = None
+        self.bias_heads_aside = os.environ.get("CAPHN_BIAS_HEADS_ASIDE", "1") == "1"
         self._pair_packed = None
         self.pack_in_adam = os.environ.get("CAPHN_PACK_IN_ADAM", "1") == "1"
         self._fork0_ev = None
@@ -764,14 +766,31 @@ class FusedTrainer:
         # one rank, the row factor is d theta in the arena itself: every pass clears its rows behind the read (it is their last
         # reader), so the next forward has no fill of d theta to launch in front of its recurrent kernel
         zg = self.zero_by_adam and R == 1 and not dp.active(self.group) and self.theta_size % 4 == 0
-        for members, _ in groups:
-            jobs = []
+
+        def jobs_of(members):
+            out = []
             for i in members:
                 gi, ai, o, w, ao, an = segs[i]
                 job = [self.W2[i].data, self.W2_m[i], self.W2_v[i], gi, ai]
                 if prefetch:
                     job += [self._acts_next[ao:ao + an], self._owned[f"hn_heads.{i}.2.bias"].data, self._theta_next[o:o + w]]
-                jobs.append(job)
+                out.append(job)
+            return out
+        if early and self.bias_heads_aside and len(groups) == 3 and groups[1][1] and not groups[0][1] and not groups[2][1]:
+            # split front: the two bias heads' launch leaves the caller's stream -- it needs the clip coefficient and the next
+            # activations only, so it runs on the caption-side stream beside the W_ih pass (b_ih is then ready long before the gate
+            # GEMM behind that pass wants it), and the W_ih and W_hh passes follow each other directly
+            if self._acts_ev is None:
+                self._acts_ev = torch.cuda.Event()
+            self._acts_ev.record()
+            self._aux_stream.wait_event(self._acts_ev)
+            with torch.cuda.stream(self._aux_stream):
+                ops.adam_rank_multi(jobs_of(groups[1][0]), self._coef, self.lr, step, self.betas, self.eps, dev_scalars=dev_sc, zero_gfac=zg)
+                self._lookup_done.record(self._aux_stream)
+            groups = [groups[0], groups[2]]
+            order = [order[0], order[-1]]
+        for members, _ in groups:
+            jobs = jobs_of(members)
             if len(jobs) == 1 and pack is not None and members[0] == 1:
                 ops.adam_rank_multi(jobs, self._coef, self.lr, step, self.betas, self.eps, dev_scalars=dev_sc, zero_gfac=zg, packs=[pack])
                 self._pair_packed = (pack.wp, self._theta_next.data_ptr())

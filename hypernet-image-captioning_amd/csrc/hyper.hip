@@ -172,8 +172,9 @@ __global__ __launch_bounds__(256) void gemv_fwd_kernel(GemvJobs jobs) {
 // in LDS (80 k multiply-adds, 320 KB of L2 reads per workgroup: nothing to exchange, no barrier between workgroups) and then its
 // share of the heads' rows; workgroup 0 also stores x, a0 and base.  Per row the arithmetic is gemv_rows_wave's (lane partials
 // over 16-byte chunks in order, wave_sum): results are bit-identical to the three-launch form.
-int g_tune_acts_fused = 0;      // caphn_tune key 28: 1 = one launch (measured: 14.6 us alone against 3 x 3.5 us + two gaps, and in the
-                                // step its 1024-thread workgroups are placed late beside the feature_fc GEMM: +4 us per step), 0 (default) = three launches
+int g_tune_acts_fused = 1;      // caphn_tune key 28: 1 (default) = one launch, 0 = three launches.  With every load of a phase in flight
+                                // (RB = 16) the launch is -10 us per step, alternating blocks in one process (tools/ab_inproc.py, two boxes);
+                                // its first form (four rows per iteration, 25 us alone) was +4
 struct ActsFusedArgs {
     const float* x; int d_in, d_mid, he, nh, rtot;
     const float* w0; const float* b0; const float* w2; const float* b2;
@@ -448,6 +449,7 @@ __global__ __launch_bounds__(256) void outer_kernel(OuterJobs jobs) {
 // kernel have dirtied in the L2.  Every workgroup must become resident for the barriers to complete: the grid is at most 64
 // workgroups and nothing it waits for depends on this stream; the polls are bounded in wall-clock time like the pair kernels'
 // (device error word, CAPHN_ETIMEOUT).  Summation orders are fixed: results are reproducible run to run.
+int g_tune_vjp_blocks = 512;    // caphn_tune key 30: workgroups per head of the transposed GEMV (64 .. 4096)
 int g_tune_hyper_tail = 0;      // caphn_tune key 27: 1 = this kernel, 0 (default) = the five-launch form (measured equal in the step,
                                 // 29 us against 31 us + four gaps alone: the branches behind BPTT are throughput-bound)
 struct TailHead { const float* partial; const float* post; const float* w1; float* g_b1; float* g_w1; int k, nblocks, dzo; };
@@ -750,13 +752,16 @@ static int hyper_forward_impl(const caphn_hyper_desc* d, const float* x, float* 
 namespace {
 struct BwdWs { size_t partial[CAPHN_MAX_HEADS]; int nblocks[CAPHN_MAX_HEADS]; size_t dz[CAPHN_MAX_HEADS];
                size_t dzb2, dzb0, bar, total; };
+constexpr int VJP_BLOCKS_MAX = 4096;
 inline BwdWs bwd_ws(const caphn_hyper_desc* d) {
     BwdWs w; size_t o = 0;
     for (int i = 0; i < d->n_heads; ++i) {
-        int nb = (int)std::min<long>(512, ((long)d->w[i] + 15) / 16);
+        // (the offsets reserve room for VJP_BLOCKS_MAX blocks whatever caphn_tune key 30 says now: a workspace sized earlier stays valid)
+        const long want = ((long)d->w[i] + 15) / 16;
+        int nb = (int)std::min<long>(g_tune_vjp_blocks, want);
         if (nb < 1) nb = 1;
         w.nblocks[i] = nb;
-        w.partial[i] = o; o += caphn_align_up((size_t)nb * d->k[i], 4);
+        w.partial[i] = o; o += caphn_align_up((size_t)std::max<long>(1, std::min<long>(VJP_BLOCKS_MAX, want)) * d->k[i], 4);
     }
     for (int i = 0; i < d->n_heads; ++i) { w.dz[i] = o; o += caphn_align_up(d->k[i], 4); }
     w.dzb2 = o; o += caphn_align_up(d->he, 4);
@@ -921,6 +926,7 @@ extern int g_tune_gemm_order;
 extern int g_tune_branch_mask;
 extern int g_tune_gemm_db;
 extern int g_tune_gemm_ws;
+extern int g_tune_adam_dense_cap;
 extern int g_tune_gemm_waves;
 extern int g_tune_hops;
 extern int g_tune_vocab_order;
@@ -950,6 +956,8 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 26) { g_tune_hops = value != 0; return CAPHN_OK; }
     if (key == 27) { g_tune_hyper_tail = value != 0; return CAPHN_OK; }
     if (key == 28) { g_tune_acts_fused = value != 0; return CAPHN_OK; }
+    if (key == 30) { if (value < 64 || value > 4096) return CAPHN_EINVAL; g_tune_vjp_blocks = value; return CAPHN_OK; }
+    if (key == 31) { if (value < 64 || value > 65535) return CAPHN_EINVAL; g_tune_adam_dense_cap = value; return CAPHN_OK; }
     if (key == 29) { if (value != 0 && value != 64 && value != 128) return CAPHN_EINVAL; g_tune_gemm_ws = value; return CAPHN_OK; }
     if (key == 25) { if (value != 0 && value != 5 && value != 6) return CAPHN_EINVAL; g_tune_gemm_waves = value; return CAPHN_OK; }
     if (key == 24) return caphn_rec_pair_debug_opts(value);

@@ -779,7 +779,10 @@ __global__ __launch_bounds__(256) void rowdot_kernel(int rows, int k, const floa
 }
 
 }  // namespace
-int g_tune_adam_cap = 4096;   // workgroups of one rank-1 Adam launch (grid-stride over rows): fewer leave wave slots for a side stream
+int g_tune_adam_dense_cap = 2048;   // workgroups of the dense arena's Adam launch (caphn_tune key 31)
+int g_tune_adam_cap = 16384;  // workgroups of one rank-1 Adam launch (grid-stride over rows).  Round 3, alternating blocks in one process
+                              // (tools/ab_inproc.py): 4096 -> 8192 -11..-26 us per step, -> 16384 -18..-23, 32768 +12 over 8192 (round 2 only
+                              // ever tried FEWER: 1024 / 2048 were slower too)
 int g_tune_adam = 6;   // measured on 240000x480 after the occupancy fix: 6 (non-temporal, 2 rows/iteration) 497 us,
                        // 3 (non-temporal, 1 row) 508 us, 0 (plain) 541 us
 namespace {
@@ -1352,7 +1355,7 @@ extern "C" int caphn_grad_norm_adam_dense(size_t n, float* p, float* m, float* v
                ce_rows > 0 ? static_cast<const float*>(ce_ws) + 4 : nullptr, static_cast<const float*>(ce_ws), ce_n_valid_dev, loss_out};
     const int vec = caphn_aligned16(p) && caphn_aligned16(m) && caphn_aligned16(v) && caphn_aligned16(g);
     size_t nbk = (n / 4 + 255) / 256;
-    if (nbk > 2048) nbk = 2048;
+    if (nbk > (size_t)g_tune_adam_dense_cap) nbk = (size_t)g_tune_adam_dense_cap;
     if (nbk < 1) nbk = 1;
     hipLaunchKernelGGL(adam_dense_clip_kernel, dim3((unsigned)nbk), dim3(256), 0, s, n, p, m, v, g, nf, make_adam(hp), vec);
     return caphn_launch_status();

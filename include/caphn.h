@@ -599,8 +599,10 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * slower); key 26: 1 = the composites' cross-stream dependencies as stream memory operations instead of events (0 default:
  * measured slower); key 27: 1 = the tail of caphn_hyper_backward behind the transposed GEMV (reduce, three small
  * transposed GEMVs, the small layers' rank-1 gradients) as ONE launch with counter barriers, 0 (default) = five launches (measured
- * equal in the step); key 28: 1 = hn_base and the heads' first layers of caphn_hyper_forward / _forward_acts in ONE launch
- * (bit-identical results), 0 (default) = three launches (measured 4 us faster in the step).
+ * equal in the step); key 28: 1 (default) = hn_base and the heads' first layers of caphn_hyper_forward / _forward_acts in ONE launch
+ * (bit-identical results; -10 us per step), 0 = three launches; key 30: workgroups per head of the hypernet VJP's transposed GEMV
+ * (64..4096, default 512: no effect measured); key 31: workgroups of the dense arena's Adam launch (default 2048: no effect measured).
+ * key 14's default is 16384 since round 3 (measured -18..-23 us per step against 4096).
  * Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 

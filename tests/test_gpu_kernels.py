@@ -175,7 +175,7 @@ def test_hyper_small_layers_in_one_launch_bit_identical(ops):
                 theta, acts = ops.hyper_forward(shape, pd, x)
                 out.append((theta.clone(), acts.clone()))
         finally:
-            L.load().caphn_tune(28, 0)
+            L.load().caphn_tune(28, 1)
         assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
         assert float(out[1][1].abs().sum()) > 0
 

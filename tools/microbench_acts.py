@@ -38,7 +38,7 @@ def main():
     for mode in (0, 1, 0, 1):
         lib.caphn_tune(28, mode)
         print(f"hyper_forward_acts, caphn_tune(28, {mode}): {timeit(lambda: ops.hyper_forward_acts(shape, pd, x, acts)):7.1f} us per call")
-    lib.caphn_tune(28, 0)
+    lib.caphn_tune(28, 1)
     dth = torch.randn(theta.numel(), device=DEV)
     grads = {n: torch.empty(s, device=DEV) for n, s in shape.param_shapes().items() if not n.endswith(".2.weight")}
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
