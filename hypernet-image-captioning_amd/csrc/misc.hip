@@ -1156,6 +1156,8 @@ static int adam_rank_launch(int R, int rows, int k, float* W, float* m, float* v
         if (k <= 256) ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, 1); else if (k <= 512) ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, 2); \
         else if (k <= 1024) ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, 4); else ADAM_RANK_LAUNCH_Q(RB, NTL, NTS, 8); } while (0)
     // caphn_tune(1, v): 0 plain loads/stores, RB=1; 3 (default) non-temporal, RB=1; 6 non-temporal, RB=2
+    // (fused pass, measured in the step with tools/ab_inproc.py and removed again: plain loads and stores +77 us per step, plain stores
+    //  +59, plain loads +76, one row per iteration +90, four rows per iteration for k > 256 -4: profiles/r03_inproc_ab.txt)
     if (nk.a && g_tune_adam != 0) {
         // fused next-theta GEMV: with two (four for short rows) rows per iteration all loads are issued before
         // either row's shuffle reduction
