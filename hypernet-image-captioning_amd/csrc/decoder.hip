@@ -31,6 +31,7 @@ int g_tune_fork = 4;        // 0: one stream; 1: independent branches on side st
                             // the pair kernels run BPTT (512-thread workgroups leave wave slots, registers and 60 KB of LDS per CU
                             // for a GEMM workgroup: 1.987/2.004 -> 1.956/1.958 ms per step), else 1 (a 1024-thread BPTT workgroup
                             // and the GEMM fight for the same CUs: 1-2 % worse, round 1)
+int g_tune_sk_dhs = 0, g_tune_sk_vocab_w = 0;      // experiments (caphn_tune keys 33 / 34): split-K of the two live-row vocabulary GEMMs of the backward, 0 = automatic
 #define RUN(x) do { int _rc = (x); if (_rc != CAPHN_OK) return _rc; } while (0)
 
 namespace {
@@ -344,7 +345,9 @@ inline int gemm_auto(int ta, int tb, int M, int N, int K, const float* A, int ld
 // weight gradient dW = A^T B (A stored [K, M]) with its bias gradient db = column sums of A fused into the GEMM
 inline int wgrad_bias(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* dW, int ldc, float* db,
                       const int* rowmap, void* cws, hipStream_t s, bool prezeroed) {
-    return caphn_gemm_tn_colsum(M, N, K, A, lda, B, ldb, dW, ldc, db, pick_splitk(M, N, K), rowmap, cws, prezeroed, s);
+    int sk = pick_splitk(M, N, K);
+    if (rowmap && g_tune_sk_vocab_w > 0 && !g_tune_deterministic) sk = g_tune_sk_vocab_w;      // (experiment: caphn_tune key 34)
+    return caphn_gemm_tn_colsum(M, N, K, A, lda, B, ldb, dW, ldc, db, sk, rowmap, cws, prezeroed, s);
 }
 
 // feature_fc, init_hidden (+ init_c), W_a f, G = f W_ih[:,E:]^T  -- everything that does not depend on the captions.
@@ -708,7 +711,8 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     bool ctx_side = false;
     if (rmap) {   // rows of ignored targets have d logits == 0: dHs of those rows is zero, the others are gathered
         if (!dhs_zero) RUN(caphn_zero_f32(ws + w.dHs, (size_t)BT * H, s));
-        RUN(caphn_gemm_mapped(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, pick_splitk(BT, H, V),
+        RUN(caphn_gemm_mapped(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0,
+                              (g_tune_sk_dhs > 0 && !g_tune_deterministic) ? g_tune_sk_dhs : pick_splitk(BT, H, V),
                               rmap + 4, rmap, 1, s));
     } else
     RUN(gemm_auto(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, s, nullptr, 0, dhs_zero));

@@ -602,7 +602,8 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * equal in the step); key 28: 1 (default) = hn_base and the heads' first layers of caphn_hyper_forward / _forward_acts in ONE launch
  * (bit-identical results; -10 us per step), 0 = three launches; key 30: workgroups per head of the hypernet VJP's transposed GEMV
  * (64..4096, default 512: no effect measured); key 31: workgroups of the dense arena's Adam launch (default 2048: no effect measured).
- * key 14's default is 16384 since round 3 (measured -18..-23 us per step against 4096).
+ * key 14's default is 16384 since round 3 (measured -18..-23 us per step against 4096); keys 33 / 34 (experiments): split-K of the
+ * backward's two live-row vocabulary GEMMs (dHs, dW_fc), 0 (default) = automatic -- every other value measured equal or slower.
  * Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 
