@@ -31,6 +31,7 @@ int g_tune_fork = 4;        // 0: one stream; 1: independent branches on side st
                             // the pair kernels run BPTT (512-thread workgroups leave wave slots, registers and 60 KB of LDS per CU
                             // for a GEMM workgroup: 1.987/2.004 -> 1.956/1.958 ms per step), else 1 (a 1024-thread BPTT workgroup
                             // and the GEMM fight for the same CUs: 1-2 % worse, round 1)
+int g_tune_join_chain = 0;   // caphn_tune key 35: 1 = the backward's branches 0 and 2 end into branch 1, which alone joins the caller's stream (measured +2..+3 us: off)
 int g_tune_sk_dhs = 0, g_tune_sk_vocab_w = 0;      // experiments (caphn_tune keys 33 / 34): split-K of the two live-row vocabulary GEMMs of the backward, 0 = automatic
 #define RUN(x) do { int _rc = (x); if (_rc != CAPHN_OK) return _rc; } while (0)
 
@@ -127,6 +128,15 @@ struct Side {
         forked[i] = false;
         if (post(D_JOIN + i, st[i]) != CAPHN_OK) return CAPHN_ELAUNCH;
         return await(D_JOIN + i, main);
+    }
+    // branch i ends INTO branch j (j then carries both to main: one wait on the caller's stream instead of two -- every event
+    // operation on that stream is a ~7 us packet between two kernels that would otherwise follow each other without a gap)
+    int join_into(int i, int j) {
+        if (!on || !((g_tune_branch_mask >> i) & 1)) return CAPHN_OK;
+        if (!((g_tune_branch_mask >> j) & 1)) return jointo(i);        // j is folded into the caller's stream
+        forked[i] = false;
+        if (post(D_JOIN + i, st[i]) != CAPHN_OK) return CAPHN_ELAUNCH;
+        return await(D_JOIN + i, st[j]);
     }
     // A composite that returns early (a failed launch) must not leave a branch forked: inside a stream capture an
     // unjoined branch makes hipStreamEndCapture fail (hipErrorStreamCaptureUnjoined) -- every composite holds a Scope.
@@ -866,7 +876,8 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
         RUN(sd.wait(4, b2));
         RUN(wgrad_bias(F, F, BP, ws + w.df, F, ws + w.Y1, F, g->fc2_w, F, g->fc2_b, nullptr, cw2, b2, gz));
     }
-    RUN(sd.jointo(0)); RUN(sd.jointo(1)); RUN(sd.jointo(2));
+    if (g_tune_join_chain) { RUN(sd.join_into(0, 1)); RUN(sd.join_into(2, 1)); RUN(sd.jointo(1)); }
+    else { RUN(sd.jointo(0)); RUN(sd.jointo(1)); RUN(sd.jointo(2)); }
     (void)captions;
     return caphn_launch_status();
 }
