@@ -890,6 +890,11 @@ int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s) {
     if (g.K < 512) tiles128 = 0;
     if (g_tune_gemm_tile == 64) tiles128 = 0; else if (g_tune_gemm_tile == 128) tiles128 = 1 << 20;      // A/B experiments (caphn_tune key 12)
     const bool pl = caphn_gemm_planes_ok(g, ta, tb);
+    if (!pl && g_tune_gemm_single == 0 && g_tune_gemm_tile == 0 && g_tune_gemm_ws == 0) {
+        // short-K NT products (vocabulary logits and the other K = 200 GEMMs of the forward): A's fragments resident in registers
+        const int rc = caphn_gemm_kres_launch(g, ta, tb, s);
+        if (rc != 1) return rc;
+    }
     if (pl) {
         if (tiles128 >= 512) return launch_cfg<128, 128, 1>(g, ta, tb, s);
         return launch_cfg<64, 64, 1>(g, ta, tb, s);

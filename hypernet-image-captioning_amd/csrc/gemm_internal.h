@@ -72,4 +72,6 @@ int caphn_gemm_tn_colsum(int M, int N, int K, const float* A, int lda, const flo
 bool caphn_gemm_planes_ok(const GemmArgs& g, int ta, int tb);
 // split-bf16 back end (gemm_bf16x3.hip): BK = 32
 int caphn_gemm_bf16x3_launch(GemmArgs g, int ta, int tb, hipStream_t s);
+// K-resident NT kernel for short contractions (gemm_kres.hip): CAPHN_OK = launched, 1 = not applicable, else an error
+int caphn_gemm_kres_launch(const GemmArgs& g, int ta, int tb, hipStream_t s);
 extern int g_tune_gemm;     // 0: fp32 MFMA, 1: split-bf16 MFMA

@@ -929,6 +929,7 @@ extern int g_tune_gemm_ws;
 extern int g_tune_adam_dense_cap;
 extern int g_tune_sk_dhs, g_tune_sk_vocab_w;
 extern int g_tune_join_chain;
+extern int g_tune_gemm_kres;
 extern int g_tune_gemm_waves;
 extern int g_tune_hops;
 extern int g_tune_vocab_order;
@@ -958,6 +959,7 @@ extern "C" int caphn_tune(int key, int value) {
     if (key == 26) { g_tune_hops = value != 0; return CAPHN_OK; }
     if (key == 27) { g_tune_hyper_tail = value != 0; return CAPHN_OK; }
     if (key == 28) { g_tune_acts_fused = value != 0; return CAPHN_OK; }
+    if (key == 36) { g_tune_gemm_kres = value != 0; return CAPHN_OK; }
     if (key == 35) { g_tune_join_chain = value != 0; return CAPHN_OK; }
     if (key == 33) { if (value < 0 || value > 64) return CAPHN_EINVAL; g_tune_sk_dhs = value; return CAPHN_OK; }
     if (key == 34) { if (value < 0 || value > 64) return CAPHN_EINVAL; g_tune_sk_vocab_w = value; return CAPHN_OK; }

@@ -603,7 +603,9 @@ int caphn_outer_f32(int rows, int k, const float* g, const float* a, float* out,
  * (bit-identical results; -10 us per step), 0 = three launches; key 30: workgroups per head of the hypernet VJP's transposed GEMV
  * (64..4096, default 512: no effect measured); key 31: workgroups of the dense arena's Adam launch (default 2048: no effect measured).
  * key 14's default is 16384 since round 3 (measured -18..-23 us per step against 4096); keys 33 / 34 (experiments): split-K of the
- * backward's two live-row vocabulary GEMMs (dHs, dW_fc), 0 (default) = automatic -- every other value measured equal or slower.
+ * backward's two live-row vocabulary GEMMs (dHs, dW_fc), 0 (default) = automatic -- every other value measured equal or slower;
+ * key 35: 1 = the backward's side branches end into one another (0 default: measured slower); key 36: 1 = the K = 200 NT products
+ * with N >= 1024 (the vocabulary logits) through the K-resident kernel (0 default: 1.09x alone, +12 us in the step).
  * Defaults are the measured-fastest. */
 int caphn_tune(int key, int value);
 

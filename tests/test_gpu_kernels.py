@@ -54,6 +54,59 @@ def test_gemm_layouts(ops, gemm_backend, ta, tb, M, N, K):
     assert maxdiff(out.cpu(), ref + bias.double()) < tol
 
 
+@pytest.mark.parametrize("M,N", [(300, 1100), (1660, 9684), (129, 1024)])
+def test_gemm_k_resident_variant(ops, M, N):
+    """caphn_tune key 36 (off by default): the K = 200 NT products with A's fragments resident in registers (csrc/gemm_kres.hip) against
+    fp64 and against the general kernel; plain, bias + ReLU, and through a live-row map (the vocabulary projection of the fused
+    step: models/decoderlstm.py:105 over the rows whose target is not <pad>)."""
+    import caphn._lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N)
+    A, B, bias = torch.randn(M, 200, generator=g).to(DEV), (torch.randn(N, 200, generator=g) * 0.07).to(DEV), torch.randn(N, generator=g).to(DEV)
+    ref = A.double() @ B.double().t()
+    try:
+        lib.caphn_tune(36, 0)
+        base = ops.gemm(A, B, False, True, bias=bias, relu=True)
+        lib.caphn_tune(36, 1)
+        out = ops.gemm(A, B, False, True)
+        assert float((out.double() - ref).abs().max()) < 1e-6 * math.sqrt(200) * 4
+        out2 = ops.gemm(A, B, False, True, bias=bias, relu=True)
+        assert float((out2.double() - torch.relu(ref + bias.double())).abs().max()) < 1e-6 * math.sqrt(200) * 4
+        assert maxdiff(out2.cpu(), base.cpu()) < 5e-6
+    finally:
+        lib.caphn_tune(36, 0)
+
+
+def test_gemm_k_resident_variant_in_the_decoder_forward(ops):
+    """The same variant behind caphn_decoder_forward's live-row vocabulary projection (row map from caphn_decoder_prepare_rows)."""
+    import dataclasses
+    import caphn._lib as L
+    from helpers import dec_dims, dec_params_from_oracle
+    lib = L.load()
+    dims = O.Dims(D=32, F=200, E=200, H=200, V=1100, he=6)
+    p = O.init_params(dims, seed=4)
+    x = torch.zeros(dims.he); x[2] = 1.0
+    theta = O.hyper_forward(p, x).detach()
+    batch = O.synth_batch(dims, B=5, T=6, P=7, seed=5)
+    dd = dataclasses.replace(dec_dims(dims, 5, 6, 7), rows=True)
+    params = dec_params_from_oracle(p, theta, dims, DEV)
+    feats, caps = batch["features"].to(DEV), batch["captions"].to(DEV)
+    out = []
+    try:
+        for mode in (0, 1):
+            lib.caphn_tune(36, mode)
+            ws = ops.decoder_workspace(dd, DEV)
+            ops.decoder_prepare_rows(dd, caps, 0, ws)
+            logits = torch.zeros(5, 6, dims.V, device=DEV)
+            ops.decoder_forward(dd, params, feats, caps, ws, logits=logits, want_alphas=False)
+            out.append(logits.clone())
+    finally:
+        lib.caphn_tune(36, 0)
+    live = (caps != 0)
+    assert int(live.sum()) > 0 and maxdiff(out[0][live].cpu(), out[1][live].cpu()) < 2e-6
+    assert torch.equal(out[0][~live], out[1][~live])            # dead rows: untouched by either
+
+
 @pytest.mark.parametrize("K", [96, 200])
 def test_gemm_large_tile_config(ops, gemm_backend, K):
     """>= 1024 128x128 tiles selects the 128x128 kernel (BK = 32 for K = 96, BK = 40 for K = 200)."""
