@@ -129,6 +129,7 @@ class FusedTrainer:
         self._zero_lo_by_adam = False
         self._aux_joined = False
         self._acts_ev = None
+        self.fork_after_acts = os.environ.get("CAPHN_FORK_AFTER_ACTS", "1") == "1"
         self.bias_heads_aside = os.environ.get("CAPHN_BIAS_HEADS_ASIDE", "1") == "1"
         self._pair_packed = None
         self.pack_in_adam = os.environ.get("CAPHN_PACK_IN_ADAM", "1") == "1"
@@ -713,7 +714,9 @@ class FusedTrainer:
         # beside the LAST pass only the two GEMMs that need theta are left (G, x-side gates: done long before the pass ends)
         early = split and self.overlap_level >= 4
         pack = None
-        if early:
+
+        def early_fork():
+            nonlocal early, pack
             self._precompute_next(*next_batch, level=1, lookup_dp=True)
             early = self._pre_key is not None and self._pre_key[1] is not None     # (the captions were looked up)
             if early and self.pack_in_adam:
@@ -727,6 +730,8 @@ class FusedTrainer:
                     with torch.cuda.stream(self._aux_stream):
                         ops.decoder_pair_prep(nbuf["dims"], self._dec_tensors(self._theta, grads=False), nbuf["ws"])
                         self._lookup_done.record(self._aux_stream)
+        if early and not self.fork_after_acts:
+            early_fork()
         if prefetch:
             # the small layers (and the style row of the embedding / the front-end) are already updated: compute the next
             # step's head activations, then let the rank-1 Adam pass emit theta_next = W2' a' + b2' row by row
@@ -745,6 +750,8 @@ class FusedTrainer:
             ops.hyper_forward_acts(self.shape, hp, xn, self._acts_next)
             if self._theta_next is None:
                 self._theta_next = torch.empty(self.theta_size, dtype=torch.float32, device=self.dev)
+        if early and self.fork_after_acts:
+            early_fork()        # (experiment: ONE record on the caller's stream -- behind the next activations -- serves the front and the bias heads)
         # Order of the rank-1 passes when the next minibatch is known: everything the front of the next forward needs
         # (W_ih, b_ih -- heads 0, 2; and the tiny b_hh head) first, then the side stream starts the next forward's
         # front end while the W_hh pass (head 1, HBM-bound) is still streaming.
@@ -780,10 +787,11 @@ class FusedTrainer:
             # split front: the two bias heads' launch leaves the caller's stream -- it needs the clip coefficient and the next
             # activations only, so it runs on the caption-side stream beside the W_ih pass (b_ih is then ready long before the gate
             # GEMM behind that pass wants it), and the W_ih and W_hh passes follow each other directly
-            if self._acts_ev is None:
-                self._acts_ev = torch.cuda.Event()
-            self._acts_ev.record()
-            self._aux_stream.wait_event(self._acts_ev)
+            if not self.fork_after_acts:     # (else: the caption-side stream already waits for a record behind the activations)
+                if self._acts_ev is None:
+                    self._acts_ev = torch.cuda.Event()
+                self._acts_ev.record()
+                self._aux_stream.wait_event(self._acts_ev)
             with torch.cuda.stream(self._aux_stream):
                 ops.adam_rank_multi(jobs_of(groups[1][0]), self._coef, self.lr, step, self.betas, self.eps, dev_scalars=dev_sc, zero_gfac=zg)
                 self._lookup_done.record(self._aux_stream)
