@@ -557,3 +557,56 @@ def test_standalone_bahdanau_attention_forward_backward(B, P, Fd, H):
     with torch.no_grad():
         c2, a2_ = att(feats, hid)
     assert torch.equal(c2, ctx.detach()) and torch.equal(a2_, alpha.detach())
+
+
+def test_announcement_state_machine_under_a_random_schedule():
+    """Sixty steps in which every announcement is drawn at random -- honoured, wrong features, wrong captions, wrong style, only the
+    features, nothing at all, a forward_backward without its optimiser step in between -- against a trainer that never announces
+    anything.  The split front (overlap_level 4), the packed W_hh from the Adam pass, the rank-1 passes clearing d theta and the
+    fall-backs for a batch that did not come as announced must all leave the trajectory alone."""
+    import random
+    from caphn.engine import FusedTrainer
+    from caphn import ops
+    dims = TINY_DIMS["gru_tiny_flickr"]
+    g, p = load_case("gru_tiny_flickr")
+    x, tok = style_args(g)
+    assert tok is not None
+    caps0 = g["captions"].to(DEV)
+    f0 = g["features"].to(DEV)
+    feats = [f0, (f0 * 0.5 + 0.1).contiguous(), (f0 * 1.5 - 0.2).contiguous()]
+    caps = [caps0]
+    for s in (2, 4):
+        c = caps0.clone(); c[:, 2] = (c[:, 2] + s) % dims.V; c[:, 0] = caps0[:, 0]
+        caps.append(c)
+    toks = [tok, (tok + 1) % dims.V or 1, (tok + 2) % dims.V or 2]
+    rng = random.Random(7)
+    sched = [(rng.randrange(3), rng.randrange(3), rng.randrange(3)) for _ in range(61)]
+    ta = FusedTrainer(build_net(dims, p, cc=False), lr=1e-3)
+    tb = FusedTrainer(build_net(dims, p, cc=False), lr=1e-3)
+    assert tb.overlap_level == 4
+    la, lb, kinds = [], [], []
+    for i in range(60):
+        fi, ci, ti = sched[i]
+        nfi, nci, nti = sched[i + 1]
+        kind = rng.choice(["ok", "ok", "ok", "wrong_f", "wrong_c", "wrong_s", "features_only", "none", "extra_fb"])
+        kinds.append(kind)
+        la.append(float(ta.step(feats[fi], caps[ci], style_token=toks[ti])[0]))
+        kw = {}
+        if kind in ("ok", "extra_fb"):
+            kw = dict(next_style_token=toks[nti], next_features=feats[nfi], next_captions=caps[nci])
+        elif kind == "wrong_f":
+            kw = dict(next_style_token=toks[nti], next_features=feats[(nfi + 1) % 3], next_captions=caps[nci])
+        elif kind == "wrong_c":
+            kw = dict(next_style_token=toks[nti], next_features=feats[nfi], next_captions=caps[(nci + 1) % 3])
+        elif kind == "wrong_s":
+            kw = dict(next_style_token=toks[(nti + 1) % 3], next_features=feats[nfi], next_captions=caps[nci])
+        elif kind == "features_only":
+            kw = dict(next_features=feats[nfi])
+        lb.append(float(tb.step(feats[fi], caps[ci], style_token=toks[ti], **kw)[0]))
+        if kind == "extra_fb":       # a forward_backward whose optimiser step never comes (validation-style), on both trainers
+            ta.forward_backward(feats[nfi], caps[nci], style_token=toks[nti])
+            tb.forward_backward(feats[nfi], caps[nci], style_token=toks[nti])
+    worst = max(abs(a - b) for a, b in zip(la, lb))
+    assert worst < 5e-5, (worst, [(k, a, b) for k, a, b in zip(kinds, la, lb) if abs(a - b) > 5e-5][:5])
+    assert maxdiff(ta.flat_p.cpu(), tb.flat_p.cpu()) < 5e-4
+    assert ops.device_error() == 0
