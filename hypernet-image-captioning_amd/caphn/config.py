@@ -11,6 +11,11 @@ DETACH_THETA = False
 # torch.optim.Adam over dense gradients (the hypernet backward then materialises dW2, 4 B per hypernet parameter).
 TORCH_OPTIMIZER = False
 
+# The module API's decoder forward range-checks the caption token ids on the host before it launches (an out-of-range id must raise
+# IndexError as torch's nn.Embedding does on the CPU, not fault on the device).  The check is one device-to-host synchronisation per
+# forward: the host cannot run ahead of the GPU across it.  False: skip it (a loader that guarantees 0 <= id < vocab_size).
+VALIDATE_TOKENS = True
+
 
 def make_adam(params, lr, hypernet=None, max_norm=None):
     """The optimiser the reference builds at hypernet_attention.py:131 / cc_train_hypernet.py:120 / hypernet.py:121."""

@@ -21,7 +21,8 @@ class _DecoderFn(torch.autograd.Function):
         features = features.detach().contiguous()
         captions = captions.contiguous()
         ws = ops.decoder_workspace(dims, features.device)
-        logits, alphas = ops.decoder_forward(dims, params, features, captions, ws)
+        from . import config
+        logits, alphas = ops.decoder_forward(dims, params, features, captions, ws, validate=config.VALIDATE_TOKENS)
         # saved through autograd: a parameter updated in place between forward and backward is detected (version check)
         ctx.save_for_backward(features, captions, *tensors)
         ctx.dims, ctx.ws = dims, ws

@@ -80,13 +80,20 @@ class HyperNetCC(_Base):
     def style_embedding(self, domain):
         """cc_train_hypernet.py:136-149: the hypernet's input row for one domain name."""
         dev = self._device()
+        # (the per-domain input tensors are made once per device: built from Python data they are host-to-device copies the host waits for)
+        cache = self.__dict__.setdefault("_style_in_cache", {})
+        key = (domain, str(dev))
         if self.embedding == 'embedding':
-            idx = torch.tensor(self.dict_domain[domain], dtype=torch.long, device=dev)
-            return self.embed(idx)
+            if key not in cache:
+                cache[key] = torch.tensor(self.dict_domain[domain], dtype=torch.long, device=dev)
+            return self.embed(cache[key])
         if self.embedding == 'one hot':
-            return self.embed[self.dict_domain[domain]].to(device=dev, dtype=torch.float32)
-        feats = torch.tensor(self.dict_domain[domain], dtype=torch.float32, device=dev)
-        return self.embed(feats)
+            if key not in cache:
+                cache[key] = self.embed[self.dict_domain[domain]].to(device=dev, dtype=torch.float32)
+            return cache[key]
+        if key not in cache:
+            cache[key] = torch.tensor(self.dict_domain[domain], dtype=torch.float32, device=dev)
+        return self.embed(cache[key])
 
     def domain_input(self, domain):
         """What FusedTrainer.from_cc(self).step(..., domain_input=...) takes for one domain name: the embedding index, or the

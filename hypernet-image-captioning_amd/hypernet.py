@@ -108,7 +108,11 @@ class HyperNet(_Base):
         the text metrics.  The loss has no ignore_index here (:146)."""
         imgs, (style, (caps, lengths)) = train_batch
         dev = self.captioner.embed.weight.device
-        style = torch.tensor([self.vocab(style)], dtype=torch.long, device=dev)
+        cache = self.__dict__.setdefault("_style_id_cache", {})       # (a tensor from a Python list is a host-to-device copy the host waits for)
+        key = (style, str(dev))
+        if key not in cache:
+            cache[key] = torch.tensor([self.vocab(style)], dtype=torch.long, device=dev)
+        style = cache[key]
         style_embed = self.captioner.embed(style)
         self.forward(style_embed)
         img_feats = self.image_encoder(imgs.float())
