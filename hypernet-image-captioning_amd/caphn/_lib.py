@@ -34,7 +34,8 @@ class HyperGrads(C.Structure):
 
 class DecoderDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "T", "P", "D", "F", "E", "H", "V", "cell", "raw_features", "row_subset",
-                                         "grads_zeroed", "precomputed", "layers")] + [("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
+                                         "grads_zeroed", "precomputed", "layers")] + [("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
+                                                                                       ("logits_ld", C.c_int)]
 
 
 _DEC_FIELDS = ("fc0_w", "fc0_b", "fc2_w", "fc2_b", "embed_w", "out_w", "out_b", "Wa_w", "Wa_b",
@@ -160,6 +161,7 @@ SIGNATURES = {
     "caphn_attention_bwd": (C.c_int, [C.POINTER(AttnDims), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "caphn_ce_workspace_bytes": (C.c_size_t, [C.c_int]),
     "caphn_cross_entropy_rows": (C.c_int, [C.c_int, C.c_int, c_fp, c_fp, C.c_int64, c_fp, C.c_int, c_fp, c_fp, c_fp]),
+    "caphn_cross_entropy_rows_ld": (C.c_int, [C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_int64, c_fp, C.c_int, c_fp, c_fp, c_fp]),
     "caphn_cross_entropy_finish": (C.c_int, [C.c_int, c_fp, c_fp, c_fp, c_fp]),
     "caphn_decoder_profile_ptr": (C.c_void_p, [C.POINTER(DecoderDims), c_fp]),
     "caphn_decoder_rowcount_ptr": (C.c_void_p, [C.POINTER(DecoderDims), c_fp]),

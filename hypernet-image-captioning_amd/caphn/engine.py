@@ -129,6 +129,7 @@ class FusedTrainer:
         self._zero_lo_by_adam = False
         self._aux_joined = False
         self._acts_ev = None
+        self.pad_logits = os.environ.get("CAPHN_PAD_LOGITS", "1") == "1"
         self.fork_after_acts = os.environ.get("CAPHN_FORK_AFTER_ACTS", "1") == "1"
         self.bias_heads_aside = os.environ.get("CAPHN_BIAS_HEADS_ASIDE", "1") == "1"
         self._pair_packed = None
@@ -280,8 +281,14 @@ class FusedTrainer:
             import dataclasses
             # gz: the gradient arena is cleared once per step (forward_backward), not tensor by tensor
             dims = dataclasses.replace(self.cap.dec_dims(B, T, P), rows=self.skip_ignored_rows, gz=True)
+            # the logits / d logits buffer is the trainer's own: its row pitch is padded to whole 128-byte lines (V = 9684: every
+            # 128-byte store of the logits GEMM straddled two lines, every d logits row of the two backward GEMMs started mid-line;
+            # tools/microbench_logits_pitch.py: logits -5 us, dHs -12 us, dW_fc -5 us)
+            ld = (dims.V + 31) // 32 * 32 if self.pad_logits else dims.V
+            if ld != dims.V:
+                dims = dataclasses.replace(dims, logits_ld=ld)
             b = {"dims": dims, "ws": ops.decoder_workspace(dims, self.dev),
-                 "logits": torch.empty(B, T, dims.V, dtype=torch.float32, device=self.dev),
+                 "logits": torch.empty(B, T, ld, dtype=torch.float32, device=self.dev),
                  "alphas": torch.empty(B, T, P, dtype=torch.float32, device=self.dev),
                  "loss": torch.zeros(2, dtype=torch.float32, device=self.dev),
                  "ce_ws": ops.ce_workspace(B * T, self.dev)}
@@ -512,7 +519,7 @@ class FusedTrainer:
         # on the device waits for it; step() joins it at the end)
         cnt = buf["cnt_ptr"] if dims.rows else None
         ops.cross_entropy_rows(buf["logits"], captions, 0, buf["logits"], buf["ce_ws"], leave_ignored_rows=dims.rows,
-                               n_valid_ptr=cnt)
+                               n_valid_ptr=cnt, V=dims.V)
         dlogits = buf["logits"]
         # (the reduction of the per-row losses used to run on the side stream; the two events that took -- a record on
         #  this stream, a wait at the end of the backward -- cost the chain more than the 6 us kernel does in line)

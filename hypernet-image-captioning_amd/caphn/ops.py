@@ -317,6 +317,7 @@ class DecDims:
     layers: int = 1          # AttentionGru(num_layers): extra GRUCells h = layer(h, h) per time step (GRU only)
     drop_p: float = 0.0      # dropout on h_t in training mode (caphn_decoder_dims.dropout_p); the backward needs the same seed
     seed: int = 0
+    logits_ld: int = 0       # row pitch of the logits / d logits buffer (caphn_decoder_dims.logits_ld); 0 = V, contiguous [B,T,V]
 
     @property
     def NG(self) -> int:
@@ -325,7 +326,7 @@ class DecDims:
     def c(self) -> L.DecoderDims:
         return L.DecoderDims(self.B, self.T, self.P, self.D, self.F, self.E, self.H, self.V,
                              1 if self.cell == "lstm" else 0, int(self.raw), int(self.rows), int(self.gz), int(self.pre),
-                             int(self.layers), float(self.drop_p), int(self.seed) & (2 ** 64 - 1))
+                             int(self.layers), float(self.drop_p), int(self.seed) & (2 ** 64 - 1), int(self.logits_ld))
 
     def fields(self):
         """Ordered (C struct field, parameter name) pairs this configuration uses."""
@@ -502,12 +503,16 @@ def decoder_forward(dims: DecDims, params: Dict[str, torch.Tensor], features: to
     ps = _dec_struct(L.DecoderParams, dims, params)
     dev = features.device
     if logits is None:
-        logits = _f32(dims.B, dims.T, dims.V, device=dev)
+        logits = _f32(dims.B, dims.T, dims.logits_ld or dims.V, device=dev)
+    elif logits.numel() < dims.B * dims.T * (dims.logits_ld or dims.V):
+        raise L.CaphnError(f"logits buffer of {logits.numel()} floats is too small for {dims}")
     if alphas is None and want_alphas:          # want_alphas=False: the attention maps stay in the workspace (no copy out)
         alphas = _f32(dims.B, dims.T, dims.P, device=dev)
     L.check(lib.caphn_decoder_forward(C.byref(cd), C.byref(ps), L.ptr(features), L.ptr(captions, torch.int64),
                                       L.ptr(logits), L.ptr(alphas, allow_none=True), C.c_void_p(ws.data_ptr()), L.stream_ptr()),
             "caphn_decoder_forward")
+    if dims.logits_ld and dims.logits_ld != dims.V and logits.shape[-1] == dims.logits_ld:
+        return logits[..., :dims.V], alphas          # (a view: rows are logits_ld floats apart)
     return logits, alphas
 
 
@@ -631,15 +636,19 @@ def cross_entropy_fwd_bwd(logits: torch.Tensor, targets: torch.Tensor, ignore_in
 
 
 def cross_entropy_rows(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int, dlogits: torch.Tensor,
-                       ws: torch.Tensor, leave_ignored_rows: bool = False, n_valid_ptr: Optional[int] = None) -> None:
-    """Stage 1 of the loss: d logits (may alias logits) and per-row losses into ws; cross_entropy_finish reduces them."""
+                       ws: torch.Tensor, leave_ignored_rows: bool = False, n_valid_ptr: Optional[int] = None, V: Optional[int] = None) -> None:
+    """Stage 1 of the loss: d logits (may alias logits) and per-row losses into ws; cross_entropy_finish reduces them.
+    V: the vocabulary size when the buffers' last dimension is a PADDED row pitch (DecDims.logits_ld) -- rows are then
+    logits.shape[-1] floats apart and hold V logits each."""
     lib = L.load()
-    V = logits.shape[-1]
-    rows = logits.numel() // V
-    L.check(lib.caphn_cross_entropy_rows(rows, V, L.ptr(logits), L.ptr(targets.reshape(-1), torch.int64), ignore_index,
-                                         L.ptr(dlogits), int(leave_ignored_rows),
-                                         C.c_void_p(n_valid_ptr) if n_valid_ptr else None, C.c_void_p(ws.data_ptr()),
-                                         L.stream_ptr()), "caphn_cross_entropy_rows")
+    ld = logits.shape[-1]
+    rows = logits.numel() // ld
+    V = ld if V is None else int(V)
+    assert dlogits.shape[-1] == ld and V <= ld
+    L.check(lib.caphn_cross_entropy_rows_ld(rows, V, ld, L.ptr(logits), L.ptr(targets.reshape(-1), torch.int64), ignore_index,
+                                            L.ptr(dlogits), int(leave_ignored_rows),
+                                            C.c_void_p(n_valid_ptr) if n_valid_ptr else None, C.c_void_p(ws.data_ptr()),
+                                            L.stream_ptr()), "caphn_cross_entropy_rows_ld")
 
 
 def cross_entropy_finish(rows: int, ws: torch.Tensor, out: torch.Tensor, n_valid_ptr: Optional[int] = None) -> None:

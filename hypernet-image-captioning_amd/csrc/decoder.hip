@@ -304,6 +304,7 @@ inline bool dims_ok(const caphn_decoder_dims* d) {
     if (d->raw_features && d->F != d->D) return false;
     if (d->layers < 0 || d->layers > CAPHN_MAX_DEC_LAYERS) return false;
     if (d->layers > 1 && d->cell != CAPHN_CELL_GRU) return false;      // the reference's AttentionLstm has no extra layers
+    if (d->logits_ld != 0 && d->logits_ld < d->V) return false;
     return true;
 }
 inline bool layer_params_ok(const caphn_decoder_dims* d, const caphn_decoder_params* p) {
@@ -635,11 +636,12 @@ extern "C" int caphn_decoder_forward(const caphn_decoder_dims* d, const caphn_de
     if ((pc & 8) && !pair) RUN(caphn_zero_f32(ws + w.dHs, (size_t)BT * H, s));      // (the pair path folded it into its prep kernel)
 
     // vocab projection for all (b,t) at once      decoderlstm.py:105
+    const int LV = d->logits_ld > 0 ? d->logits_ld : V;       // row pitch of the caller's logits buffer
     if (d->row_subset)     // only rows with a live target (caphn_decoder_prepare_rows)
-        RUN(caphn_gemm_mapped(0, 1, BT, V, H, ws + w.Hs, H, p->out_w, H, logits, V, p->out_b, CAPHN_GEMM_BIAS, 1,
+        RUN(caphn_gemm_mapped(0, 1, BT, V, H, ws + w.Hs, H, p->out_w, H, logits, LV, p->out_b, CAPHN_GEMM_BIAS, 1,
                               reinterpret_cast<const int*>(ws + w.rowmap) + 4, reinterpret_cast<const int*>(ws + w.rowmap), 1, s));
     else
-        RUN(caphn_gemm_f32(0, 1, BT, V, H, ws + w.Hs, H, p->out_w, H, logits, V, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
+        RUN(caphn_gemm_f32(0, 1, BT, V, H, ws + w.Hs, H, p->out_w, H, logits, LV, p->out_b, nullptr, 0, CAPHN_GEMM_BIAS, 1, s));
     // bit 32 (given to the forward AND the backward of a training step): the context vectors ctx_t = sum_p alpha_tp f_p -- the
     // second operand of dW_ih, which the forward never forms (it uses G) -- are left beside the embeddings now, behind the logits
     // GEMM, instead of in front of the dW_ih GEMM on the backward's chain to d theta
@@ -708,24 +710,25 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     // vocab projection.  dHs = dlogits W feeds BPTT (main); dW = dlogits^T Hs and db = colsum(dlogits) are only
     // needed by the optimiser: branch 0 computes them beside the BPTT kernel, which occupies B of the 256 CUs.
     const int* rmap = d->row_subset ? reinterpret_cast<const int*>(ws + w.rowmap) : nullptr;
+    const int LV = d->logits_ld > 0 ? d->logits_ld : V;       // row pitch of the caller's d logits buffer
     const int fork_mode = g_tune_fork == 4 ? (pair ? 2 : 1) : g_tune_fork;
     const bool late = fork_mode != 2;
     const bool gz = d->grads_zeroed != 0;
     const bool wg_first = !late && g_tune_vocab_order == 0;     // vocabulary gradients beside the dHs GEMM (and BPTT after it)
     if (wg_first) {
         RUN(sd.forkto(0));
-        RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, sd.s(0), gz));
+        RUN(wgrad_bias(V, H, BT, dlogits, LV, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, sd.s(0), gz));
         RUN(sd.milestone(CAPHN_MS_VOCAB, sd.s(0)));
     }
     const bool dhs_zero = (d->precomputed & 8) != 0;      // the forward of this step left d Hs zero-filled (dims.precomputed bit 8)
     bool ctx_side = false;
     if (rmap) {   // rows of ignored targets have d logits == 0: dHs of those rows is zero, the others are gathered
         if (!dhs_zero) RUN(caphn_zero_f32(ws + w.dHs, (size_t)BT * H, s));
-        RUN(caphn_gemm_mapped(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0,
+        RUN(caphn_gemm_mapped(0, 0, BT, H, V, dlogits, LV, p->out_w, H, ws + w.dHs, H, nullptr, 0,
                               (g_tune_sk_dhs > 0 && !g_tune_deterministic) ? g_tune_sk_dhs : pick_splitk(BT, H, V),
                               rmap + 4, rmap, 1, s));
     } else
-    RUN(gemm_auto(0, 0, BT, H, V, dlogits, V, p->out_w, H, ws + w.dHs, H, nullptr, 0, s, nullptr, 0, dhs_zero));
+    RUN(gemm_auto(0, 0, BT, H, V, dlogits, LV, p->out_w, H, ws + w.dHs, H, nullptr, 0, s, nullptr, 0, dhs_zero));
     if (!late && !wg_first) {
         // ... or only beside BPTT: dHs = dlogits W_fc sits on the chain into BPTT and ran 135 instead of ~105 us with the
         // vocabulary gradients streaming the same 99 MB of d logits next to it; BPTT alone is long enough to cover them
@@ -740,7 +743,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
             ctx_side = true;
         } else
         RUN(sd.forkto(0));
-        RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, sd.s(0), gz));
+        RUN(wgrad_bias(V, H, BT, dlogits, LV, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, sd.s(0), gz));
         RUN(sd.milestone(CAPHN_MS_VOCAB, sd.s(0)));
     }
 
@@ -793,7 +796,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
     const bool hold_big = late && !raw && fork_mode == 3;   // 3: release the two big leaves only once df exists (measured: no gain)
     RUN(sd.fork_many({0, 1, 2}));
     if (late && !hold_big) {   // the optimiser-only vocab gradients
-        RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0, gz));
+        RUN(wgrad_bias(V, H, BT, dlogits, LV, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0, gz));
         RUN(sd.milestone(CAPHN_MS_VOCAB, b0));
     }
     // sT -- input weights dW_ih = dgi^T [Xe | ctx] (ctx lands beside the embeddings, so this is ONE GEMM: two back to back on the
@@ -856,7 +859,7 @@ static int decoder_backward_impl(const caphn_decoder_dims* d, const caphn_decode
             // df_kernel in the kernel trace), so the latency-critical front of the chain runs first; the optimiser-only
             // vocab gradients (b0) and the hypernet VJP (sT) start here, beside the two remaining chain GEMMs.
             RUN(sd.wait(4, b0));
-            RUN(wgrad_bias(V, H, BT, dlogits, V, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0, gz));
+            RUN(wgrad_bias(V, H, BT, dlogits, LV, ws + w.Hs, H, g->out_w, H, g->out_b, rmap, cws, b0, gz));
             RUN(sd.milestone(CAPHN_MS_VOCAB, b0));
             if (hook) {
                 RUN(sd.wait(4, sT));
@@ -901,7 +904,7 @@ extern "C" int caphn_decoder_forward_sampled(const caphn_decoder_dims* d, const 
                                              const float* features, const int64_t* captions,
                                              const unsigned char* use_sampling,
                                              float* logits, float* alphas, void* ws_, caphn_stream_t stream) {
-    if (!dims_ok(d) || !p || !features || !captions || !use_sampling || !logits || !ws_) return CAPHN_EINVAL;
+    if (!dims_ok(d) || !p || !features || !captions || !use_sampling || !logits || !ws_ || d->logits_ld != 0) return CAPHN_EINVAL;
     if (d->dropout_p > 0.f) return CAPHN_EINVAL;      // forward only: evaluation, no dropout
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = layout(d);
@@ -965,7 +968,7 @@ extern "C" int caphn_decoder_forward_sampled_train(const caphn_decoder_dims* d, 
                                                    const unsigned char* use_sampling,
                                                    float* logits, float* alphas, void* ws_, caphn_stream_t stream) {
     if (!dims_ok(d) || !p || !features || !captions || !use_sampling || !logits || !ws_) return CAPHN_EINVAL;
-    if (d->row_subset || d->precomputed) return CAPHN_EINVAL;
+    if (d->row_subset || d->precomputed || d->logits_ld != 0) return CAPHN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = layout(d);
     float* ws = static_cast<float*>(ws_);

@@ -21,14 +21,14 @@ __global__ __launch_bounds__(256) void ce_count_kernel(int rows, const int64_t* 
     if (threadIdx.x == 0) nvalid[0] = (float)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
 }
 
-__global__ __launch_bounds__(256) void ce_row_kernel(int V, const float* logits, const int64_t* __restrict__ tgt,
+__global__ __launch_bounds__(256) void ce_row_kernel(int V, int ld, const float* logits, const int64_t* __restrict__ tgt,
                                                      int64_t ignore, const float* __restrict__ nvalid, const int* __restrict__ nvi,
                                                      float* dlogits, float* __restrict__ row_loss, int vec) {
     __shared__ float red[4];
     __shared__ float bc[2];
     const int row = blockIdx.x, tid = threadIdx.x;
-    const float* x = logits + (size_t)row * V;
-    float* dx = dlogits + (size_t)row * V;
+    const float* x = logits + (size_t)row * ld;
+    float* dx = dlogits + (size_t)row * ld;
     const int64_t t = tgt[row];
     if (t == ignore) {                       // ignored rows contribute neither loss nor gradient
         for (int i = tid; i < V; i += 256) dx[i] = 0.f;
@@ -73,14 +73,14 @@ __global__ __launch_bounds__(256) void ce_row_kernel(int V, const float* logits,
 // once and every exponential is evaluated once (the three-pass kernel above re-reads the 38 KB row from L2 twice and
 // evaluates 2 V exponentials).  skip_ignored: with the live-row map nobody reads the d logits rows of ignored targets.
 template <int NV>
-__global__ __launch_bounds__(256) void ce_row_reg_kernel(int V, const float* logits, const int64_t* __restrict__ tgt,
+__global__ __launch_bounds__(256) void ce_row_reg_kernel(int V, int ld, const float* logits, const int64_t* __restrict__ tgt,
                                                          int64_t ignore, const float* __restrict__ nvalid, const int* __restrict__ nvi,
                                                          float* dlogits, float* __restrict__ row_loss, int skip_ignored) {
     __shared__ float red[4];
     __shared__ float bc[2];
     const int row = blockIdx.x, tid = threadIdx.x, V4 = V >> 2;
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(logits + (size_t)row * V);
-    f32x4* d4 = reinterpret_cast<f32x4*>(dlogits + (size_t)row * V);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(logits + (size_t)row * ld);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dlogits + (size_t)row * ld);
     const int64_t t = tgt[row];
     if (t == ignore) {
         if (!skip_ignored) for (int i = tid; i < V4; i += 256) d4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void ce_row_reg_kernel(int V, const float* log
     // LDS in front of the first barrier forces the load to complete there; as a plain register value the compiler may
     // delay the load to its use after the row has been overwritten by other waves (seen: the reported loss off by 0.2 / n)
     __shared__ float xt_s;
-    if (tid == 0) xt_s = logits[(size_t)row * V + t];
+    if (tid == 0) xt_s = logits[(size_t)row * ld + t];
     f32x4 v[NV];
     float m = -INFINITY;
 #pragma unroll
@@ -905,17 +905,22 @@ extern "C" size_t caphn_ce_workspace_bytes(int rows) { return sizeof(float) * (s
 extern "C" int caphn_cross_entropy_rows(int rows, int V, const float* logits, const int64_t* targets, int64_t ignore_index,
                                         float* dlogits, int leave_ignored_rows, const int* n_valid_dev, void* ws,
                                         caphn_stream_t stream) {
-    if (rows <= 0 || V <= 0 || !logits || !targets || !dlogits || !ws) return CAPHN_EINVAL;
+    return caphn_cross_entropy_rows_ld(rows, V, V, logits, targets, ignore_index, dlogits, leave_ignored_rows, n_valid_dev, ws, stream);
+}
+extern "C" int caphn_cross_entropy_rows_ld(int rows, int V, int ld, const float* logits, const int64_t* targets, int64_t ignore_index,
+                                           float* dlogits, int leave_ignored_rows, const int* n_valid_dev, void* ws,
+                                           caphn_stream_t stream) {
+    if (rows <= 0 || V <= 0 || ld < V || !logits || !targets || !dlogits || !ws) return CAPHN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* nvalid = static_cast<float*>(ws);
     float* row_loss = nvalid + 4;
-    const int vec = (V % 4 == 0) && caphn_aligned16(logits) && caphn_aligned16(dlogits);
+    const int vec = (V % 4 == 0) && (ld % 4 == 0) && caphn_aligned16(logits) && caphn_aligned16(dlogits);
     if (!n_valid_dev) hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, rows, targets, ignore_index, nvalid);
     const int nv = vec ? (V / 4 + 255) / 256 : 0;
-    if (nv >= 1 && nv <= 4) hipLaunchKernelGGL(ce_row_reg_kernel<4>, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, n_valid_dev, dlogits, row_loss, leave_ignored_rows);
-    else if (nv > 4 && nv <= 10) hipLaunchKernelGGL(ce_row_reg_kernel<10>, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, n_valid_dev, dlogits, row_loss, leave_ignored_rows);
-    else if (nv > 10 && nv <= 16) hipLaunchKernelGGL(ce_row_reg_kernel<16>, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, n_valid_dev, dlogits, row_loss, leave_ignored_rows);
-    else hipLaunchKernelGGL(ce_row_kernel, dim3(rows), dim3(256), 0, s, V, logits, targets, ignore_index, nvalid, n_valid_dev, dlogits, row_loss, vec);
+    if (nv >= 1 && nv <= 4) hipLaunchKernelGGL(ce_row_reg_kernel<4>, dim3(rows), dim3(256), 0, s, V, ld, logits, targets, ignore_index, nvalid, n_valid_dev, dlogits, row_loss, leave_ignored_rows);
+    else if (nv > 4 && nv <= 10) hipLaunchKernelGGL(ce_row_reg_kernel<10>, dim3(rows), dim3(256), 0, s, V, ld, logits, targets, ignore_index, nvalid, n_valid_dev, dlogits, row_loss, leave_ignored_rows);
+    else if (nv > 10 && nv <= 16) hipLaunchKernelGGL(ce_row_reg_kernel<16>, dim3(rows), dim3(256), 0, s, V, ld, logits, targets, ignore_index, nvalid, n_valid_dev, dlogits, row_loss, leave_ignored_rows);
+    else hipLaunchKernelGGL(ce_row_kernel, dim3(rows), dim3(256), 0, s, V, ld, logits, targets, ignore_index, nvalid, n_valid_dev, dlogits, row_loss, vec);
     return caphn_launch_status();
 }
 extern "C" int caphn_cross_entropy_finish(int rows, const int* n_valid_dev, float* loss_out, void* ws, caphn_stream_t stream) {

@@ -229,6 +229,11 @@ typedef struct caphn_decoder_dims {
                            torch's Philox stream: masks differ from the reference's, parity is pinned with dropout off and,
                            with it on, against the oracle given this mask.  The backward needs the same p and seed. */
     unsigned long long dropout_seed;
+    int logits_ld;      /* row pitch (floats) of the logits / d logits buffer given to caphn_decoder_forward / _backward / _hyper_backward;
+                           0 = V (contiguous [B,T,V], what the module API returns).  A trainer that owns the buffer pads the pitch to a
+                           multiple of 32 floats: the three vocabulary GEMMs then read and write whole 128-byte lines (V = 9684: 38 736
+                           bytes a row, every 128-byte store straddles two lines; measured on the canonical shapes: logits -5 us,
+                           dHs -12 us, dW_fc -5 us).  >= V.  The free-running / sampled / search entry points need 0. */
 } caphn_decoder_dims;
 
 #define CAPHN_MAX_DEC_LAYERS 4
@@ -460,6 +465,9 @@ size_t caphn_ce_workspace_bytes(int rows);
 int caphn_cross_entropy_rows(int rows, int V, const float* logits, const int64_t* targets, int64_t ignore_index,
                              float* dlogits, int leave_ignored_rows, const int* n_valid_dev, void* ws, caphn_stream_t stream);
 int caphn_cross_entropy_finish(int rows, const int* n_valid_dev, float* loss_out, void* ws, caphn_stream_t stream);
+/* caphn_cross_entropy_rows over rows that are `ld` floats apart (ld >= V; caphn_decoder_dims.logits_ld) in logits AND d logits. */
+int caphn_cross_entropy_rows_ld(int rows, int V, int ld, const float* logits, const int64_t* targets, int64_t ignore_index,
+                                float* dlogits, int leave_ignored_rows, const int* n_valid_dev, void* ws, caphn_stream_t stream);
 int caphn_cross_entropy_fwd_bwd(int rows, int V, const float* logits, const int64_t* targets,
                                 int64_t ignore_index, float* dlogits, float* loss_out,
                                 int leave_ignored_rows, void* ws, caphn_stream_t stream);

@@ -31,9 +31,22 @@ def main():
     torch.manual_seed(1234)
     net = HyperNet(F, E, H, V, bench._Vocab()).to(dev)
     tr = FusedTrainer(net, lr=1e-3, max_norm=5.0)
+    trs = None
+    if attr.startswith("init:"):          # a construction-time switch (environment variable): TWO trainers, alternating blocks
+        var = attr.split(":")[1]
+        trs = []
+        for v in (va, vb):
+            os.environ[var] = str(v)
+            torch.manual_seed(1234)
+            trs.append(FusedTrainer(HyperNet(F, E, H, V, bench._Vocab()).to(dev), lr=1e-3, max_norm=5.0))
+        del os.environ[var]
     from caphn import _lib
     lib = _lib.load()
-    if attr.startswith("tune:"):          # a caphn_tune key instead of a trainer attribute
+    cur = [tr]
+    if trs is not None:
+        def setv(v):
+            cur[0] = trs[0] if v == va else trs[1]
+    elif attr.startswith("tune:"):          # a caphn_tune key instead of a trainer attribute
         key = int(attr.split(":")[1])
 
         def setv(v):
@@ -50,9 +63,14 @@ def main():
         for _ in range(n):
             f, c = batches[j[0] % 4]
             nf, nc = batches[(j[0] + 1) % 4]
-            tr.step(f, c, style_token=4 + j[0] % 3, next_style_token=4 + (j[0] + 1) % 3, next_features=nf, next_captions=nc)
+            cur[0].step(f, c, style_token=4 + j[0] % 3, next_style_token=4 + (j[0] + 1) % 3, next_features=nf, next_captions=nc)
             j[0] += 1
-    run(60)
+    if trs is not None:
+        for t in trs:
+            cur[0] = t
+            run(40)
+    else:
+        run(60)
     res = {0: [], 1: []}
     for r in range(rounds):
         for k, v in ((0, va), (1, vb)):
